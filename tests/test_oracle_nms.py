@@ -1,0 +1,83 @@
+"""Known-answer + property tests for oracle/nms.py (torchvision semantics;
+parity unpinned against the reference -- see the module header)."""
+import numpy as np
+
+from oracle import nms as onms
+
+
+def test_hand_cases():
+    boxes = np.array([[0, 0, 10, 10], [1, 1, 11, 11], [20, 20, 30, 30], [0, 0, 10, 10]], dtype=np.float32)
+    scores = np.array([0.9, 0.8, 0.7, 0.95], dtype=np.float32)
+    # box3 (0.95) suppresses box0 (iou 1) and box1 (iou 81/119=0.68>0.5)
+    assert onms.nms(boxes, scores, 0.5).tolist() == [3, 2]
+    # strict '>' : iou exactly equal to thr is kept
+    b = np.array([[0, 0, 2, 2], [1, 0, 3, 2]], dtype=np.float32)  # inter 2, union 6 -> 1/3
+    s = np.array([0.9, 0.8], dtype=np.float32)
+    assert onms.nms(b, s, np.float32(2.0) / np.float32(6.0)).tolist() == [0, 1]
+    assert onms.nms(b, s, 0.33).tolist() == [0]
+    # ties in score: lower index first
+    assert onms.nms(boxes[[0, 2]], np.array([0.5, 0.5], np.float32), 0.5).tolist() == [0, 1]
+    assert onms.nms(np.zeros((0, 4), np.float32), np.zeros((0,), np.float32), 0.5).shape == (0,)
+
+
+def test_batched_is_class_aware_and_modes_agree():
+    rng = np.random.default_rng(0)
+    ctr = rng.uniform(50, 600, size=(60, 2))
+    boxes = []
+    for c in ctr:
+        for _ in range(5):
+            cc = c + rng.normal(0, 4, 2)
+            wh = np.exp(rng.uniform(np.log(16), np.log(128), 2))
+            boxes.append([cc[0] - wh[0] / 2, cc[1] - wh[1] / 2, cc[0] + wh[0] / 2, cc[1] + wh[1] / 2])
+    boxes = np.asarray(boxes, np.float32)
+    scores = rng.uniform(0.01, 1, len(boxes)).astype(np.float32)
+    cls = rng.integers(0, 5, len(boxes)).astype(np.float32)
+    trick = onms.batched_nms(boxes, scores, cls, 0.65, numel_threshold=10 ** 9)
+    vanilla = onms.batched_nms(boxes, scores, cls, 0.65, numel_threshold=0)
+    assert trick.tolist() == vanilla.tolist()
+    # per-class brute force agrees
+    keep = np.zeros(len(boxes), bool)
+    for c in np.unique(cls):
+        sel = np.nonzero(cls == c)[0]
+        keep[sel[onms.nms_bruteforce(boxes[sel], scores[sel], 0.65)]] = True
+    assert sorted(trick.tolist()) == np.nonzero(keep)[0].tolist()
+    assert np.all(np.diff(scores[trick]) <= 0)
+
+
+def test_greedy_vs_bruteforce_random():
+    rng = np.random.default_rng(1)
+    for n in (1, 2, 17, 200):
+        xy = rng.uniform(0, 100, (n, 2))
+        wh = rng.uniform(5, 60, (n, 2))
+        b = np.concatenate([xy, xy + wh], 1).astype(np.float32)
+        s = rng.uniform(0, 1, n).astype(np.float32)
+        for thr in (0.3, 0.65):
+            assert onms.nms(b, s, thr).tolist() == onms.nms_bruteforce(b, s, thr).tolist()
+
+
+def test_postprocess_contract():
+    rng = np.random.default_rng(2)
+    B, A, C = 3, 500, 7
+    p = np.zeros((B, A, 5 + C), np.float32)
+    xy = rng.uniform(0, 300, (B, A, 2))
+    wh = rng.uniform(10, 80, (B, A, 2))
+    p[..., 0:2] = xy
+    p[..., 2:4] = xy + wh
+    p[..., 4] = rng.uniform(0, 1, (B, A))
+    p[..., 5:] = rng.uniform(0, 1, (B, A, C))
+    p[1, :, 4] = 0.0  # image 1: nothing passes -> None
+    out = onms.postprocess(p, 0.3, 0.65)
+    assert out[1] is None
+    for i in (0, 2):
+        d = out[i]
+        assert d.shape[1] == 6 and d.shape[0] <= 300
+        assert np.all(d[:, 4] >= 0.3) and np.all(np.diff(d[:, 4]) <= 0)
+        cls = p[i, :, 5:].argmax(1)
+        conf = p[i, :, 4] * p[i, :, 5:].max(1)
+        # every output row is one of the input anchors with its conf/class
+        for row in d[:5]:
+            j = np.nonzero((p[i, :, 0] == row[0]) & (p[i, :, 1] == row[1]))[0][0]
+            assert row[4] == conf[j] and row[5] == cls[j]
+    # max_det cap
+    out = onms.postprocess(p, 0.0, 1.0, max_det=10)
+    assert out[0].shape[0] == 10

@@ -1,0 +1,327 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by IMPORTING the reference (build container only).
+
+Run:  python tools/gen_golden.py            (needs /root/reference mounted)
+
+The reference publishes no tests or golden vectors, so
+every fixture under tests/golden/ is produced here by running the reference's
+own modules on seeded inputs.  Fixtures are DATA (inputs + expected outputs);
+no reference source text is stored.  /root/reference does not exist on the GPU
+box, so nothing at test time imports this script.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import yaml
+
+REF = "/root/reference"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, REF)
+
+from PL_Modules.build_detection import build_model  # noqa: E402
+from models.layers.network_blocks import BaseConv, CSPLayer, SPPBottleneck, Focus, Bottleneck  # noqa: E402
+from models.losses.yolox import yolox_loss as ref_loss_mod  # noqa: E402
+from models.losses.yolox.yolox_loss import YOLOXLoss  # noqa: E402
+from models.layers.lr_scheduler import CosineWarmupScheduler  # noqa: E402
+from models.utils.ema import ModelEMA  # noqa: E402
+
+torch.set_num_threads(4)
+
+
+def npy(d):
+    return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in d.items()}
+
+
+def save(name, d):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **npy(d))
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
+def load_cfg(name):
+    with open(os.path.join(ROOT, "configs", "model", "yolox", name + ".yaml")) as f:
+        return yaml.safe_load(f)
+
+
+# --------------------------------------------------------------------------
+# capture the SimOTA assignment from inside the reference
+# --------------------------------------------------------------------------
+_calls = []
+_orig_dk = ref_loss_mod.dynamic_k_matching
+
+
+def _dk_spy(fg_mask, cost, pair_wise_ious, gt_classes, num_gt):
+    r = _orig_dk(fg_mask, cost, pair_wise_ious, gt_classes, num_gt)
+    # boundary gap diagnostic on the reference's own cost matrix
+    n_k = min(10, pair_wise_ious.size(1))
+    ks = torch.clamp(pair_wise_ious.sort(descending=True)[0][:, :n_k].sum(1).int(), min=1)
+    gap = float("inf")
+    for g in range(num_gt):
+        sc = cost[g].sort()[0]
+        k = int(ks[g])
+        if k < sc.numel() - 1:
+            gap = min(gap, abs(float(sc[k]) - float(sc[k - 1])) / max(abs(float(sc[k - 1])), 1.0))
+    _calls.append(dict(fg=r[0].clone(), num_fg=int(r[1]), mg=r[2].clone(), iou=r[4].clone(), gap=gap, ks=ks.clone()))
+    return r
+
+
+ref_loss_mod.dynamic_k_matching = _dk_spy
+
+
+def run_ref_loss(maps, labels, strides, num_classes):
+    """maps: list of leaf-less tensors; returns dict of outputs incl. dense assignment."""
+    _calls.clear()
+    loss_fn = YOLOXLoss(num_classes, strides)
+    loss_fn.train()
+    leafs = [m.clone().requires_grad_(True) for m in maps]
+    # the loss writes through views of its inputs: hand it non-leaf copies
+    out = loss_fn([l * 1.0 for l in leafs], labels)
+    out["loss"].backward()
+    B = maps[0].shape[0]
+    A = sum(m.shape[2] * m.shape[3] for m in maps)
+    fg = torch.zeros(B, A, dtype=torch.bool)
+    mg = torch.full((B, A), -1, dtype=torch.int64)
+    mi = torch.zeros(B, A)
+    nlabel = (labels.sum(dim=2) > 0).sum(dim=1)
+    ci = 0
+    gap = float("inf")
+    for b in range(B):
+        if int(nlabel[b]) == 0:
+            continue
+        c = _calls[ci]
+        ci += 1
+        fg[b] = c["fg"]
+        mg[b, c["fg"]] = c["mg"]
+        mi[b, c["fg"]] = c["iou"]
+        gap = min(gap, c["gap"])
+    assert ci == len(_calls)
+    res = dict(
+        loss=out["loss"], loss_iou=out["loss_iou"], loss_obj=out["loss_obj"], loss_cls=out["loss_cls"],
+        proportion=float(out["proportion"]), fg=fg, matched_gt=mg, matched_iou=mi, boundary_gap=gap,
+    )
+    for i, l in enumerate(leafs):
+        res["grad%d" % i] = l.grad
+    loss_fn.eval()
+    res["eval_decode"] = loss_fn([m.clone() for m in maps], labels)
+    return res
+
+
+def rand_maps(gen, B, C, sizes, reg_std=0.5):
+    maps = []
+    for h, w in sizes:
+        m = torch.randn(B, 5 + C, h, w, generator=gen)
+        m[:, :4] *= reg_std
+        m[:, 4] = m[:, 4] * 2.0 - 2.0
+        m[:, 5:] = m[:, 5:] * 2.0 - 2.0
+        maps.append(m)
+    return maps
+
+
+def rand_labels(gen, counts, C, size, max_gt, min_wh=8.0):
+    B = len(counts)
+    lab = torch.zeros(B, max_gt, 5)
+    for b, g in enumerate(counts):
+        lab[b, :g, 0] = torch.randint(0, C, (g,), generator=gen).float()
+        lab[b, :g, 1:3] = (0.15 + 0.7 * torch.rand(g, 2, generator=gen)) * size
+        lab[b, :g, 3:5] = min_wh + torch.rand(g, 2, generator=gen) * 0.3 * size
+    return lab
+
+
+def gen_loss_cases():
+    cases = {}
+    # A: realistic multi-level case incl. an image with zero GTs
+    gen = torch.Generator().manual_seed(101)
+    maps = rand_maps(gen, 4, 80, [(20, 20), (10, 10), (5, 5)])
+    labels = rand_labels(gen, [12, 0, 30, 5], 80, 160, 40)
+    cases["A"] = (maps, labels, [8, 16, 32], 80)
+    # B: few classes, overlapping GTs (conflict resolution) + a tiny edge GT
+    gen = torch.Generator().manual_seed(202)
+    maps = rand_maps(gen, 2, 3, [(16, 16), (8, 8), (4, 4)])
+    labels = torch.zeros(2, 10, 5)
+    labels[0, 0] = torch.tensor([0, 60.0, 60.0, 50.0, 40.0])
+    labels[0, 1] = torch.tensor([1, 62.0, 58.0, 48.0, 44.0])
+    labels[0, 2] = torch.tensor([2, 64.0, 64.0, 90.0, 90.0])
+    labels[0, 3] = torch.tensor([1, 20.0, 100.0, 30.0, 30.0])
+    labels[1, 0] = torch.tensor([2, 3.0, 3.0, 2.5, 2.5])     # tiny GT hugging the corner
+    labels[1, 1] = torch.tensor([0, 100.0, 30.0, 40.0, 20.0])
+    cases["B"] = (maps, labels, [8, 16, 32], 3)
+    # C: single 2x2 level, well-fitting predictions -> k >= N_c - 1 branch (take ALL)
+    gen = torch.Generator().manual_seed(303)
+    m = torch.zeros(2, 5 + 4, 2, 2)
+    m[:, 4:] = torch.randn(2, 5, 2, 2, generator=gen)
+    # decoded box = ((t+g)*32, exp(t)*32): aim every anchor at the GT (32,32,40,40)
+    for gy in range(2):
+        for gx in range(2):
+            m[:, 0, gy, gx] = 1.0 - gx + 0.01 * (gx + 2 * gy)
+            m[:, 1, gy, gx] = 1.0 - gy - 0.01 * (gx + 2 * gy)
+            m[:, 2, gy, gx] = float(np.log(40.0 / 32)) + 0.02 * gx
+            m[:, 3, gy, gx] = float(np.log(40.0 / 32)) - 0.02 * gy
+    labels = torch.zeros(2, 4, 5)
+    labels[0, 0] = torch.tensor([1, 32.0, 32.0, 40.0, 40.0])
+    labels[1, 0] = torch.tensor([3, 32.0, 32.0, 40.0, 40.0])
+    labels[1, 1] = torch.tensor([0, 30.0, 34.0, 36.0, 44.0])
+    cases["C"] = ([m], labels, [32], 4)
+    # D: non-square map -> documents the grid quirk (yolox_loss.py:198-200)
+    gen = torch.Generator().manual_seed(404)
+    maps = rand_maps(gen, 2, 2, [(2, 3)])
+    labels = torch.zeros(2, 3, 5)
+    labels[0, 0] = torch.tensor([1, 20.0, 12.0, 18.0, 14.0])
+    labels[1, 0] = torch.tensor([0, 30.0, 20.0, 25.0, 22.0])
+    labels[1, 1] = torch.tensor([1, 10.0, 10.0, 12.0, 12.0])
+    cases["D"] = (maps, labels, [16], 2)
+    # E: larger candidate sets, 60 GTs in one image, COCO-like class count
+    gen = torch.Generator().manual_seed(505)
+    maps = rand_maps(gen, 2, 80, [(32, 32), (16, 16), (8, 8)], reg_std=0.3)
+    labels = rand_labels(gen, [60, 17], 80, 256, 64, min_wh=6.0)
+    cases["E"] = (maps, labels, [8, 16, 32], 80)
+
+    for name, (maps, labels, strides, C) in cases.items():
+        r = run_ref_loss(maps, labels, strides, C)
+        d = dict(labels=labels, strides=np.asarray(strides), num_classes=C, nmaps=len(maps))
+        for i, m in enumerate(maps):
+            d["map%d" % i] = m
+        d.update(r)
+        print("loss case", name, "loss=%.6f" % float(r["loss"]), "num_fg=%d" % int(r["fg"].sum()), "gap=%.3g" % r["boundary_gap"])
+        save("loss_case_" + name, d)
+
+
+def gen_blocks():
+    torch.manual_seed(7)
+    d = {}
+
+    def run(tag, mod, x):
+        mod.train()
+        # non-trivial BN affine so gamma/beta gradients are exercised
+        for n, p in mod.named_parameters():
+            if n.endswith("norm.weight") or n.endswith("bn.weight"):
+                p.data.uniform_(0.5, 1.5)
+            if n.endswith("norm.bias") or n.endswith("bn.bias"):
+                p.data.uniform_(-0.5, 0.5)
+        for k, v in mod.state_dict().items():
+            d["%s/state/%s" % (tag, k)] = v.clone()
+        xl = x.clone().requires_grad_(True)
+        y = mod(xl)
+        r = torch.randn(y.shape)
+        (y * r).sum().backward()
+        d[tag + "/x"] = x
+        d[tag + "/y"] = y
+        d[tag + "/r"] = r
+        d[tag + "/dx"] = xl.grad
+        for n, p in mod.named_parameters():
+            if p.grad is not None:
+                d["%s/grad/%s" % (tag, n)] = p.grad
+        for k, v in mod.state_dict().items():
+            if "running" in k:
+                d["%s/state_after/%s" % (tag, k)] = v.clone()
+
+    run("conv3s2", BaseConv(8, 16, 3, 2), torch.randn(2, 8, 16, 16))
+    run("conv3s1", BaseConv(8, 16, 3, 1), torch.randn(2, 8, 12, 12))
+    run("conv1", BaseConv(16, 8, 1, 1), torch.randn(2, 16, 8, 8))
+    run("focus", Focus(3, 8, ksize=3), torch.rand(2, 3, 16, 16) * 255)
+    run("bottleneck", Bottleneck(8, 8, True, 1.0), torch.randn(2, 8, 8, 8))
+    run("csp", CSPLayer(16, 16, num_bottle=2), torch.randn(2, 16, 8, 8))
+    run("csp_noshort", CSPLayer(32, 16, num_bottle=1, shortcut=False), torch.randn(2, 32, 8, 8))
+    run("spp", SPPBottleneck(32, 32), torch.randn(2, 32, 8, 8))
+    save("blocks", d)
+
+
+def gen_network():
+    cfg = load_cfg("yolox_test")
+    C = 3
+    torch.manual_seed(96)
+    model = build_model(cfg, C)
+    # perturb BN affine + running stats so eval mode is non-trivial too
+    g = torch.Generator().manual_seed(5)
+    for n, p in model.named_parameters():
+        if n.endswith(".norm.weight"):
+            p.data = 0.5 + torch.rand(p.shape, generator=g)
+        if n.endswith(".norm.bias"):
+            p.data = torch.rand(p.shape, generator=g) - 0.5
+    gen = torch.Generator().manual_seed(1234)
+    x = torch.rand(2, 3, 64, 64, generator=gen) * 255
+    labels = torch.zeros(2, 8, 5)
+    labels[0, :3] = torch.tensor([[0, 20.0, 24.0, 18.0, 22.0], [2, 40.0, 40.0, 30.0, 26.0], [1, 50.0, 14.0, 16.0, 12.0]])
+    labels[1, :2] = torch.tensor([[1, 30.0, 30.0, 40.0, 36.0], [0, 12.0, 50.0, 14.0, 18.0]])
+    d = dict(x=x, labels=labels, num_classes=C)
+    for k, v in model.state_dict().items():
+        d["state/" + k] = v.clone()
+    model.train()
+    _calls.clear()
+    maps = model(x)  # labels=None -> raw head maps (this also updates BN running stats once)
+    for i, m in enumerate(maps):
+        d["maps_train%d" % i] = m.detach().clone()
+    # restore buffers, then the real training step
+    model.load_state_dict({k[len("state/"):]: torch.as_tensor(v) for k, v in d.items() if k.startswith("state/")})
+    model.zero_grad()
+    out = model(x, labels)
+    out["loss"].backward()
+    for k in ("loss", "loss_iou", "loss_obj", "loss_cls"):
+        d["out/" + k] = out[k].detach()
+    d["out/proportion"] = float(out["proportion"])
+    d["boundary_gap"] = min([c["gap"] for c in _calls] + [float("inf")])
+    nograd = []
+    for n, p in model.named_parameters():
+        if p.grad is None:
+            nograd.append(n)
+        else:
+            d["grad/" + n] = p.grad.clone()
+    d["nograd_names"] = np.asarray(nograd)
+    for k, v in model.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            d["state_after/" + k] = v.clone()
+    # eval branch (uses the running stats after that one step)
+    model.eval()
+    with torch.no_grad():
+        d["eval_out"] = model(x, labels).clone()
+        for i, m in enumerate(model(x)):
+            d["maps_eval%d" % i] = m.clone()
+    print("network fixture: loss=%.6f gap=%.3g nograd=%d" % (float(out["loss"]), d["boundary_gap"], len(nograd)))
+    save("network_yolox_test", d)
+
+    # one full SGD(momentum) x2 + EMA + LR schedule trajectory on the same model (a25)
+    model.load_state_dict({k[len("state/"):]: torch.as_tensor(v) for k, v in d.items() if k.startswith("state/")})
+    model.train()
+    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9)
+    sched = CosineWarmupScheduler(opt, warmup=0.1 * 20, max_iters=20)
+    ema = ModelEMA(model, 0.9998)
+    h = dict(x=x, labels=labels)
+    lrs = []
+    for step in range(3):
+        lrs.append(opt.param_groups[0]["lr"])
+        out = model(x, labels)
+        opt.zero_grad()
+        out["loss"].backward()
+        opt.step()
+        ema.update(model)
+        sched.step()
+        h["loss%d" % step] = out["loss"].detach()
+    h["lrs"] = np.asarray(lrs)
+    for k, v in model.state_dict().items():
+        h["final/" + k] = v.clone()
+    for k, v in ema.ema.state_dict().items():
+        h["ema/" + k] = v.clone()
+    save("harness_trajectory", h)
+
+
+def gen_schedule():
+    d = {}
+    for i, (warm, T) in enumerate([(0.1 * 100, 100), (0.0 + 5, 37), (300, 3000)]):
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.SGD([p], lr=0.01, momentum=0.9)
+        s = CosineWarmupScheduler(opt, warmup=warm, max_iters=T)
+        fac = [s.get_lr_factor(t) for t in range(T + 1)]
+        d["sched%d_warm" % i] = warm
+        d["sched%d_T" % i] = T
+        d["sched%d_factor" % i] = np.asarray(fac, dtype=np.float64)
+    save("lr_schedule", d)
+
+
+if __name__ == "__main__":
+    gen_loss_cases()
+    gen_blocks()
+    gen_network()
+    gen_schedule()
