@@ -1,0 +1,234 @@
+/*
+ * plyolo.h -- C ABI of libplyolo_hip.so: the MI355X (gfx950) kernels behind the
+ * pl_YOLO detector hot path  OneStageD.forward(x, labels)  + eval decode / NMS.
+ *
+ * Boundary rules:
+ *   - plain pointers + sizes only, no torch types; every buffer is allocated by
+ *     the caller (device memory), the library owns no tensor state;
+ *   - every op enqueues on the caller's hipStream_t (passed as void*), never
+ *     synchronises, never allocates, never throws across the boundary;
+ *   - return value 0 = ok, negative = error; text via plyolo_last_error()
+ *     (thread local);
+ *   - while a plan is being recorded on the calling thread (plyolo_plan_begin)
+ *     op calls are RECORDED into the plan instead of launched; the plan replays
+ *     them (plyolo_plan_run) or replays them from an instantiated hipGraph
+ *     (plyolo_plan_graph_launch).  Descriptors are copied at record time.
+ *
+ * Layouts: activations are NHWC ("pixel rows" of C channels, row pitch `ld`
+ * elements so that channel-concatenation is a strided write, not a copy);
+ * dtype PLYOLO_BF16 = bf16 storage + bf16 MFMA + fp32 accumulation,
+ * PLYOLO_F32 = fp32 storage and arithmetic (parity mode).  Convolution weights
+ * are consumed in packed form ([tap][Cout][Cin] for fwd, [tap][Cin][Cout] for
+ * dgrad), produced from the torch OIHW fp32 master copy by plyolo_pack_weights.
+ *
+ * Each entry point cites the reference code it replaces (file:line into
+ * Iywie/pl_YOLO).  The reference has no native FFI: these are the bindings its
+ * Python plugin layer (PL_Modules/build_detection.py) reaches through
+ * pl_yolo_amd/_lib.py (ctypes) -- see INTEGRATION.md.
+ */
+#ifndef PLYOLO_H
+#define PLYOLO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PLYOLO_BF16 0
+#define PLYOLO_F32 1
+
+#define PLYOLO_ACT_NONE 0
+#define PLYOLO_ACT_SILU 1
+#define PLYOLO_ACT_RELU 2
+#define PLYOLO_ACT_LRELU 3 /* slope 0.1, models/layers/activation.py:13 */
+
+/* ---------------------------------------------------------------- probes */
+int plyolo_version(void);            /* ABI version */
+const char* plyolo_arch(void);       /* "gfx950" */
+const char* plyolo_last_error(void); /* thread-local message of the last failure */
+
+/* ------------------------------------------------------------------ plans */
+typedef struct plyolo_plan plyolo_plan;
+plyolo_plan* plyolo_plan_create(void);
+void plyolo_plan_destroy(plyolo_plan*);
+int plyolo_plan_begin(plyolo_plan*);           /* start recording on this thread */
+int plyolo_plan_end(plyolo_plan*);             /* stop recording */
+int plyolo_plan_size(const plyolo_plan*);      /* number of recorded launches */
+int plyolo_plan_run(plyolo_plan*, void* stream); /* replay eagerly */
+int plyolo_plan_graph_instantiate(plyolo_plan*, void* stream); /* capture into a hipGraphExec */
+int plyolo_plan_graph_launch(plyolo_plan*, void* stream);
+
+/* ------------------------------------------------------------ convolution
+ * Replaces nn.Conv2d inside BaseConv (models/layers/network_blocks.py:18-26)
+ * and the bare prediction convs of DecoupledHead (models/heads/decoupled_head.py:43-62)
+ * -- forward, and what autograd's convolution_backward does for them. */
+typedef struct plyolo_conv_desc {
+  int dtype;          /* PLYOLO_BF16 | PLYOLO_F32: storage of x / y / packed w */
+  int N, H, W;        /* input batch and spatial size */
+  int Cin, Cout;
+  int ksize;          /* 1 or 3 (square, pad (k-1)/2) */
+  int stride;         /* 1 or 2 */
+  int x_ld, y_ld;     /* pixel pitch (elements) of x and y */
+  int y_f32;          /* 1: y (fwd) / dy (bwd) is fp32 regardless of dtype (head preds) */
+} plyolo_conv_desc;
+
+/* y[n,oh,ow,co] = sum x[n,oh*s+kh-p,ow*s+kw-p,ci] * w[co,ci,kh,kw] (+ bias[co]).
+ * wp: packed fwd weights.  bias: fp32[Cout] or NULL.
+ * stats: NULL, or fp32 [2][plyolo_conv2d_stat_rows(d)][Cout] receiving per-block
+ * partial sums of y and y^2 (train-mode BatchNorm statistics, fused epilogue). */
+int plyolo_conv2d_fwd(const plyolo_conv_desc* d, const void* x, const void* wp, const float* bias,
+                      void* y, float* stats, void* stream);
+int plyolo_conv2d_stat_rows(const plyolo_conv_desc* d);
+/* dx = conv_transpose(dy, w).  wpd: packed dgrad weights.  accumulate!=0: dx += */
+int plyolo_conv2d_dgrad(const plyolo_conv_desc* d, const void* dy, const void* wpd, void* dx,
+                        int accumulate, void* stream);
+/* dwp[tap][Cout][Cin] (fp32) += sum_pixels dy (x) x.  The caller zeroes dwp. */
+int plyolo_conv2d_wgrad(const plyolo_conv_desc* d, const void* x, const void* dy, float* dwp, void* stream);
+/* dbias[co] = sum over pixels of dy[m][co] (head prediction convs, decoupled_head.py:43-62). */
+int plyolo_bias_grad(int dtype, const void* dy, int M, int C, int ld, float* dbias, void* stream);
+
+/* Weight (re)packing, one launch for a whole table of convolutions. The table
+ * lives in DEVICE memory: n entries of plyolo_pack_entry. */
+typedef struct plyolo_pack_entry {
+  const float* w;   /* OIHW fp32 master weights (torch layout), [Cout][Cin][k][k] */
+  void* wp;         /* [tap][Cout_total][Cin_p] fwd pack (bf16 or fp32) */
+  void* wpd;        /* [tap][Cin_p][Cout_p8] dgrad pack, or NULL */
+  float* dwp;       /* [tap][Cout_total][Cin_p] fp32 wgrad accumulator (unpack source) */
+  float* dw;        /* OIHW fp32 gradient (unpack destination), or NULL */
+  const float* b;   /* fp32 bias [Cout] or NULL */
+  float* bp;        /* packed bias [Cout_total] */
+  float* dbp;       /* packed bias gradient [Cout_total] */
+  float* db;        /* bias gradient [Cout] or NULL */
+  int Cout, Cin, Cin_p, ksize;
+  int Cout_total;   /* rows of the packed matrix (several torch convs may share one
+                       packed conv: reg_preds(4)+obj_preds(1), decoupled_head.py:55-62) */
+  int Cout_p8;      /* Cout_total rounded up to 8 (dgrad contraction length) */
+  int co_off;       /* first packed row of this entry */
+  int pad_;
+} plyolo_pack_entry;
+int plyolo_pack_weights(const plyolo_pack_entry* table_dev, int n, int dtype, int max_elems, void* stream);
+/* dw (OIHW) (+)= permute(dwp) for the whole table. */
+int plyolo_unpack_wgrads(const plyolo_pack_entry* table_dev, int n, int max_elems, int accumulate, void* stream);
+
+/* ------------------------------------------------- BatchNorm + activation
+ * Replaces nn.BatchNorm2d(eps=1e-3, momentum=0.03) + SiLU of BaseConv
+ * (models/layers/normalization.py:8, network_blocks.py:30-37) fwd and bwd. */
+/* Reduce conv-epilogue partials -> mean / biased var -> coef[0:C]=scale,
+ * coef[C:2C]=shift, coef[2C:3C]=mean, coef[3C:4C]=invstd; update running stats
+ * (unbiased var) and num_batches_tracked (int64) when non-NULL. */
+int plyolo_bn_finalize(const float* stats, int rows, int C, double count, const float* gamma,
+                       const float* beta, float eps, float momentum, float* running_mean,
+                       float* running_var, int64_t* num_batches_tracked, float* coef, void* stream);
+/* eval mode: coef from running statistics */
+int plyolo_bn_eval_coef(int C, const float* gamma, const float* beta, const float* running_mean,
+                        const float* running_var, float eps, float* coef, void* stream);
+/* out = act(z*scale+shift) (+ res).  z [M][C] pitch z_ld; out pitch o_ld; res pitch r_ld or NULL */
+int plyolo_bn_act_fwd(int dtype, int M, int C, const void* z, int z_ld, const float* coef, int act,
+                      const void* res, int r_ld, void* out, int o_ld, void* stream);
+/* partial[2][rows][C]: sum du, sum du*zhat  with du = dout * act'(u) */
+int plyolo_bn_bwd_rows(int M);
+int plyolo_bn_act_bwd_reduce(int dtype, int M, int C, const void* dout, int d_ld, const void* z, int z_ld,
+                             const float* coef, int act, float* partial, void* stream);
+/* dgamma/dbeta (+)=; bcoef[0:C]=A, [C:2C]=B, [2C:3C]=Cc so that dz = A*du + B*z + Cc */
+int plyolo_bn_bwd_finalize(const float* partial, int rows, int C, double count, const float* gamma,
+                           const float* coef, float* dgamma, float* dbeta, int accumulate, float* bcoef,
+                           void* stream);
+int plyolo_bn_act_bwd_dz(int dtype, int M, int C, const void* dout, int d_ld, const void* z, int z_ld,
+                         const float* coef, const float* bcoef, int act, void* dz, int dz_ld, void* stream);
+
+/* -------------------------------------------------- data movement kernels */
+/* Focus space-to-depth (network_blocks.py:50-65): NCHW fp32 image ->
+ * NHWC [N,H/2,W/2,Cp] with channel blocks TL,BL,TR,BR (3 each) then zero pad. */
+int plyolo_focus_s2d(int dtype, const float* img, int N, int H, int W, void* out, int Cp, void* stream);
+/* out[m][0:C] (pitch o_ld) = (accumulate ? out : 0) + in[m][0:C] (pitch i_ld) */
+int plyolo_copy_add(int dtype, int M, int C, const void* in, int i_ld, void* out, int o_ld, int accumulate,
+                    void* stream);
+/* nearest x2 upsample (models/necks/pafpn_csp.py:22) fwd, and its bwd (2x2 sum) */
+int plyolo_upsample2x_fwd(int dtype, int N, int H, int W, int C, const void* in, int i_ld, void* out, int o_ld,
+                          void* stream);
+int plyolo_upsample2x_bwd(int dtype, int N, int H, int W, int C, const void* dout, int d_ld, void* din, int i_ld,
+                          int accumulate, void* stream);
+/* MaxPool2d(k, stride 1, pad k/2) (network_blocks.py:144): fwd, and bwd that
+ * routes dout to the FIRST maximum in row-major window order (ATen rule),
+ * accumulating into din (fp32 [N,H,W,C] scratch, caller zeroes). */
+int plyolo_maxpool_s1_fwd(int dtype, int N, int H, int W, int C, int k, const void* in, int i_ld, void* out,
+                          int o_ld, void* stream);
+int plyolo_maxpool_s1_bwd(int dtype, int N, int H, int W, int C, int k, const void* in, int i_ld,
+                          const void* dout, int d_ld, float* din_f32, void* stream);
+/* out (pitch o_ld) (+)= convert(in fp32 [M][C]) */
+int plyolo_f32_to_act(int dtype, int M, int C, const float* in, void* out, int o_ld, int accumulate, void* stream);
+int plyolo_memset_async(void* p, int value, size_t bytes, void* stream);
+/* NHWC activation -> NCHW fp32 (API edge: returning feature maps to torch callers) and back */
+int plyolo_nhwc_to_nchw_f32(int dtype, int N, int H, int W, int C, const void* in, int i_ld, float* out,
+                            void* stream);
+int plyolo_nchw_f32_to_nhwc(int dtype, int N, int H, int W, int C, const float* in, void* out, int o_ld,
+                            void* stream);
+
+/* ------------------------------------------------------------- YOLOX loss
+ * Replaces YOLOXLoss (models/losses/yolox/yolox_loss.py:20-228),
+ * get_in_boxes_info (:231-315), dynamic_k_matching (:318-370),
+ * bboxes_iou / IOUloss (models/layers/losses/iou_loss.py:7-50,391-414). */
+typedef struct plyolo_yolox_desc {
+  int B, A, C;          /* batch, total anchors, classes */
+  int M;                /* label rows per image */
+  int nlevels;          /* <= 8 */
+  int lvl_h[8], lvl_w[8], lvl_stride[8];
+  int lvl_off[8];       /* first anchor of the level in the per-image anchor order */
+  int lvl_row[8];       /* first row of the level's dense [B, h*w, 5+C] block (level-major raw) */
+} plyolo_yolox_desc;
+size_t plyolo_yolox_workspace(const plyolo_yolox_desc* d);
+/* raw: fp32 head output (tx,ty,tw,th,obj,cls..), LEVEL-major: level l is the dense NHWC
+ * head map [B, h_l, w_l, 5+C] at row lvl_row[l] (so the head convs write it directly
+ * and the reference's permute at yolox_loss.py:210-213 disappears).
+ * labels [B,M,5] fp32 rows (cls,cx,cy,w,h), zero padded.
+ * Outputs (batch-major, anchor order of the reference): fg u8[B,A]; matched_gt i32[B,A]
+ * (-1 bg); matched_iou f32[B,A];
+ * losses f32[8] = {loss, loss_iou, loss_obj, loss_cls, num_fg, num_gt, proportion, 0}. */
+int plyolo_yolox_loss_fwd(const plyolo_yolox_desc* d, const float* raw, const float* labels, uint8_t* fg,
+                          int32_t* matched_gt, float* matched_iou, float* losses, void* workspace,
+                          size_t ws_bytes, void* stream);
+/* d(sum_i gout[i]*losses[i])/d(raw), gout fp32[4] on the device or NULL (= d loss).
+ * Level-major rows like raw.  Exactly one of the two forms is written:
+ *   draw_f32 [rows,5+C]                                  (parity mode), or
+ *   d_regobj bf16 [rows,16] (5 used) + d_cls bf16 [rows,cls_ld]   (MFMA mode). */
+int plyolo_yolox_loss_bwd(const plyolo_yolox_desc* d, const float* raw, const float* labels, const uint8_t* fg,
+                          const int32_t* matched_gt, const float* matched_iou, const float* losses,
+                          const float* gout, float* draw_f32, void* d_regobj, void* d_cls, int cls_ld,
+                          void* stream);
+/* eval branch (yolox_loss.py:25-36): out [B,A,5+C] batch-major = (x1,y1,x2,y2,sig(obj),sig(cls)) */
+int plyolo_yolox_eval_decode(const plyolo_yolox_desc* d, const float* raw, float* out, void* stream);
+
+/* ----------------------------------------------------------- postprocess
+ * Replaces postprocess() (models/evaluators/postprocess.py:7-48) including
+ * torchvision.ops.batched_nms / nms (un-vendored third party; algorithm per
+ * torchvision/ops/boxes.py: coordinate trick when 4*n <= 20000 else per class). */
+typedef struct plyolo_nms_desc {
+  int B, A, C;
+  float conf_thre, nms_thre;
+  int class_agnostic;
+  int max_nms;   /* 10000 */
+  int max_det;   /* 300 */
+  int numel_threshold; /* 20000 (torchvision GPU rule) */
+} plyolo_nms_desc;
+size_t plyolo_postprocess_workspace(const plyolo_nms_desc* d);
+/* pred [B,A,5+C] fp32 (eval decode output) -> det f32 [B,max_det,6], count i32[B],
+ * ncand i32[B] (boxes that entered NMS) */
+int plyolo_postprocess(const plyolo_nms_desc* d, const float* pred, float* det, int32_t* count, int32_t* ncand,
+                       void* workspace, size_t ws_bytes, void* stream);
+/* NMS only: boxes [B,n,6] (x1,y1,x2,y2,score,cls) already filtered, n per image in nbox[B] */
+int plyolo_batched_nms(const plyolo_nms_desc* d, const float* boxes, int n_max, const int32_t* nbox, float* det,
+                       int32_t* count, void* workspace, size_t ws_bytes, void* stream);
+
+/* -------------------------------------------------- optimizer step (a25)
+ * SGD(momentum, no wd, no nesterov) + EMA over flat fp32 buffers
+ * (PL_Modules/pl_detection.py:58-64,107-111; models/utils/ema.py:48-60). */
+int plyolo_sgd_momentum(float* p, const float* g, float* mom, size_t n, const float* lr_dev, float lr,
+                        float momentum, int first_step, void* stream);
+int plyolo_ema_update(float* ema, const float* model, size_t n, float decay, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,133 @@
+// C-ABI glue: probes, error text, launch plans (record / replay / hipGraph) and the
+// dtype dispatch of the convolution entry points.
+#include <stdarg.h>
+
+#include "common.h"
+
+namespace plyolo {
+
+static thread_local std::string g_err;
+static thread_local Plan* g_rec = nullptr;
+
+void set_error(const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+Plan* recording_plan() { return g_rec; }
+
+int conv_mfma_stat_rows(const plyolo_conv_desc* d);
+int conv_mfma_fwd(const plyolo_conv_desc*, const void*, const void*, const float*, void*, float*, void*);
+int conv_mfma_dgrad(const plyolo_conv_desc*, const void*, const void*, void*, int, void*);
+int conv_mfma_wgrad(const plyolo_conv_desc*, const void*, const void*, float*, void*);
+int conv_ref_stat_rows(const plyolo_conv_desc* d);
+int conv_ref_fwd(const plyolo_conv_desc*, const void*, const void*, const float*, void*, float*, void*);
+int conv_ref_dgrad(const plyolo_conv_desc*, const void*, const void*, void*, int, void*);
+int conv_ref_wgrad(const plyolo_conv_desc*, const void*, const void*, float*, void*);
+
+static int check_conv(const plyolo_conv_desc* d, const char* who) {
+  PLY_CHECK_ARG(d != nullptr, "%s: null descriptor", who);
+  PLY_CHECK_ARG(d->dtype == PLYOLO_BF16 || d->dtype == PLYOLO_F32, "%s: bad dtype %d", who, d->dtype);
+  PLY_CHECK_ARG(d->ksize == 1 || d->ksize == 3, "%s: ksize must be 1 or 3 (got %d)", who, d->ksize);
+  PLY_CHECK_ARG(d->stride == 1 || d->stride == 2, "%s: stride must be 1 or 2 (got %d)", who, d->stride);
+  PLY_CHECK_ARG(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "%s: non-positive dimension", who);
+  PLY_CHECK_ARG(d->x_ld >= d->Cin, "%s: x_ld %d < Cin %d", who, d->x_ld, d->Cin);
+  if (d->dtype == PLYOLO_BF16) {
+    PLY_CHECK_ARG(d->Cin % 8 == 0 && d->x_ld % 8 == 0, "%s: bf16 path needs Cin and x_ld multiples of 8 (Cin %d, x_ld %d)", who, d->Cin, d->x_ld);
+    if (!d->y_f32) PLY_CHECK_ARG(d->Cout % 8 == 0 && d->y_ld % 8 == 0, "%s: bf16 output needs Cout and y_ld multiples of 8 (Cout %d, y_ld %d)", who, d->Cout, d->y_ld);
+  }
+  return 0;
+}
+
+}  // namespace plyolo
+
+using namespace plyolo;
+
+extern "C" {
+
+int plyolo_version(void) { return 1; }
+const char* plyolo_arch(void) { return "gfx950"; }
+const char* plyolo_last_error(void) { return g_err.c_str(); }
+
+plyolo_plan* plyolo_plan_create(void) { return (plyolo_plan*)new Plan(); }
+void plyolo_plan_destroy(plyolo_plan* p) {
+  Plan* q = (Plan*)p;
+  if (!q) return;
+  if (q->exec) (void)hipGraphExecDestroy(q->exec);
+  if (q->graph) (void)hipGraphDestroy(q->graph);
+  if (g_rec == q) g_rec = nullptr;
+  delete q;
+}
+int plyolo_plan_begin(plyolo_plan* p) {
+  PLY_CHECK_ARG(p != nullptr, "plan_begin: null plan");
+  PLY_CHECK_ARG(g_rec == nullptr, "plan_begin: another plan is already recording on this thread");
+  g_rec = (Plan*)p;
+  return 0;
+}
+int plyolo_plan_end(plyolo_plan* p) {
+  PLY_CHECK_ARG(g_rec == (Plan*)p, "plan_end: this plan is not recording");
+  g_rec = nullptr;
+  return 0;
+}
+int plyolo_plan_size(const plyolo_plan* p) { return p ? (int)((const Plan*)p)->ops.size() : 0; }
+int plyolo_plan_run(plyolo_plan* p, void* stream) {
+  PLY_CHECK_ARG(p != nullptr, "plan_run: null plan");
+  PLY_CHECK_ARG(g_rec == nullptr, "plan_run: cannot replay while recording");
+  Plan* q = (Plan*)p;
+  for (size_t i = 0; i < q->ops.size(); ++i) {
+    hipError_t e = q->ops[i]((hipStream_t)stream);
+    if (e != hipSuccess) {
+      set_error("plan_run: launch %zu failed: %s", i, hipGetErrorString(e));
+      return -2;
+    }
+  }
+  return 0;
+}
+int plyolo_plan_graph_instantiate(plyolo_plan* p, void* stream) {
+  PLY_CHECK_ARG(p != nullptr, "plan_graph_instantiate: null plan");
+  Plan* q = (Plan*)p;
+  hipStream_t s = (hipStream_t)stream;
+  if (q->exec) { (void)hipGraphExecDestroy(q->exec); q->exec = nullptr; }
+  if (q->graph) { (void)hipGraphDestroy(q->graph); q->graph = nullptr; }
+  hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+  if (e != hipSuccess) { set_error("hipStreamBeginCapture: %s", hipGetErrorString(e)); return -2; }
+  hipError_t le = hipSuccess;
+  for (size_t i = 0; i < q->ops.size() && le == hipSuccess; ++i) le = q->ops[i](s);
+  e = hipStreamEndCapture(s, &q->graph);
+  if (le != hipSuccess || e != hipSuccess) {
+    set_error("graph capture failed: %s / %s", hipGetErrorString(le), hipGetErrorString(e));
+    return -2;
+  }
+  e = hipGraphInstantiate(&q->exec, q->graph, nullptr, nullptr, 0);
+  if (e != hipSuccess) { set_error("hipGraphInstantiate: %s", hipGetErrorString(e)); return -2; }
+  return 0;
+}
+int plyolo_plan_graph_launch(plyolo_plan* p, void* stream) {
+  Plan* q = (Plan*)p;
+  PLY_CHECK_ARG(q && q->exec, "plan_graph_launch: plan has no instantiated graph");
+  hipError_t e = hipGraphLaunch(q->exec, (hipStream_t)stream);
+  if (e != hipSuccess) { set_error("hipGraphLaunch: %s", hipGetErrorString(e)); return -2; }
+  return 0;
+}
+
+int plyolo_conv2d_stat_rows(const plyolo_conv_desc* d) {
+  if (check_conv(d, "conv2d_stat_rows")) return -1;
+  return d->dtype == PLYOLO_BF16 ? conv_mfma_stat_rows(d) : conv_ref_stat_rows(d);
+}
+int plyolo_conv2d_fwd(const plyolo_conv_desc* d, const void* x, const void* wp, const float* bias, void* y, float* stats, void* stream) {
+  if (check_conv(d, "conv2d_fwd")) return -1;
+  return d->dtype == PLYOLO_BF16 ? conv_mfma_fwd(d, x, wp, bias, y, stats, stream) : conv_ref_fwd(d, x, wp, bias, y, stats, stream);
+}
+int plyolo_conv2d_dgrad(const plyolo_conv_desc* d, const void* dy, const void* wpd, void* dx, int accumulate, void* stream) {
+  if (check_conv(d, "conv2d_dgrad")) return -1;
+  return d->dtype == PLYOLO_BF16 ? conv_mfma_dgrad(d, dy, wpd, dx, accumulate, stream) : conv_ref_dgrad(d, dy, wpd, dx, accumulate, stream);
+}
+int plyolo_conv2d_wgrad(const plyolo_conv_desc* d, const void* x, const void* dy, float* dwp, void* stream) {
+  if (check_conv(d, "conv2d_wgrad")) return -1;
+  return d->dtype == PLYOLO_BF16 ? conv_mfma_wgrad(d, x, dy, dwp, stream) : conv_ref_wgrad(d, x, dy, dwp, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,108 @@
+// Shared host/device helpers for libplyolo_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../../include/plyolo.h"
+
+typedef unsigned short bf16_t;  // raw bf16 bits
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+#define DEVINL __device__ __forceinline__
+
+DEVINL float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+DEVINL bf16_t f2bf(float f) {
+  // round-to-nearest-even; NaN stays NaN (plain cast -> v_cvt_pk_bf16_f32 on gfx950)
+  __bf16 b = (__bf16)f;
+  return *(bf16_t*)&b;
+}
+DEVINL unsigned pack2bf(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+
+template <typename T> struct ActT;
+template <> struct ActT<bf16_t> {
+  static DEVINL float ld(const bf16_t* p) { return bf2f(*p); }
+  static DEVINL void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+template <> struct ActT<float> {
+  static DEVINL float ld(const float* p) { return *p; }
+  static DEVINL void st(float* p, float v) { *p = v; }
+};
+
+DEVINL float act_fwd(float u, int act) {
+  switch (act) {
+    case PLYOLO_ACT_SILU: return u / (1.0f + __expf(-u));
+    case PLYOLO_ACT_RELU: return u > 0.f ? u : 0.f;
+    case PLYOLO_ACT_LRELU: return u > 0.f ? u : 0.1f * u;
+    default: return u;
+  }
+}
+DEVINL float act_fwd_precise(float u, int act) {
+  switch (act) {
+    case PLYOLO_ACT_SILU: return u / (1.0f + expf(-u));
+    case PLYOLO_ACT_RELU: return u > 0.f ? u : 0.f;
+    case PLYOLO_ACT_LRELU: return u > 0.f ? u : 0.1f * u;
+    default: return u;
+  }
+}
+DEVINL float act_grad(float u, int act) {
+  switch (act) {
+    case PLYOLO_ACT_SILU: {
+      float s = 1.0f / (1.0f + expf(-u));
+      return s * (1.0f + u * (1.0f - s));
+    }
+    case PLYOLO_ACT_RELU: return u > 0.f ? 1.f : 0.f;
+    case PLYOLO_ACT_LRELU: return u > 0.f ? 1.f : 0.1f;
+    default: return 1.f;
+  }
+}
+
+// ---------------------------------------------------------------- host side
+namespace plyolo {
+
+void set_error(const char* fmt, ...);
+
+struct Plan {
+  std::vector<std::function<hipError_t(hipStream_t)>> ops;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+};
+Plan* recording_plan();
+
+// Either run `fn` now on `stream`, or append it to the plan being recorded.
+template <typename F> int submit(void* stream, F&& fn) {
+  Plan* p = recording_plan();
+  if (p) {
+    p->ops.emplace_back(std::forward<F>(fn));
+    return 0;
+  }
+  hipError_t e = fn((hipStream_t)stream);
+  if (e != hipSuccess) {
+    set_error("HIP launch failed: %s", hipGetErrorString(e));
+    return -2;
+  }
+  return 0;
+}
+
+inline hipError_t launch_status() { return hipGetLastError(); }
+
+}  // namespace plyolo
+
+#define PLY_CHECK_ARG(cond, ...)        \
+  do {                                  \
+    if (!(cond)) {                      \
+      plyolo::set_error(__VA_ARGS__);   \
+      return -1;                        \
+    }                                   \
+  } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t cdivz(size_t a, size_t b) { return (a + b - 1) / b; }

@@ -1,0 +1,581 @@
+// YOLOX loss side on gfx950: decode, SimOTA label assignment, IoU/obj/cls losses
+// (forward and analytic backward) and the eval decode.  fp32 throughout.
+//
+// Restates /root/reference semantics (file:line into Iywie/pl_YOLO):
+//   decode                      models/losses/yolox/yolox_loss.py:175-228
+//   get_in_boxes_info           models/losses/yolox/yolox_loss.py:231-315
+//   pair-wise cost              models/losses/yolox/yolox_loss.py:84-108
+//   dynamic_k_matching          models/losses/yolox/yolox_loss.py:318-370
+//   targets + losses            models/losses/yolox/yolox_loss.py:120-173
+//   bboxes_iou / IOUloss(giou)  models/layers/losses/iou_loss.py:391-414 / :7-50
+//
+// Structure (no [G, N_c, C] tensors are ever materialised, no host syncs):
+//   k_prep    one thread per anchor: decode, candidate mask, and for candidates the
+//             class-independent part of the BCE cost  S_a = sum_c -log(1-p_ac)
+//   k_topk    one workgroup per (image, GT): streams the candidates once, keeps the
+//             10 largest IoUs and the 10 cheapest (cost, anchor) pairs per thread,
+//             merges them with wavefront reductions, derives dynamic k and votes
+//   k_resolve one thread per anchor: 0 votes -> background, 1 vote -> that GT,
+//             >1 votes -> argmin over ALL GTs of the recomputed cost (lowest GT wins ties)
+//   k_loss    per-anchor loss terms, block partials;  k_final: fixed-order sum
+//   k_bwd     d(loss)/d(raw) for every (anchor, channel), coalesced
+// Tie rule: equal costs are ordered by lowest anchor index (the reference's
+// torch.sort is unstable there).
+#include "common.h"
+
+namespace {
+
+struct LossWs {
+  float* dec;      // [B,A,4]
+  float* S;        // [B,A]
+  uint8_t* cand;   // [B,A]
+  int* cnt;        // [B,A]
+  int* lastg;      // [B,A]
+  int* G;          // [B]
+  float* partial;  // [nblk,4]
+};
+
+constexpr int MAXM = 256;  // label rows per image supported by the LDS staging
+
+DEVINL float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+DEVINL int anchor_level(const plyolo_yolox_desc& d, int a) {
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < 8; ++i)
+    if (i < d.nlevels && a >= d.lvl_off[i]) l = i;
+  return l;
+}
+// The head output is LEVEL-major: level l is a dense NHWC block [B, h_l*w_l, 5+C] that starts
+// at row lvl_row[l]; row of (image b, anchor a):
+DEVINL size_t raw_row(const plyolo_yolox_desc& d, int b, int a) {
+  const int l = anchor_level(d, a);
+  return (size_t)d.lvl_row[l] + (size_t)b * (d.lvl_h[l] * d.lvl_w[l]) + (a - d.lvl_off[l]);
+}
+
+DEVINL void anchor_geom(const plyolo_yolox_desc& d, int a, float* xs, float* ys, float* st) {
+  const int l = anchor_level(d, a);
+  const int f = a - d.lvl_off[l];
+  // grid quirk kept verbatim (yolox_loss.py:198-200): (f % h, f / h); equals (f % w, f / w) for square maps
+  *xs = (float)(f % d.lvl_h[l]);
+  *ys = (float)(f / d.lvl_h[l]);
+  *st = (float)d.lvl_stride[l];
+}
+
+DEVINL float pair_iou(const float* gt, const float* pb) {
+  // bboxes_iou(xyxy=False): `en = (tl < br)` gate, no eps
+  const float tlx = fmaxf(gt[0] - gt[2] / 2, pb[0] - pb[2] / 2), tly = fmaxf(gt[1] - gt[3] / 2, pb[1] - pb[3] / 2);
+  const float brx = fminf(gt[0] + gt[2] / 2, pb[0] + pb[2] / 2), bry = fminf(gt[1] + gt[3] / 2, pb[1] + pb[3] / 2);
+  const float area_a = gt[2] * gt[3], area_b = pb[2] * pb[3];
+  const float en = (tlx < brx && tly < bry) ? 1.f : 0.f;
+  const float area_i = (brx - tlx) * (bry - tly) * en;
+  return area_i / (area_a + area_b - area_i);
+}
+
+DEVINL void in_masks(const float* gt, float xc, float yc, float st, bool* in_box, bool* in_ctr) {
+  const float l = gt[0] - 0.5f * gt[2], r = gt[0] + 0.5f * gt[2];
+  const float t = gt[1] - 0.5f * gt[3], b = gt[1] + 0.5f * gt[3];
+  *in_box = fminf(fminf(xc - l, yc - t), fminf(r - xc, b - yc)) > 0.0f;
+  const float rad = 2.5f * st;
+  const float cl = gt[0] - rad, cr = gt[0] + rad, ct = gt[1] - rad, cb = gt[1] + rad;
+  *in_ctr = fminf(fminf(xc - cl, yc - ct), fminf(cr - xc, cb - yc)) > 0.0f;
+}
+
+// cost[g,a] and iou[g,a] -- the ONE definition used by both k_topk and k_resolve
+DEVINL float pair_cost(const plyolo_yolox_desc& d, const float* raw_a, const float* dec_a, float S_a, const float* lab_g, float xc,
+                       float yc, float st, float* iou_out) {
+  const float iou = pair_iou(lab_g + 1, dec_a);
+  *iou_out = iou;
+  const float iou_cost = -logf(iou + 1e-8f);
+  const int cg = (int)lab_g[0];
+  const float p = sqrtf(sigmoidf_(raw_a[5 + cg]) * sigmoidf_(raw_a[4]));
+  // F.binary_cross_entropy: -(t*max(log p,-100) + (1-t)*max(log1p(-p),-100)); S_a holds the t=0 terms of all classes
+  const float t0 = -fmaxf(log1pf(-p), -100.0f);
+  const float t1 = -fmaxf(logf(p), -100.0f);
+  const float cls_cost = (S_a - t0) + t1;
+  bool ib, ic;
+  in_masks(lab_g + 1, xc, yc, st, &ib, &ic);
+  return (cls_cost + 3.0f * iou_cost) + 100000.0f * ((ib && ic) ? 0.0f : 1.0f);
+}
+
+__global__ void k_prep(const plyolo_yolox_desc d, const float* raw, const float* labels, LossWs ws) {
+  __shared__ float lab[MAXM * 5];
+  __shared__ int sG;
+  const int b = blockIdx.y;
+  const int nch = 5 + d.C;
+  for (int i = threadIdx.x; i < d.M * 5; i += blockDim.x) lab[i] = labels[(size_t)b * d.M * 5 + i];
+  if (threadIdx.x == 0) sG = 0;
+  __syncthreads();
+  {
+    int local = 0;
+    for (int g = threadIdx.x; g < d.M; g += blockDim.x) {
+      const float s = lab[g * 5] + lab[g * 5 + 1] + lab[g * 5 + 2] + lab[g * 5 + 3] + lab[g * 5 + 4];
+      local += s > 0.f ? 1 : 0;
+    }
+    if (local) atomicAdd(&sG, local);
+  }
+  __syncthreads();
+  const int G = sG;
+  if (blockIdx.x == 0 && threadIdx.x == 0) ws.G[b] = G;
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= d.A) return;
+  const size_t ba = (size_t)b * d.A + a;
+  const float* r = raw + raw_row(d, b, a) * nch;
+  float xs, ys, st;
+  anchor_geom(d, a, &xs, &ys, &st);
+  float dec[4];
+  dec[0] = (r[0] + xs) * st;
+  dec[1] = (r[1] + ys) * st;
+  dec[2] = expf(r[2]) * st;
+  dec[3] = expf(r[3]) * st;
+  *(f32x4*)(ws.dec + ba * 4) = f32x4{dec[0], dec[1], dec[2], dec[3]};
+  const float xc = xs * st + 0.5f * st, yc = ys * st + 0.5f * st;
+  bool any_box = false, any_ctr = false;
+  for (int g = 0; g < G; ++g) {
+    bool ib, ic;
+    in_masks(lab + g * 5 + 1, xc, yc, st, &ib, &ic);
+    any_box |= ib;
+    any_ctr |= ic;
+  }
+  const bool cand = any_box || any_ctr;
+  ws.cand[ba] = cand ? 1 : 0;
+  float S = 0.f;
+  if (cand) {
+    const float so = sigmoidf_(r[4]);
+    for (int c = 0; c < d.C; ++c) {
+      const float p = sqrtf(sigmoidf_(r[5 + c]) * so);
+      S += -fmaxf(log1pf(-p), -100.0f);
+    }
+  }
+  ws.S[ba] = S;
+}
+
+DEVINL unsigned orderable(float c) {
+  const unsigned u = __float_as_uint(c);
+  return (u & 0x80000000u) ? ~u : (u ^ 0x80000000u);  // monotone float -> uint
+}
+DEVINL float unorderable(unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u ^ 0x80000000u) : ~u); }
+// ascending sort key: (cost, anchor) -- equal costs resolve to the lowest anchor index
+DEVINL unsigned long long cost_key(float c, int idx) { return ((unsigned long long)orderable(c) << 32) | (unsigned)idx; }
+// descending sort key for IoU values; the low word only makes keys unique
+DEVINL unsigned long long iou_key(float v, int idx) { return ((unsigned long long)orderable(v) << 32) | (unsigned)(~idx); }
+
+DEVINL unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long other = __shfl_xor(v, o);
+    v = other < v ? other : v;
+  }
+  return v;
+}
+DEVINL unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long other = __shfl_xor(v, o);
+    v = other > v ? other : v;
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(256) void k_topk(const plyolo_yolox_desc d, const float* raw, const float* labels, LossWs ws) {
+  const int b = blockIdx.y, g = blockIdx.x;
+  if (g >= ws.G[b]) return;
+  const int nch = 5 + d.C;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ float lab_g[5];
+  __shared__ unsigned long long red_k[2][4], red_i[2][4];
+  __shared__ int red_n[4];
+  __shared__ int sel[10];
+  __shared__ int s_k, s_nc;
+  if (tid < 5) lab_g[tid] = labels[((size_t)b * d.M + g) * 5 + tid];
+  __syncthreads();
+  float gl[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) gl[i] = lab_g[i];
+
+  unsigned long long top_ik[10], top_key[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) { top_ik[i] = 0ull; top_key[i] = ~0ull; }
+  int nc = 0;
+  for (int a = tid; a < d.A; a += 256) {
+    const size_t ba = (size_t)b * d.A + a;
+    if (!ws.cand[ba]) continue;
+    ++nc;
+    float xs, ys, st;
+    anchor_geom(d, a, &xs, &ys, &st);
+    const float xc = xs * st + 0.5f * st, yc = ys * st + 0.5f * st;
+    float iou;
+    const float cost = pair_cost(d, raw + raw_row(d, b, a) * nch, ws.dec + ba * 4, ws.S[ba], gl, xc, yc, st, &iou);
+    unsigned long long x = iou_key(iou, a);
+    unsigned long long k = cost_key(cost, a);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      if (x > top_ik[i]) { const unsigned long long t = top_ik[i]; top_ik[i] = x; x = t; }
+      if (k < top_key[i]) { const unsigned long long t = top_key[i]; top_key[i] = k; k = t; }
+    }
+  }
+  {
+    int v = nc;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) red_n[wave] = v;
+    __syncthreads();
+    if (tid == 0) s_nc = red_n[0] + red_n[1] + red_n[2] + red_n[3];
+    __syncthreads();
+  }
+  const int NC = s_nc;
+  const int n_k = NC < 10 ? NC : 10;
+  // merge: 10 rounds; each thread exposes the head of its two sorted lists, the
+  // (unique) owner of the block-wide best key pops it.
+  float iou_sum = 0.f;
+  for (int round = 0; round < 10; ++round) {
+    const int pb = round & 1;
+    const unsigned long long hk = top_key[0], hi = top_ik[0];
+    unsigned long long mk = wave_min_u64(hk), mi = wave_max_u64(hi);
+    if (lane == 0) { red_k[pb][wave] = mk; red_i[pb][wave] = mi; }
+    __syncthreads();
+    mk = red_k[pb][0];
+    mi = red_i[pb][0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      mk = red_k[pb][w] < mk ? red_k[pb][w] : mk;
+      mi = red_i[pb][w] > mi ? red_i[pb][w] : mi;
+    }
+    if (round < n_k) iou_sum += unorderable((unsigned)(mi >> 32));  // descending, sequential fp32 sum
+    if (tid == 0) sel[round] = (int)(unsigned)(mk & 0xffffffffull);
+    if (hk == mk && mk != ~0ull) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) top_key[i] = top_key[i + 1];
+      top_key[9] = ~0ull;
+    }
+    if (hi == mi && mi != 0ull) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) top_ik[i] = top_ik[i + 1];
+      top_ik[9] = 0ull;
+    }
+  }
+  if (tid == 0) {
+    int k = (int)iou_sum;  // .int() truncation (yolox_loss.py:340)
+    if (k < 1) k = 1;
+    s_k = k;
+  }
+  __syncthreads();
+  const int k = s_k;
+  if (k < NC - 1) {
+    if (tid < k) {
+      const int a = sel[tid];
+      const size_t ba = (size_t)b * d.A + a;
+      atomicAdd(&ws.cnt[ba], 1);
+      ws.lastg[ba] = g;
+    }
+  } else {
+    // yolox_loss.py:343-344: k >= N_c - 1  ->  every candidate is taken
+    for (int a = tid; a < d.A; a += 256) {
+      const size_t ba = (size_t)b * d.A + a;
+      if (ws.cand[ba]) {
+        atomicAdd(&ws.cnt[ba], 1);
+        ws.lastg[ba] = g;
+      }
+    }
+  }
+}
+
+__global__ void k_resolve(const plyolo_yolox_desc d, const float* raw, const float* labels, LossWs ws, uint8_t* fg, int32_t* mgt,
+                          float* miou) {
+  const int b = blockIdx.y;
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= d.A) return;
+  const size_t ba = (size_t)b * d.A + a;
+  const int c = ws.cnt[ba];
+  if (c == 0) {
+    fg[ba] = 0;
+    mgt[ba] = -1;
+    miou[ba] = 0.f;
+    return;
+  }
+  const int nch = 5 + d.C;
+  float xs, ys, st;
+  anchor_geom(d, a, &xs, &ys, &st);
+  const float xc = xs * st + 0.5f * st, yc = ys * st + 0.5f * st;
+  const float* lab = labels + (size_t)b * d.M * 5;
+  const float* rawa = raw + raw_row(d, b, a) * nch;
+  int g = ws.lastg[ba];
+  float iou;
+  if (c > 1) {
+    const int G = ws.G[b];
+    float best = INFINITY;
+    g = 0;
+    for (int gg = 0; gg < G; ++gg) {
+      float io;
+      const float cost = pair_cost(d, rawa, ws.dec + ba * 4, ws.S[ba], lab + gg * 5, xc, yc, st, &io);
+      if (cost < best) { best = cost; g = gg; }
+    }
+  }
+  pair_cost(d, rawa, ws.dec + ba * 4, ws.S[ba], lab + g * 5, xc, yc, st, &iou);
+  fg[ba] = 1;
+  mgt[ba] = g;
+  miou[ba] = iou;
+}
+
+// IOUloss(loss_type="giou") of iou_loss.py:13-43 (note the (area_c - area_i)/area_c penalty) and its gradient
+DEVINL float giou_loss(const float* p, const float* t, float* grad /* d loss / d(cx,cy,w,h) or null */) {
+  const float plx = p[0] - p[2] / 2, ply = p[1] - p[3] / 2, phx = p[0] + p[2] / 2, phy = p[1] + p[3] / 2;
+  const float glx = t[0] - t[2] / 2, gly = t[1] - t[3] / 2, ghx = t[0] + t[2] / 2, ghy = t[1] + t[3] / 2;
+  const float tlx = fmaxf(plx, glx), tly = fmaxf(ply, gly), brx = fminf(phx, ghx), bry = fminf(phy, ghy);
+  const float area_p = p[2] * p[3], area_g = t[2] * t[3];
+  const float en = (tlx < brx && tly < bry) ? 1.f : 0.f;
+  const float iw = brx - tlx, ih = bry - tly;
+  const float I = iw * ih * en;
+  const float U = area_p + area_g - I + 1e-16f;
+  const float iou = I / U;
+  const float ctlx = fminf(plx, glx), ctly = fminf(ply, gly), cbrx = fmaxf(phx, ghx), cbry = fmaxf(phy, ghy);
+  const float cw = cbrx - ctlx, ch = cbry - ctly;
+  const float Ac = cw * ch;
+  const float ac = fmaxf(Ac, 1e-16f);
+  const float giou = iou - (Ac - I) / ac;
+  const float loss = 1.0f - fminf(fmaxf(giou, -1.0f), 1.0f);
+  if (grad) {
+    const float dL = (giou >= -1.0f && giou <= 1.0f) ? -1.0f : 0.0f;
+    const float dI = dL * ((U + I) / (U * U) + 1.0f / ac);
+    const float dAp = dL * (-I / (U * U));
+    const float dAc = dL * (-(1.0f / ac) + ((Ac >= 1e-16f) ? (Ac - I) / (ac * ac) : 0.0f));
+    // maximum/minimum backward: the larger (smaller) argument takes the gradient, ties split 1/2
+    auto wmax = [](float a, float b) { return a > b ? 1.0f : (a == b ? 0.5f : 0.0f); };
+    auto wmin = [](float a, float b) { return a < b ? 1.0f : (a == b ? 0.5f : 0.0f); };
+    const float g_phx = dI * ih * en * wmin(phx, ghx) + dAc * ch * wmax(phx, ghx);
+    const float g_plx = -dI * ih * en * wmax(plx, glx) - dAc * ch * wmin(plx, glx);
+    const float g_phy = dI * iw * en * wmin(phy, ghy) + dAc * cw * wmax(phy, ghy);
+    const float g_ply = -dI * iw * en * wmax(ply, gly) - dAc * cw * wmin(ply, gly);
+    grad[0] = g_phx + g_plx;
+    grad[1] = g_phy + g_ply;
+    grad[2] = 0.5f * (g_phx - g_plx) + dAp * p[3];
+    grad[3] = 0.5f * (g_phy - g_ply) + dAp * p[2];
+  }
+  return loss;
+}
+
+DEVINL float bce_logits(float x, float t) {
+  // (1-t)*x - log_sigmoid(x),  log_sigmoid(x) = min(x,0) - log1p(exp(-|x|))
+  return (1.0f - t) * x - (fminf(x, 0.0f) - log1pf(expf(-fabsf(x))));
+}
+
+__global__ __launch_bounds__(256) void k_loss(const plyolo_yolox_desc d, const float* raw, const float* labels, LossWs ws,
+                                              const uint8_t* fg, const int32_t* mgt, const float* miou) {
+  const size_t total = (size_t)d.B * d.A;
+  const int nch = 5 + d.C;
+  float s_iou = 0.f, s_obj = 0.f, s_cls = 0.f, s_fg = 0.f;
+  const size_t ba = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ba < total) {
+    const int b = (int)(ba / d.A);
+    const float* r = raw + raw_row(d, b, (int)(ba - (size_t)b * d.A)) * nch;
+    const bool f = fg[ba] != 0;
+    s_obj = bce_logits(r[4], f ? 1.0f : 0.0f);
+    if (f) {
+      const float* lg = labels + ((size_t)b * d.M + mgt[ba]) * 5;
+      s_fg = 1.f;
+      s_iou = giou_loss(ws.dec + ba * 4, lg + 1, nullptr);
+      const int cg = (int)lg[0];
+      const float io = miou[ba];
+      for (int c = 0; c < d.C; ++c) s_cls += bce_logits(r[5 + c], c == cg ? io : 0.0f);
+    }
+  }
+  __shared__ float red[4][4];
+  float v[4] = {s_iou, s_obj, s_cls, s_fg};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v[i] += __shfl_xor(v[i], o);
+  }
+  if ((threadIdx.x & 63) == 0)
+    for (int i = 0; i < 4; ++i) red[threadIdx.x >> 6][i] = v[i];
+  __syncthreads();
+  if (threadIdx.x < 4) ws.partial[(size_t)blockIdx.x * 4 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ void k_final(int nblk, int B, LossWs ws, float* losses) {
+  __shared__ double red[256][4];
+  double s[4] = {0, 0, 0, 0};
+  for (int i = threadIdx.x; i < nblk; i += 256)
+    for (int j = 0; j < 4; ++j) s[j] += ws.partial[(size_t)i * 4 + j];
+  for (int j = 0; j < 4; ++j) red[threadIdx.x][j] = s[j];
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o)
+      for (int j = 0; j < 4; ++j) red[threadIdx.x][j] += red[threadIdx.x + o][j];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    int ngt = 0;
+    for (int b = 0; b < B; ++b) ngt += ws.G[b];
+    const double nfg = red[0][3];
+    const double N = nfg > 1.0 ? nfg : 1.0;
+    const float li = (float)(red[0][0] / N), lo = (float)(red[0][1] / N), lc = (float)(red[0][2] / N);
+    losses[0] = 5.0f * li + lo + lc;
+    losses[1] = li;
+    losses[2] = lo;
+    losses[3] = lc;
+    losses[4] = (float)nfg;
+    losses[5] = (float)ngt;
+    losses[6] = (float)(N / (ngt > 1 ? (double)ngt : 1.0));  // proportion (yolox_loss.py:171)
+    losses[7] = 0.f;
+  }
+}
+
+// d(sum_i gout[i]*losses[i]) / d(raw): losses[0] = 5*iou + obj + cls, so the three terms carry
+// w_iou = 5*g0+g1, w_obj = g0+g2, w_cls = g0+g3.  One thread per (level-major row, channel).
+template <bool BF16OUT>
+__global__ void k_bwd(const plyolo_yolox_desc d, const float* raw, const float* labels, const uint8_t* fg, const int32_t* mgt,
+                      const float* miou, const float* losses, const float* gout, float* draw, bf16_t* d_regobj, bf16_t* d_cls,
+                      int cls_ld) {
+  const int nch = 5 + d.C;
+  const size_t total = (size_t)d.B * d.A * nch;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const size_t row = idx / nch;
+  const int c = (int)(idx - row * nch);
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < 8; ++i)
+    if (i < d.nlevels && row >= (size_t)d.lvl_row[i]) l = i;
+  const int hw = d.lvl_h[l] * d.lvl_w[l];
+  const int rr = (int)(row - d.lvl_row[l]);
+  const int b = rr / hw;
+  const int a = d.lvl_off[l] + (rr - b * hw);
+  const size_t ba = (size_t)b * d.A + a;
+  const float g0 = gout ? gout[0] : 1.0f;
+  const float w_iou = gout ? 5.0f * g0 + gout[1] : 5.0f, w_obj = gout ? g0 + gout[2] : 1.0f, w_cls = gout ? g0 + gout[3] : 1.0f;
+  const float nfg = losses[4];
+  const float invN = 1.0f / (nfg > 1.0f ? nfg : 1.0f);
+  const float* r = raw + row * nch;
+  const bool f = fg[ba] != 0;
+  float g = 0.f;
+  if (c == 4) {
+    g = (sigmoidf_(r[4]) - (f ? 1.0f : 0.0f)) * invN * w_obj;
+  } else if (f) {
+    const float* lg = labels + ((size_t)b * d.M + mgt[ba]) * 5;
+    if (c >= 5) {
+      const float t = (c - 5 == (int)lg[0]) ? miou[ba] : 0.0f;
+      g = (sigmoidf_(r[c]) - t) * invN * w_cls;
+    } else {
+      float xs, ys, st;
+      anchor_geom(d, a, &xs, &ys, &st);
+      float p[4] = {(r[0] + xs) * st, (r[1] + ys) * st, expf(r[2]) * st, expf(r[3]) * st};
+      float gr[4];
+      giou_loss(p, lg + 1, gr);
+      const float chain = (c < 2) ? st : p[c];  // d cx/d tx = s ; d w/d tw = w
+      g = w_iou * gr[c] * chain * invN;
+    }
+  }
+  if (BF16OUT) {
+    if (c < 5) d_regobj[row * 16 + c] = f2bf(g);
+    else d_cls[row * cls_ld + (c - 5)] = f2bf(g);
+  } else {
+    draw[idx] = g;
+  }
+}
+
+// eval branch: out is BATCH-major [B,A,5+C] (the reference's return layout)
+__global__ void k_eval_decode(const plyolo_yolox_desc d, const float* raw, float* out) {
+  const int nch = 5 + d.C;
+  const size_t total = (size_t)d.B * d.A * nch;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const size_t ba = idx / nch;
+  const int c = (int)(idx - ba * nch);
+  const int b = (int)(ba / d.A), a = (int)(ba - (size_t)b * d.A);
+  const float* r = raw + raw_row(d, b, a) * nch;
+  float v;
+  if (c >= 4) {
+    v = sigmoidf_(r[c]);
+  } else {
+    float xs, ys, st;
+    anchor_geom(d, a, &xs, &ys, &st);
+    const int ax = c & 1;  // 0: x, 1: y
+    const float ctr = (r[ax] + (ax ? ys : xs)) * st;
+    const float ext = expf(r[2 + ax]) * st;
+    v = (c < 2) ? ctr - ext / 2 : ctr + ext / 2;
+  }
+  out[idx] = v;
+}
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+LossWs carve(const plyolo_yolox_desc* d, void* workspace, size_t* used) {
+  const size_t BA = (size_t)d->B * d->A;
+  unsigned char* p = (unsigned char*)workspace;
+  size_t off = 0;
+  LossWs ws;
+  ws.dec = (float*)(p + off); off += align256(BA * 16);
+  ws.S = (float*)(p + off); off += align256(BA * 4);
+  ws.cnt = (int*)(p + off); off += align256(BA * 4);
+  ws.lastg = (int*)(p + off); off += align256(BA * 4);
+  ws.cand = (uint8_t*)(p + off); off += align256(BA);
+  ws.G = (int*)(p + off); off += align256((size_t)d->B * 4);
+  const size_t nblk = (BA + 255) / 256;
+  ws.partial = (float*)(p + off); off += align256(nblk * 16);
+  *used = off;
+  return ws;
+}
+
+}  // namespace
+
+using plyolo::submit;
+
+extern "C" {
+
+size_t plyolo_yolox_workspace(const plyolo_yolox_desc* d) {
+  size_t used;
+  carve(d, nullptr, &used);
+  return used;
+}
+
+int plyolo_yolox_loss_fwd(const plyolo_yolox_desc* dp, const float* raw, const float* labels, uint8_t* fg, int32_t* matched_gt,
+                          float* matched_iou, float* losses, void* workspace, size_t ws_bytes, void* stream) {
+  const plyolo_yolox_desc d = *dp;
+  PLY_CHECK_ARG(d.M <= MAXM, "yolox_loss: at most %d label rows per image (got %d)", MAXM, d.M);
+  PLY_CHECK_ARG(d.nlevels >= 1 && d.nlevels <= 8, "yolox_loss: 1..8 levels");
+  size_t need;
+  const LossWs ws = carve(&d, workspace, &need);
+  PLY_CHECK_ARG(ws_bytes >= need, "yolox_loss: workspace too small (%zu < %zu)", ws_bytes, need);
+  const size_t BA = (size_t)d.B * d.A;
+  const int nblk = (int)((BA + 255) / 256);
+  return submit(stream, [=](hipStream_t s) -> hipError_t {
+    hipError_t e = hipMemsetAsync(ws.cnt, 0, BA * 4, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_prep, dim3(cdiv(d.A, 256), d.B), dim3(256), 0, s, d, raw, labels, ws);
+    hipLaunchKernelGGL(k_topk, dim3(d.M, d.B), dim3(256), 0, s, d, raw, labels, ws);
+    hipLaunchKernelGGL(k_resolve, dim3(cdiv(d.A, 256), d.B), dim3(256), 0, s, d, raw, labels, ws, fg, matched_gt, matched_iou);
+    hipLaunchKernelGGL(k_loss, dim3(nblk), dim3(256), 0, s, d, raw, labels, ws, fg, matched_gt, matched_iou);
+    hipLaunchKernelGGL(k_final, dim3(1), dim3(256), 0, s, nblk, d.B, ws, losses);
+    return hipGetLastError();
+  });
+}
+
+int plyolo_yolox_loss_bwd(const plyolo_yolox_desc* dp, const float* raw, const float* labels, const uint8_t* fg,
+                          const int32_t* matched_gt, const float* matched_iou, const float* losses, const float* gout,
+                          float* draw_f32, void* d_regobj, void* d_cls, int cls_ld, void* stream) {
+  const plyolo_yolox_desc d = *dp;
+  PLY_CHECK_ARG((draw_f32 != nullptr) != (d_regobj != nullptr && d_cls != nullptr), "yolox_loss_bwd: give draw_f32 OR (d_regobj, d_cls)");
+  const size_t total = (size_t)d.B * d.A * (5 + d.C);
+  const unsigned grid = (unsigned)cdivz(total, 256);
+  return submit(stream, [=](hipStream_t s) -> hipError_t {
+    if (draw_f32)
+      hipLaunchKernelGGL(k_bwd<false>, dim3(grid), dim3(256), 0, s, d, raw, labels, fg, matched_gt, matched_iou, losses, gout, draw_f32,
+                         (bf16_t*)nullptr, (bf16_t*)nullptr, 0);
+    else
+      hipLaunchKernelGGL(k_bwd<true>, dim3(grid), dim3(256), 0, s, d, raw, labels, fg, matched_gt, matched_iou, losses, gout,
+                         (float*)nullptr, (bf16_t*)d_regobj, (bf16_t*)d_cls, cls_ld);
+    return hipGetLastError();
+  });
+}
+
+int plyolo_yolox_eval_decode(const plyolo_yolox_desc* dp, const float* raw, float* out, void* stream) {
+  const plyolo_yolox_desc d = *dp;
+  const size_t total = (size_t)d.B * d.A * (5 + d.C);
+  return submit(stream, [=](hipStream_t s) -> hipError_t {
+    hipLaunchKernelGGL(k_eval_decode, dim3((unsigned)cdivz(total, 256)), dim3(256), 0, s, d, raw, out);
+    return hipGetLastError();
+  });
+}
+
+}  // extern "C"
