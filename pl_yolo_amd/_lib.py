@@ -1,0 +1,133 @@
+"""ctypes binding of libplyolo_hip.so (the C ABI declared in include/plyolo.h).
+
+There is NO fallback: if the shared library is missing or an entry point fails the
+caller gets an exception (`PlyoloError`).  The library is built in-tree by
+`__graft_entry__.build()` / `make -C pl_yolo_amd/csrc`.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libplyolo_hip.so")
+
+BF16, F32 = 0, 1
+ACT = {None: 0, "silu": 1, "relu": 2, "lrelu": 3}
+
+
+class PlyoloError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("dtype", "N", "H", "W", "Cin", "Cout", "ksize", "stride", "x_ld", "y_ld", "y_f32")]
+
+
+class PackEntry(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("w", "wp", "wpd", "dwp", "dw", "b", "bp", "dbp", "db")] + [
+        (n, C.c_int) for n in ("Cout", "Cin", "Cin_p", "ksize", "Cout_total", "Cout_p8", "co_off", "pad_")
+    ]
+
+
+class YoloxDesc(C.Structure):
+    _fields_ = [
+        ("B", C.c_int), ("A", C.c_int), ("C", C.c_int), ("M", C.c_int), ("nlevels", C.c_int),
+        ("lvl_h", C.c_int * 8), ("lvl_w", C.c_int * 8), ("lvl_stride", C.c_int * 8),
+        ("lvl_off", C.c_int * 8), ("lvl_row", C.c_int * 8),
+    ]
+
+
+class NmsDesc(C.Structure):
+    _fields_ = [
+        ("B", C.c_int), ("A", C.c_int), ("C", C.c_int), ("conf_thre", C.c_float), ("nms_thre", C.c_float),
+        ("class_agnostic", C.c_int), ("max_nms", C.c_int), ("max_det", C.c_int), ("numel_threshold", C.c_int),
+    ]
+
+
+_vp, _i, _f, _d, _sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
+_P = C.POINTER
+
+# name -> (restype, argtypes); every symbol include/plyolo.h declares
+SIGNATURES = {
+    "plyolo_version": (_i, []),
+    "plyolo_arch": (C.c_char_p, []),
+    "plyolo_last_error": (C.c_char_p, []),
+    "plyolo_plan_create": (_vp, []),
+    "plyolo_plan_destroy": (None, [_vp]),
+    "plyolo_plan_begin": (_i, [_vp]),
+    "plyolo_plan_end": (_i, [_vp]),
+    "plyolo_plan_size": (_i, [_vp]),
+    "plyolo_plan_run": (_i, [_vp, _vp]),
+    "plyolo_plan_graph_instantiate": (_i, [_vp, _vp]),
+    "plyolo_plan_graph_launch": (_i, [_vp, _vp]),
+    "plyolo_conv2d_fwd": (_i, [_P(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
+    "plyolo_conv2d_stat_rows": (_i, [_P(ConvDesc)]),
+    "plyolo_conv2d_dgrad": (_i, [_P(ConvDesc), _vp, _vp, _vp, _i, _vp]),
+    "plyolo_conv2d_wgrad": (_i, [_P(ConvDesc), _vp, _vp, _vp, _vp]),
+    "plyolo_bias_grad": (_i, [_i, _vp, _i, _i, _i, _vp, _vp]),
+    "plyolo_pack_weights": (_i, [_vp, _i, _i, _i, _vp]),
+    "plyolo_unpack_wgrads": (_i, [_vp, _i, _i, _i, _vp]),
+    "plyolo_bn_finalize": (_i, [_vp, _i, _i, _d, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "plyolo_bn_eval_coef": (_i, [_i, _vp, _vp, _vp, _vp, _f, _vp, _vp]),
+    "plyolo_bn_act_fwd": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp]),
+    "plyolo_bn_bwd_rows": (_i, [_i]),
+    "plyolo_bn_act_bwd_reduce": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp]),
+    "plyolo_bn_bwd_finalize": (_i, [_vp, _i, _i, _d, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "plyolo_bn_act_bwd_dz": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp]),
+    "plyolo_focus_s2d": (_i, [_i, _vp, _i, _i, _i, _vp, _i, _vp]),
+    "plyolo_copy_add": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _i, _vp]),
+    "plyolo_upsample2x_fwd": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
+    "plyolo_upsample2x_bwd": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp]),
+    "plyolo_maxpool_s1_fwd": (_i, [_i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
+    "plyolo_maxpool_s1_bwd": (_i, [_i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp]),
+    "plyolo_f32_to_act": (_i, [_i, _i, _i, _vp, _vp, _i, _i, _vp]),
+    "plyolo_memset_async": (_i, [_vp, _i, _sz, _vp]),
+    "plyolo_nhwc_to_nchw_f32": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "plyolo_nchw_f32_to_nhwc": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "plyolo_yolox_workspace": (_sz, [_P(YoloxDesc)]),
+    "plyolo_yolox_loss_fwd": (_i, [_P(YoloxDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "plyolo_yolox_loss_bwd": (_i, [_P(YoloxDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "plyolo_yolox_eval_decode": (_i, [_P(YoloxDesc), _vp, _vp, _vp]),
+    "plyolo_postprocess_workspace": (_sz, [_P(NmsDesc)]),
+    "plyolo_postprocess": (_i, [_P(NmsDesc), _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "plyolo_batched_nms": (_i, [_P(NmsDesc), _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "plyolo_sgd_momentum": (_i, [_vp, _vp, _vp, _sz, _vp, _f, _f, _i, _vp]),
+    "plyolo_ema_update": (_i, [_vp, _vp, _sz, _f, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the shared library; raise if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PlyoloError(
+                "libplyolo_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C pl_yolo_amd/csrc`. There is no CPU fallback." % LIB_PATH
+            )
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().plyolo_last_error()
+        raise PlyoloError("%s failed (rc=%d): %s" % (what or "plyolo call", rc, msg.decode() if msg else "?"))
+
+
+def call(name, *args):
+    """Call an int-returning entry point and raise on a non-zero status."""
+    rc = getattr(lib(), name)(*args)
+    if rc != 0:
+        check(rc, name)
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()

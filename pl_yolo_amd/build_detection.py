@@ -1,0 +1,113 @@
+"""Model+loss provider with the reference's plugin API
+(reference PL_Modules/build_detection.py:23-144).
+
+    build_model(cfg_models, num_classes) -> OneStageD
+    OneStageD(backbone, neck, head, loss).forward(x, labels=None)
+
+Plugin factories are looked up by the YAML `name` exactly like the reference (which
+uses eval(name)); unknown names raise NameError, missing YAML keys KeyError.  The
+returned module exposes .backbone/.neck/.head/.loss with the reference's state_dict
+key layout, so `LitDetection` (PL_Modules/pl_detection.py) can use it unchanged as
+`self.model`: training_step -> model(imgs, labels) -> dict of losses whose 'loss'
+entry back-propagates into ordinary nn.Parameter .grad tensors.
+"""
+import os
+
+import torch
+import torch.nn as nn
+
+from ._lib import PlyoloError
+from .backbones import CSPDarkNet
+from .necks import CSPPAFPN
+from .heads import DecoupledHead
+from .losses import YOLOXLoss
+from . import runner as R
+
+
+def build_model(cfg_models, num_classes):
+    cb = cfg_models['backbone']
+    cn = cfg_models['neck']
+    ch = cfg_models['head']
+    cl = cfg_models['loss']
+    backbone = _plugin(cb['name'])(cb)
+    neck = _plugin(cn['name'])(cn)
+    head = _plugin(ch['name'])(ch, num_classes)
+    loss = _plugin(cl['name'])(cl, num_classes)
+    return OneStageD(backbone, neck, head, loss)
+
+
+class OneStageD(nn.Module):
+    """backbone -> neck -> head -> (loss if labels is not None), executed as HIP launch
+    plans on one MI355X.  `compute_dtype`: "bf16" (MFMA path, default) or "fp32"
+    (parity mode); env PLYOLO_DTYPE overrides the default."""
+
+    def __init__(self, backbone=None, neck=None, head=None, loss=None):
+        super().__init__()
+        self.backbone = backbone
+        self.neck = neck
+        self.head = head
+        self.loss = loss
+        self.compute_dtype = os.environ.get("PLYOLO_DTYPE", "bf16")
+        self.__dict__['_runner'] = None
+
+    def runner(self):
+        r = self.__dict__.get('_runner')
+        want = self.compute_dtype
+        if r is None or r.dtype_name != want:
+            if want not in ("bf16", "fp32"):
+                raise PlyoloError("compute_dtype must be 'bf16' or 'fp32'")
+            r = R.DetectorRunner(self, want)
+            r.dtype_name = want
+            self.__dict__['_runner'] = r
+        return r
+
+    def forward(self, x, labels=None):
+        r = self.runner()
+        if labels is None:
+            return r.forward_maps(x)           # list of raw NCHW head maps (build_detection.py:51-52)
+        if not self.training:
+            return r.forward_eval(x)           # [B, A, 5+C]: x1,y1,x2,y2,sig(obj),sig(cls) (yolox_loss.py:25-36)
+        out = R.train_step(r, x, labels)       # fp32[8], differentiable
+        return {
+            "loss": out[0],
+            "loss_iou": out[1],
+            "loss_obj": out[2],
+            "loss_cls": out[3],
+            "loss_l1": 0.0,
+            "proportion": out[6].detach(),
+        }
+
+
+# ---- plugin registry (names as in the reference YAMLs) --------------------------
+def cspdarknet(cfg):
+    return CSPDarkNet(cfg['depths'], cfg['channels'], cfg['outputs'], cfg['norm'], cfg['act'])
+
+
+def csppafpn(cfg):
+    return CSPPAFPN(cfg['depths'], cfg['channels'], cfg['norm'], cfg['act'])
+
+
+def none(cfg):
+    return None
+
+
+def decoupled_head(cfg, num_classes):
+    return DecoupledHead(num_classes, cfg['num_anchor'], cfg['channels'], cfg['norm'], cfg['act'])
+
+
+def yolox(cfg, num_classes):
+    return YOLOXLoss(num_classes, cfg['stride'])
+
+
+_REGISTRY = {f.__name__: f for f in (cspdarknet, csppafpn, none, decoupled_head, yolox)}
+# reference plugins that exist upstream but are outside this build's hot path
+_KNOWN_UNBUILT = ("cspmobilenext", "eelan", "ecmnet", "shufflenetv2", "mobilenetv3s", "mobilenetv3l",
+                  "vision_transformer", "swin_transformer", "al_pafpn", "yolov7neck", "implicit_head", "yolov7")
+
+
+def _plugin(name):
+    if name in _REGISTRY:
+        return _REGISTRY[name]
+    if name in _KNOWN_UNBUILT:
+        raise NotImplementedError("plugin '%s' is part of the reference but has no HIP path in this build yet" % name)
+    raise NameError("name '%s' is not defined" % name)

@@ -28,7 +28,7 @@ int conv_ref_fwd(const plyolo_conv_desc*, const void*, const void*, const float*
 int conv_ref_dgrad(const plyolo_conv_desc*, const void*, const void*, void*, int, void*);
 int conv_ref_wgrad(const plyolo_conv_desc*, const void*, const void*, float*, void*);
 
-static int check_conv(const plyolo_conv_desc* d, const char* who) {
+static int check_conv(const plyolo_conv_desc* d, const char* who, bool fwd) {
   PLY_CHECK_ARG(d != nullptr, "%s: null descriptor", who);
   PLY_CHECK_ARG(d->dtype == PLYOLO_BF16 || d->dtype == PLYOLO_F32, "%s: bad dtype %d", who, d->dtype);
   PLY_CHECK_ARG(d->ksize == 1 || d->ksize == 3, "%s: ksize must be 1 or 3 (got %d)", who, d->ksize);
@@ -37,7 +37,8 @@ static int check_conv(const plyolo_conv_desc* d, const char* who) {
   PLY_CHECK_ARG(d->x_ld >= d->Cin, "%s: x_ld %d < Cin %d", who, d->x_ld, d->Cin);
   if (d->dtype == PLYOLO_BF16) {
     PLY_CHECK_ARG(d->Cin % 8 == 0 && d->x_ld % 8 == 0, "%s: bf16 path needs Cin and x_ld multiples of 8 (Cin %d, x_ld %d)", who, d->Cin, d->x_ld);
-    if (!d->y_f32) PLY_CHECK_ARG(d->Cout % 8 == 0 && d->y_ld % 8 == 0, "%s: bf16 output needs Cout and y_ld multiples of 8 (Cout %d, y_ld %d)", who, d->Cout, d->y_ld);
+    if (fwd && !d->y_f32) PLY_CHECK_ARG(d->Cout % 8 == 0 && d->y_ld % 8 == 0, "%s: bf16 output needs Cout and y_ld multiples of 8 (Cout %d, y_ld %d)", who, d->Cout, d->y_ld);
+    if (!fwd) PLY_CHECK_ARG(d->y_ld % 8 == 0 && d->y_ld >= ((d->Cout + 7) & ~7), "%s: bf16 dy rows must hold Cout rounded up to 8 channels (Cout %d, y_ld %d)", who, d->Cout, d->y_ld);
   }
   return 0;
 }
@@ -114,19 +115,19 @@ int plyolo_plan_graph_launch(plyolo_plan* p, void* stream) {
 }
 
 int plyolo_conv2d_stat_rows(const plyolo_conv_desc* d) {
-  if (check_conv(d, "conv2d_stat_rows")) return -1;
+  if (check_conv(d, "conv2d_stat_rows", true)) return -1;
   return d->dtype == PLYOLO_BF16 ? conv_mfma_stat_rows(d) : conv_ref_stat_rows(d);
 }
 int plyolo_conv2d_fwd(const plyolo_conv_desc* d, const void* x, const void* wp, const float* bias, void* y, float* stats, void* stream) {
-  if (check_conv(d, "conv2d_fwd")) return -1;
+  if (check_conv(d, "conv2d_fwd", true)) return -1;
   return d->dtype == PLYOLO_BF16 ? conv_mfma_fwd(d, x, wp, bias, y, stats, stream) : conv_ref_fwd(d, x, wp, bias, y, stats, stream);
 }
 int plyolo_conv2d_dgrad(const plyolo_conv_desc* d, const void* dy, const void* wpd, void* dx, int accumulate, void* stream) {
-  if (check_conv(d, "conv2d_dgrad")) return -1;
+  if (check_conv(d, "conv2d_dgrad", false)) return -1;
   return d->dtype == PLYOLO_BF16 ? conv_mfma_dgrad(d, dy, wpd, dx, accumulate, stream) : conv_ref_dgrad(d, dy, wpd, dx, accumulate, stream);
 }
 int plyolo_conv2d_wgrad(const plyolo_conv_desc* d, const void* x, const void* dy, float* dwp, void* stream) {
-  if (check_conv(d, "conv2d_wgrad")) return -1;
+  if (check_conv(d, "conv2d_wgrad", false)) return -1;
   return d->dtype == PLYOLO_BF16 ? conv_mfma_wgrad(d, x, dy, dwp, stream) : conv_ref_wgrad(d, x, dy, dwp, stream);
 }
 

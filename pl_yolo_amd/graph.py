@@ -1,0 +1,548 @@
+"""Launch-plan builder: lowers a traced detector graph to recorded HIP launches.
+
+The Python module tree (pl_yolo_amd.layers / backbones / necks / heads / losses,
+mirroring the reference's plugin classes) owns the parameters and *describes* the
+network by calling the emit helpers of a `Graph`.  The graph is shape-specialised,
+then lowered once into two launch plans inside libplyolo_hip.so (forward and
+backward: `plyolo_plan_*`), which are replayed -- eagerly or as a captured hipGraph --
+for every step.  No tracing compiler, no per-op Python dispatch on the hot path.
+
+Memory model (HBM, everything resident for the whole run):
+  * activations: NHWC matrices `[N*H*W, ld]` (`Storage`); channel concatenation is a
+    strided view (`Act.c_off`) into a wider Storage, so `torch.cat` never copies;
+  * every conv unit keeps its raw conv output `z` (for the BN/SiLU backward), its
+    per-channel coefficients and the packed bf16 weights;
+  * gradients mirror the activation storages; "first writer writes, later writers
+    accumulate" is resolved at lowering time (no zero-fill passes).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import BF16, F32, ACT, ConvDesc, PackEntry, YoloxDesc, call, ptr
+
+BN_EPS_DEFAULT = 1e-3
+
+
+def _align(n, a=64):
+    return (n + a - 1) // a * a
+
+
+class Storage:
+    """A dense [rows, ld] activation matrix (rows = N*H*W pixels)."""
+
+    def __init__(self, N, H, W, ld, name=""):
+        self.N, self.H, self.W, self.ld, self.name = N, H, W, ld, name
+        self.rows = N * H * W
+        self.tensor = None
+        self.grad = None
+        self.ginit = [False] * ld  # per channel: has the gradient been written yet (lowering-time state)
+        self.views = 0
+
+
+class Act:
+    """A channel slice [c_off, c_off+C) of a Storage."""
+
+    def __init__(self, storage, C_, c_off=0):
+        self.storage, self.C, self.c_off = storage, C_, c_off
+        storage.views += 1
+        self.fixed = False  # True once something depends on the placement
+
+    N = property(lambda s: s.storage.N)
+    H = property(lambda s: s.storage.H)
+    W = property(lambda s: s.storage.W)
+    ld = property(lambda s: s.storage.ld)
+    M = property(lambda s: s.storage.rows)
+
+    def rebind(self, storage, c_off):
+        self.storage.views -= 1
+        self.storage, self.c_off = storage, c_off
+        storage.views += 1
+
+
+class Graph:
+    def __init__(self, dtype, training, device):
+        self.dtype = dtype
+        self.training = training
+        self.device = device
+        self.tdtype = torch.bfloat16 if dtype == BF16 else torch.float32
+        self.esize = 2 if dtype == BF16 else 4
+        self.vec = 8 if dtype == BF16 else 4
+        self.storages = []
+        self.ops = []
+        self.convs = []      # PackedConv records (weight arena bookkeeping)
+        self.keep = []       # tensors that must outlive the plans
+        self.scratch_elems = 0  # shared dz scratch (activation dtype)
+        self.scratch_f32 = 0    # shared fp32 scratch (maxpool backward)
+        self.image_act = None
+
+    # ------------------------------------------------------------------ tracing
+    def new_act(self, N, H, W, C_, name=""):
+        st = Storage(N, H, W, C_, name)
+        self.storages.append(st)
+        return Act(st, C_)
+
+    def concat(self, acts):
+        """torch.cat(dim=1) as a zero-copy strided placement whenever the inputs are
+        fresh producer outputs; otherwise a copy op is inserted."""
+        a0 = acts[0]
+        total = sum(a.C for a in acts)
+        st = Storage(a0.N, a0.H, a0.W, total, "cat")
+        self.storages.append(st)
+        off = 0
+        for a in acts:
+            assert (a.N, a.H, a.W) == (a0.N, a0.H, a0.W), "concat: spatial mismatch"
+            if (not a.fixed) and a.storage.views == 1 and a.c_off == 0 and a.storage.ld == a.C:
+                old = a.storage
+                a.rebind(st, off)
+                a.fixed = True
+                self.storages.remove(old)
+            else:
+                dst = Act(st, a.C, off)
+                self.ops.append(CopyOp(self, a, dst))
+            off += a.C
+        out = Act(st, total, 0)
+        out.fixed = True
+        return out
+
+    # --------------------------------------------------------------- allocation
+    def allocate(self):
+        dev = self.device
+        for st in self.storages:
+            st.tensor = torch.empty(st.rows * st.ld, dtype=self.tdtype, device=dev)
+        self.scratch = torch.empty(max(self.scratch_elems, 8), dtype=self.tdtype, device=dev)
+        self.scratch32 = torch.zeros(max(self.scratch_f32, 8), dtype=torch.float32, device=dev)
+        # weight arenas
+        wp_n = sum(_align(c.wp_elems) for c in self.convs)
+        wpd_n = sum(_align(c.wpd_elems) for c in self.convs)
+        self.wp_arena = torch.zeros(max(wp_n, 8), dtype=self.tdtype, device=dev)
+        self.wpd_arena = torch.zeros(max(wpd_n, 8), dtype=self.tdtype, device=dev)
+        self.dwp_arena = torch.zeros(max(wp_n, 8), dtype=torch.float32, device=dev)
+        nb = sum(_align(c.Cout_total) for c in self.convs)
+        self.bias_arena = torch.zeros(max(nb, 8), dtype=torch.float32, device=dev)
+        self.dbias_arena = torch.zeros(max(nb, 8), dtype=torch.float32, device=dev)
+        o1 = o2 = o3 = 0
+        entries = []
+        self.max_pack_elems = 8
+        for c in self.convs:
+            c.wp = self.wp_arena.data_ptr() + o1 * self.esize
+            c.dwp = self.dwp_arena.data_ptr() + o1 * 4
+            c.wpd = self.wpd_arena.data_ptr() + o2 * self.esize if c.need_dgrad else None
+            c.bp = self.bias_arena.data_ptr() + o3 * 4
+            c.dbp = self.dbias_arena.data_ptr() + o3 * 4
+            o1 += _align(c.wp_elems)
+            o2 += _align(c.wpd_elems)
+            o3 += _align(c.Cout_total)
+            for (w, b, co_off) in c.sources:
+                e = PackEntry()
+                e.w = w.data_ptr()
+                e.wp, e.wpd, e.dwp = c.wp, c.wpd, c.dwp
+                e.dw = None
+                e.b = b.data_ptr() if b is not None else None
+                e.bp, e.dbp, e.db = c.bp, c.dbp, None
+                e.Cout, e.Cin, e.Cin_p, e.ksize = w.shape[0], w.shape[1], c.Cin_p, c.ksize
+                e.Cout_total, e.Cout_p8, e.co_off, e.pad_ = c.Cout_total, c.Cout_p8, co_off, 0
+                entries.append((e, w, b))
+                self.max_pack_elems = max(self.max_pack_elems, c.ksize * c.ksize * w.shape[0] * c.Cin_p)
+        self.pack_entries = entries
+
+    def build_pack_table(self, grad_ptr_of):
+        """Device copy of the PackEntry table; `grad_ptr_of(param)` -> device address of
+        that parameter's gradient (inside the flat gradient buffer) or None."""
+        n = len(self.pack_entries)
+        arr = (PackEntry * max(n, 1))()
+        for i, (e, w, b) in enumerate(self.pack_entries):
+            e.dw = grad_ptr_of(w)
+            e.db = grad_ptr_of(b) if b is not None else None
+            arr[i] = e
+        raw = bytes(arr)
+        host = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+        self.pack_table = host.to(self.device)
+        self.n_pack = n
+
+    # ----------------------------------------------------------------- gradients
+    def grad_storage(self, st):
+        if st.grad is None:
+            st.grad = torch.empty(st.rows * st.ld, dtype=self.tdtype, device=self.device)
+        return st.grad
+
+    def aptr(self, a):
+        return a.storage.tensor.data_ptr() + a.c_off * self.esize
+
+    def gptr(self, a):
+        return self.grad_storage(a.storage).data_ptr() + a.c_off * self.esize
+
+    def grad_ready(self, a):
+        s = a.storage.ginit[a.c_off:a.c_off + a.C]
+        return all(s)
+
+    def grad_mode(self, a):
+        """Prepare writing a gradient contribution into view `a`: returns the accumulate
+        flag (0 = first writer).  A partially initialised view gets its missing channels
+        zero-filled first so that a single accumulate launch is correct."""
+        st = a.storage
+        flags = st.ginit[a.c_off:a.c_off + a.C]
+        if not any(flags):
+            acc = 0
+        elif all(flags):
+            acc = 1
+        else:
+            c = 0
+            while c < a.C:
+                if not flags[c]:
+                    e = c
+                    while e < a.C and not flags[e]:
+                        e += 1
+                    assert c % self.vec == 0 and (e - c) % self.vec == 0
+                    call("plyolo_copy_add", self.dtype, a.M, e - c, None, 0,
+                         self.grad_storage(st).data_ptr() + (a.c_off + c) * self.esize, st.ld, 0, None)
+                    c = e
+                else:
+                    c += 1
+            acc = 1
+        for i in range(a.c_off, a.c_off + a.C):
+            st.ginit[i] = True
+        return acc
+
+
+class PackedConv:
+    """Bookkeeping for one packed convolution (possibly fed by several torch convs)."""
+
+    def __init__(self, g, sources, ksize, Cin_p, need_dgrad=True):
+        self.sources = sources  # list of (weight Parameter, bias Parameter|None, co_off)
+        self.ksize, self.Cin_p = ksize, Cin_p
+        self.Cout_total = sum(w.shape[0] for (w, _, _) in sources)
+        self.Cout_p8 = (self.Cout_total + 7) // 8 * 8
+        taps = ksize * ksize
+        self.wp_elems = taps * self.Cout_total * Cin_p
+        self.wpd_elems = taps * Cin_p * self.Cout_p8
+        self.need_dgrad = need_dgrad
+        self.wp = self.wpd = self.dwp = self.bp = self.dbp = None
+        g.convs.append(self)
+
+
+def conv_desc(g, N, H, W, Cin, Cout, k, stride, x_ld, y_ld, y_f32=0):
+    d = ConvDesc()
+    d.dtype, d.N, d.H, d.W, d.Cin, d.Cout = g.dtype, N, H, W, Cin, Cout
+    d.ksize, d.stride, d.x_ld, d.y_ld, d.y_f32 = k, stride, x_ld, y_ld, y_f32
+    return d
+
+
+# ------------------------------------------------------------------------- ops
+class CopyOp:
+    def __init__(self, g, src, dst):
+        self.g, self.src, self.dst = g, src, dst
+
+    def fwd(self):
+        g = self.g
+        call("plyolo_copy_add", g.dtype, self.src.M, self.src.C, g.aptr(self.src), self.src.ld, g.aptr(self.dst), self.dst.ld, 0, None)
+
+    def bwd(self):
+        g = self.g
+        if not g.grad_ready(self.dst):
+            return
+        acc = g.grad_mode(self.src)
+        call("plyolo_copy_add", g.dtype, self.src.M, self.src.C, g.gptr(self.dst), self.dst.ld, g.gptr(self.src), self.src.ld, acc, None)
+
+
+class ConvUnitOp:
+    """BaseConv: conv (no bias) -> BatchNorm (batch stats in training) -> activation
+    [+ residual].  reference models/layers/network_blocks.py:7-40, :86-90."""
+
+    def __init__(self, g, x, conv_w, bn, act, stride, residual=None, need_dgrad=True, cin_pad=None):
+        self.g, self.x, self.bn, self.act, self.stride, self.res = g, x, bn, ACT[act], stride, residual
+        Cout, Cin, k, _ = conv_w.shape
+        self.k = k
+        self.Cin_p = cin_pad or Cin
+        assert x.C == self.Cin_p, "conv input channels %d != %d" % (x.C, self.Cin_p)
+        pad = (k - 1) // 2
+        self.OH = (x.H + 2 * pad - k) // stride + 1
+        self.OW = (x.W + 2 * pad - k) // stride + 1
+        self.pc = PackedConv(g, [(conv_w, None, 0)], k, self.Cin_p, need_dgrad)
+        self.need_dgrad = need_dgrad
+        self.out = g.new_act(x.N, self.OH, self.OW, Cout, "a")
+        self.z = Storage(x.N, self.OH, self.OW, Cout, "z")
+        g.storages.append(self.z)
+        self.Cout = Cout
+        self.desc = conv_desc(g, x.N, x.H, x.W, self.Cin_p, Cout, k, stride, 0, Cout)
+        g.scratch_elems = max(g.scratch_elems, self.z.rows * Cout)
+        g.ops.append(self)
+
+    def _alloc_small(self):
+        g = self.g
+        if hasattr(self, "coef"):
+            return
+        self.desc.x_ld = self.x.ld
+        rows = _lib.lib().plyolo_conv2d_stat_rows(C.byref(self.desc))
+        if rows <= 0:
+            _lib.check(-1, "plyolo_conv2d_stat_rows")
+        self.stat_rows = rows
+        dev = g.device
+        self.stats = torch.empty(2 * rows * self.Cout, dtype=torch.float32, device=dev)
+        self.coef = torch.empty(4 * self.Cout, dtype=torch.float32, device=dev)
+        self.bcoef = torch.empty(3 * self.Cout, dtype=torch.float32, device=dev)
+        self.brows = _lib.lib().plyolo_bn_bwd_rows(self.out.M)
+        self.bpartial = torch.empty(2 * self.brows * self.Cout, dtype=torch.float32, device=dev)
+
+    def fwd(self):
+        g, bn = self.g, self.bn
+        self._alloc_small()
+        zt = self.z.tensor
+        train_stats = g.training and bn is not None
+        call("plyolo_conv2d_fwd", C.byref(self.desc), g.aptr(self.x), self.pc.wp, None, zt.data_ptr(),
+             self.stats.data_ptr() if train_stats else None, None)
+        coef = None
+        if bn is not None:
+            coef = self.coef.data_ptr()
+            if g.training:
+                call("plyolo_bn_finalize", self.stats.data_ptr(), self.stat_rows, self.Cout, float(self.out.M),
+                     ptr(bn.weight), ptr(bn.bias), float(bn.eps), float(bn.momentum), ptr(bn.running_mean),
+                     ptr(bn.running_var), ptr(bn.num_batches_tracked), coef, None)
+            else:
+                call("plyolo_bn_eval_coef", self.Cout, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
+                     ptr(bn.running_var), float(bn.eps), coef, None)
+        call("plyolo_bn_act_fwd", g.dtype, self.out.M, self.Cout, zt.data_ptr(), self.Cout, coef, self.act,
+             g.aptr(self.res) if self.res is not None else None, self.res.ld if self.res is not None else 0,
+             g.aptr(self.out), self.out.ld, None)
+
+    def bwd(self):
+        g, bn = self.g, self.bn
+        if not g.grad_ready(self.out):
+            return  # nothing downstream contributes a gradient
+        if bn is None:
+            raise NotImplementedError("training a conv unit without BatchNorm is not supported by the HIP plan")
+        M, Cout = self.out.M, self.Cout
+        dout, zt = g.gptr(self.out), self.z.tensor.data_ptr()
+        if self.res is not None:
+            acc = g.grad_mode(self.res)
+            call("plyolo_copy_add", g.dtype, M, Cout, dout, self.out.ld, g.gptr(self.res), self.res.ld, acc, None)
+        call("plyolo_bn_act_bwd_reduce", g.dtype, M, Cout, dout, self.out.ld, zt, Cout, self.coef.data_ptr(), self.act,
+             self.bpartial.data_ptr(), None)
+        call("plyolo_bn_bwd_finalize", self.bpartial.data_ptr(), self.brows, Cout, float(M), ptr(bn.weight),
+             self.coef.data_ptr(), g.grad_ptr_of(bn.weight), g.grad_ptr_of(bn.bias), 0, self.bcoef.data_ptr(), None)
+        dz = g.scratch.data_ptr()
+        call("plyolo_bn_act_bwd_dz", g.dtype, M, Cout, dout, self.out.ld, zt, Cout, self.coef.data_ptr(),
+             self.bcoef.data_ptr(), self.act, dz, Cout, None)
+        call("plyolo_conv2d_wgrad", C.byref(self.desc), g.aptr(self.x), dz, self.pc.dwp, None)
+        if self.need_dgrad:
+            acc = g.grad_mode(self.x)
+            call("plyolo_conv2d_dgrad", C.byref(self.desc), dz, self.pc.wpd, g.gptr(self.x), acc, None)
+
+
+class UpsampleOp:
+    def __init__(self, g, x):
+        self.g, self.x = g, x
+        self.out = g.new_act(x.N, 2 * x.H, 2 * x.W, x.C, "up")
+        g.ops.append(self)
+
+    def fwd(self):
+        g, x = self.g, self.x
+        call("plyolo_upsample2x_fwd", g.dtype, x.N, x.H, x.W, x.C, g.aptr(x), x.ld, g.aptr(self.out), self.out.ld, None)
+
+    def bwd(self):
+        g, x = self.g, self.x
+        if not g.grad_ready(self.out):
+            return
+        acc = g.grad_mode(x)
+        call("plyolo_upsample2x_bwd", g.dtype, x.N, x.H, x.W, x.C, g.gptr(self.out), self.out.ld, g.gptr(x), x.ld, acc, None)
+
+
+class SppPoolsOp:
+    """MaxPool2d(k, stride 1, pad k//2) for k = 5, 9, 13 (network_blocks.py:141-153).
+    Forward runs the exact cascade 5 -> 5 -> 5; backward uses the independent-pool
+    rule (first maximum in row-major window order takes the gradient, like ATen)."""
+
+    def __init__(self, g, x, ks=(5, 9, 13)):
+        self.g, self.x, self.ks = g, x, tuple(ks)
+        self.outs = [g.new_act(x.N, x.H, x.W, x.C, "pool%d" % k) for k in ks]
+        g.scratch_f32 = max(g.scratch_f32, x.M * x.C)
+        g.ops.append(self)
+
+    def fwd(self):
+        g, x = self.g, self.x
+        src, prev_k = x, 1
+        for k, o in zip(self.ks, self.outs):
+            # pool_k(x) == pool_{k-prev+1}(pool_prev(x)) for stride-1 max pools
+            call("plyolo_maxpool_s1_fwd", g.dtype, x.N, x.H, x.W, x.C, k - prev_k + 1, g.aptr(src), src.ld, g.aptr(o), o.ld, None)
+            src, prev_k = o, k
+
+    def bwd(self):
+        g, x = self.g, self.x
+        ready = [g.grad_ready(o) for o in self.outs]
+        if not any(ready):
+            return
+        n = x.M * x.C
+        call("plyolo_memset_async", g.scratch32.data_ptr(), 0, n * 4, None)
+        for k, o, r in zip(self.ks, self.outs, ready):
+            if r:
+                call("plyolo_maxpool_s1_bwd", g.dtype, x.N, x.H, x.W, x.C, k, g.aptr(x), x.ld, g.gptr(o), o.ld,
+                     g.scratch32.data_ptr(), None)
+        acc = g.grad_mode(x)
+        call("plyolo_f32_to_act", g.dtype, x.M, x.C, g.scratch32.data_ptr(), g.gptr(x), x.ld, acc, None)
+
+
+class HeadPredOp:
+    """The three bare 1x1 prediction convs of one DecoupledHead level
+    (decoupled_head.py:43-62,86-93), packed as two convs (cls: C_cls outputs from the
+    cls branch; reg+obj: 5 outputs from the reg branch) that write straight into the
+    level's [B, h, w, 5+C] block of the level-major raw prediction tensor."""
+
+    def __init__(self, g, head, level, cls_feat, reg_feat, cls_conv, reg_conv, obj_conv):
+        self.g, self.head, self.level = g, head, level
+        self.cls_feat, self.reg_feat = cls_feat, reg_feat
+        self.nc = cls_conv.weight.shape[0]
+        Cin = cls_conv.weight.shape[1]
+        self.pc_cls = PackedConv(g, [(cls_conv.weight, cls_conv.bias, 0)], 1, Cin)
+        self.pc_ro = PackedConv(g, [(reg_conv.weight, reg_conv.bias, 0), (obj_conv.weight, obj_conv.bias, 4)], 1, Cin)
+        N, H, W = cls_feat.N, cls_feat.H, cls_feat.W
+        self.d_cls = conv_desc(g, N, H, W, Cin, self.nc, 1, 1, 0, head.nch, 1)
+        self.d_ro = conv_desc(g, N, H, W, Cin, 5, 1, 1, 0, head.nch, 1)
+        g.ops.append(self)
+
+    def fwd(self):
+        g, hd = self.g, self.head
+        base = hd.raw.data_ptr() + hd.lvl_row[self.level] * hd.nch * 4
+        self.d_cls.x_ld, self.d_ro.x_ld = self.cls_feat.ld, self.reg_feat.ld
+        call("plyolo_conv2d_fwd", C.byref(self.d_ro), g.aptr(self.reg_feat), self.pc_ro.wp, self.pc_ro.bp, base, None, None)
+        call("plyolo_conv2d_fwd", C.byref(self.d_cls), g.aptr(self.cls_feat), self.pc_cls.wp, self.pc_cls.bp, base + 5 * 4, None, None)
+
+    def bwd(self):
+        g, hd = self.g, self.head
+        row0 = hd.lvl_row[self.level]
+        M = self.cls_feat.M
+        if g.dtype == BF16:
+            dro = hd.d_regobj.data_ptr() + row0 * 16 * 2
+            dcl = hd.d_cls.data_ptr() + row0 * hd.cls_ld * 2
+            d_ro = conv_desc(g, self.d_ro.N, self.d_ro.H, self.d_ro.W, self.d_ro.Cin, 5, 1, 1, self.reg_feat.ld, 16, 0)
+            d_cl = conv_desc(g, self.d_cls.N, self.d_cls.H, self.d_cls.W, self.d_cls.Cin, self.nc, 1, 1, self.cls_feat.ld, hd.cls_ld, 0)
+            ld_ro, ld_cl = 16, hd.cls_ld
+        else:
+            base = hd.draw.data_ptr() + row0 * hd.nch * 4
+            dro, dcl = base, base + 5 * 4
+            d_ro, d_cl = self.d_ro, self.d_cls
+            ld_ro = ld_cl = hd.nch
+        self.keep = (d_ro, d_cl)
+        call("plyolo_bias_grad", g.dtype, dro, M, 5, ld_ro, self.pc_ro.dbp, None)
+        call("plyolo_bias_grad", g.dtype, dcl, M, self.nc, ld_cl, self.pc_cls.dbp, None)
+        call("plyolo_conv2d_wgrad", C.byref(d_ro), g.aptr(self.reg_feat), dro, self.pc_ro.dwp, None)
+        call("plyolo_conv2d_wgrad", C.byref(d_cl), g.aptr(self.cls_feat), dcl, self.pc_cls.dwp, None)
+        acc = g.grad_mode(self.reg_feat)
+        call("plyolo_conv2d_dgrad", C.byref(d_ro), dro, self.pc_ro.wpd, g.gptr(self.reg_feat), acc, None)
+        acc = g.grad_mode(self.cls_feat)
+        call("plyolo_conv2d_dgrad", C.byref(d_cl), dcl, self.pc_cls.wpd, g.gptr(self.cls_feat), acc, None)
+
+
+class HeadBuffers:
+    """Level-major raw prediction tensor + the loss-side buffers shared by all levels."""
+
+    def __init__(self, g, B, num_classes, sizes, strides, max_labels):
+        self.g = g
+        self.B, self.nc, self.nch = B, num_classes, 5 + num_classes
+        self.sizes, self.strides = list(sizes), list(strides)
+        self.lvl_off, self.lvl_row = [], []
+        a = r = 0
+        for (h, w) in sizes:
+            self.lvl_off.append(a)
+            self.lvl_row.append(r)
+            a += h * w
+            r += B * h * w
+        self.A, self.rows = a, r
+        self.M = max_labels
+        self.cls_ld = (num_classes + 7) // 8 * 8
+        dev = g.device
+        self.raw = torch.empty(self.rows * self.nch, dtype=torch.float32, device=dev)
+        self.desc = YoloxDesc()
+        d = self.desc
+        d.B, d.A, d.C, d.M, d.nlevels = B, self.A, num_classes, max_labels, len(sizes)
+        for i, ((h, w), s) in enumerate(zip(sizes, strides)):
+            d.lvl_h[i], d.lvl_w[i], d.lvl_stride[i] = h, w, int(s)
+            d.lvl_off[i], d.lvl_row[i] = self.lvl_off[i], self.lvl_row[i]
+
+    def alloc_loss(self):
+        g, dev = self.g, self.g.device
+        BA = self.B * self.A
+        self.labels = torch.zeros(self.B * self.M * 5, dtype=torch.float32, device=dev)
+        self.fg = torch.empty(BA, dtype=torch.uint8, device=dev)
+        self.mgt = torch.empty(BA, dtype=torch.int32, device=dev)
+        self.miou = torch.empty(BA, dtype=torch.float32, device=dev)
+        self.losses = torch.zeros(8, dtype=torch.float32, device=dev)
+        self.gout = torch.zeros(8, dtype=torch.float32, device=dev)
+        self.ws_bytes = _lib.lib().plyolo_yolox_workspace(C.byref(self.desc))
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
+        if g.dtype == BF16:
+            self.d_regobj = torch.zeros(self.rows * 16, dtype=torch.bfloat16, device=dev)
+            self.d_cls = torch.zeros(self.rows * self.cls_ld, dtype=torch.bfloat16, device=dev)
+            self.draw = None
+        else:
+            self.draw = torch.empty(self.rows * self.nch, dtype=torch.float32, device=dev)
+            self.d_regobj = self.d_cls = None
+
+    def alloc_eval(self):
+        self.eval_out = torch.empty(self.B * self.A * self.nch, dtype=torch.float32, device=self.g.device)
+
+
+class YoloxLossOp:
+    def __init__(self, g, head):
+        self.g, self.head = g, head
+        g.ops.append(self)
+
+    def fwd(self):
+        hd = self.head
+        call("plyolo_yolox_loss_fwd", C.byref(hd.desc), hd.raw.data_ptr(), hd.labels.data_ptr(), hd.fg.data_ptr(),
+             hd.mgt.data_ptr(), hd.miou.data_ptr(), hd.losses.data_ptr(), hd.ws.data_ptr(), hd.ws_bytes, None)
+
+    def bwd(self):
+        hd = self.head
+        call("plyolo_yolox_loss_bwd", C.byref(hd.desc), hd.raw.data_ptr(), hd.labels.data_ptr(), hd.fg.data_ptr(),
+             hd.mgt.data_ptr(), hd.miou.data_ptr(), hd.losses.data_ptr(), hd.gout.data_ptr(), ptr(hd.draw),
+             ptr(hd.d_regobj), ptr(hd.d_cls), hd.cls_ld, None)
+
+
+class YoloxEvalDecodeOp:
+    def __init__(self, g, head):
+        self.g, self.head = g, head
+        g.ops.append(self)
+
+    def fwd(self):
+        hd = self.head
+        call("plyolo_yolox_eval_decode", C.byref(hd.desc), hd.raw.data_ptr(), hd.eval_out.data_ptr(), None)
+
+    def bwd(self):
+        pass
+
+
+class Plan:
+    """Owns one plyolo_plan handle."""
+
+    def __init__(self):
+        self.h = _lib.lib().plyolo_plan_create()
+        self.graph_ready = False
+
+    def __enter__(self):
+        call("plyolo_plan_begin", self.h)
+        return self
+
+    def __exit__(self, *exc):
+        _lib.lib().plyolo_plan_end(self.h)
+        return False
+
+    def size(self):
+        return _lib.lib().plyolo_plan_size(self.h)
+
+    def run(self, stream, use_graph=False):
+        if use_graph:
+            if not self.graph_ready:
+                call("plyolo_plan_graph_instantiate", self.h, stream)
+                self.graph_ready = True
+            call("plyolo_plan_graph_launch", self.h, stream)
+        else:
+            call("plyolo_plan_run", self.h, stream)
+
+    def __del__(self):
+        try:
+            if self.h:
+                _lib.lib().plyolo_plan_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass

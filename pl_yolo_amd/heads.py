@@ -1,0 +1,56 @@
+"""YOLOX decoupled head (reference models/heads/decoupled_head.py:7-95)."""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import graph as G
+from .layers import BaseConv, HipModule
+
+
+class DecoupledHead(HipModule):
+    def __init__(self, num_classes=80, n_anchors=1, in_channels=None, norm="bn", act="silu"):
+        super().__init__()
+        if n_anchors != 1:
+            raise NotImplementedError("the YOLOX loss kernels assume one anchor per cell (yolox_loss.py:12)")
+        self.n_anchors = n_anchors
+        self.num_classes = num_classes
+        ch = self.n_anchors * self.num_classes
+        self.stems = nn.ModuleList()
+        self.cls_convs = nn.ModuleList()
+        self.cls_preds = nn.ModuleList()
+        self.reg_convs = nn.ModuleList()
+        self.reg_preds = nn.ModuleList()
+        self.obj_preds = nn.ModuleList()
+        for i in range(len(in_channels)):
+            # the stem ignores `norm` in the reference (decoupled_head.py:29-31)
+            self.stems.append(BaseConv(in_channels[i], in_channels[0], ksize=1, stride=1, act=act))
+            self.cls_convs.append(nn.Sequential(
+                BaseConv(in_channels[0], in_channels[0], ksize=3, stride=1, norm=norm, act=act),
+                BaseConv(in_channels[0], in_channels[0], ksize=3, stride=1, norm=norm, act=act)))
+            self.cls_preds.append(nn.Conv2d(in_channels[0], ch, kernel_size=(1, 1), stride=(1, 1), padding=0))
+            self.reg_convs.append(nn.Sequential(
+                BaseConv(in_channels[0], in_channels[0], ksize=3, stride=1, norm=norm, act=act),
+                BaseConv(in_channels[0], in_channels[0], ksize=3, stride=1, norm=norm, act=act)))
+            self.reg_preds.append(nn.Conv2d(in_channels[0], self.n_anchors * 4, kernel_size=(1, 1), stride=(1, 1), padding=0))
+            self.obj_preds.append(nn.Conv2d(in_channels[0], self.n_anchors * 1, kernel_size=(1, 1), stride=(1, 1), padding=0))
+        self.initialize_biases(1e-2)
+
+    def initialize_biases(self, prior_prob):
+        v = -math.log((1 - prior_prob) / prior_prob)
+        for conv in list(self.cls_preds) + list(self.obj_preds):
+            with torch.no_grad():
+                conv.bias.fill_(v)
+
+    def emit(self, g, inputs, head_buffers):
+        """Writes the raw predictions of every level into `head_buffers.raw`
+        (channel order reg(4), obj(1), cls(C) -- decoupled_head.py:93)."""
+        for k, x in enumerate(inputs):
+            x = self.stems[k].emit(g, x)
+            cls_feat, reg_feat = x, x
+            for m in self.cls_convs[k]:
+                cls_feat = m.emit(g, cls_feat)
+            for m in self.reg_convs[k]:
+                reg_feat = m.emit(g, reg_feat)
+            G.HeadPredOp(g, head_buffers, k, cls_feat, reg_feat, self.cls_preds[k], self.reg_preds[k], self.obj_preds[k])
+        return head_buffers

@@ -1,0 +1,138 @@
+"""Network blocks with the reference's names, constructor signatures and state_dict
+key layout (reference models/layers/network_blocks.py, activation.py,
+normalization.py).  The modules own the parameters (plain nn.Conv2d /
+nn.BatchNorm2d containers, so checkpoints load unchanged) and describe their
+computation to the HIP launch-plan builder through `emit(g, x)`; they never run
+torch compute kernels themselves.
+"""
+import torch
+import torch.nn as nn
+
+from . import graph as G
+from ._lib import PlyoloError
+
+_ACTS = ("silu", "relu", "lrelu")
+
+
+def get_activation(name="silu", inplace=True):
+    """activation.py:5-20.  Returns a marker module (the activation is fused into the
+    BatchNorm-apply kernel).  hswish/gelu exist in the reference but are not used by
+    the YOLOX/YOLOv7 configs; they are rejected here rather than silently changed."""
+    if name is None:
+        return None
+    if name in _ACTS:
+        m = nn.Identity()
+        m.act_name = name
+        return m
+    if name in ("hswish", "gelu"):
+        raise NotImplementedError("activation '%s' has no HIP epilogue yet" % name)
+    raise AttributeError("Unsupported activation function type: {}".format(name))
+
+
+def get_normalization(name, out_channels):
+    """normalization.py:4-13 (bn = BatchNorm2d(eps=1e-3, momentum=0.03))."""
+    if name is None:
+        return None
+    if name == "bn":
+        return nn.BatchNorm2d(out_channels, eps=1e-3, momentum=0.03)
+    if name == "ln":
+        raise NotImplementedError("norm 'ln' has no HIP kernel (unused by the YOLOX/YOLOv7 configs)")
+    raise AttributeError("Unsupported normalization function type: {}".format(name))
+
+
+class HipModule(nn.Module):
+    """Base: sub-modules are graph describers.  Calling one directly (outside a
+    detector) is not part of the hot path and is refused loudly."""
+
+    def forward(self, *a, **k):
+        raise PlyoloError(
+            "%s is a graph describer for the HIP launch plan; run it through build_model()/OneStageD "
+            "(pl_yolo_amd has no eager per-module path)" % type(self).__name__
+        )
+
+
+class BaseConv(HipModule):
+    """A Convolution2d -> Normalization -> Activation (network_blocks.py:7-40)."""
+
+    def __init__(self, in_channels, out_channels, ksize, stride, padding=None, groups=1, bias=False, norm="bn", act="silu"):
+        super().__init__()
+        pad = (ksize - 1) // 2 if padding is None else padding
+        if groups != 1 or bias or pad != (ksize - 1) // 2 or ksize not in (1, 3) or stride not in (1, 2):
+            raise NotImplementedError("HIP conv supports k in {1,3}, stride in {1,2}, same padding, groups=1, no bias")
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=ksize, stride=stride, padding=pad, groups=groups, bias=bias)
+        self.norm = get_normalization(norm, out_channels)
+        self.act = get_activation(act, inplace=True)
+        self.stride = stride
+
+    def emit(self, g, x, residual=None, need_dgrad=True, cin_pad=None):
+        act = self.act.act_name if self.act is not None else None
+        op = G.ConvUnitOp(g, x, self.conv.weight, self.norm, act, self.stride, residual, need_dgrad, cin_pad)
+        return op.out
+
+
+class Focus(HipModule):
+    """Focus width and height information into channel space (network_blocks.py:43-65)."""
+
+    def __init__(self, in_channels, out_channels, ksize=1, stride=1, norm="bn", act="silu"):
+        super().__init__()
+        if in_channels != 3:
+            raise NotImplementedError("Focus kernel is written for RGB input")
+        self.conv = BaseConv(in_channels * 4, out_channels, ksize, stride, norm=norm, act=act)
+
+    def emit(self, g, image_act):
+        # image_act: NHWC space-to-depth tensor produced by plyolo_focus_s2d (12 real channels)
+        return self.conv.emit(g, image_act, need_dgrad=False, cin_pad=image_act.C)
+
+
+class Bottleneck(HipModule):
+    """network_blocks.py:68-91 (carries the reference's unused `bn`, line 81)."""
+
+    def __init__(self, in_channels, out_channels, shortcut=True, expansion=0.5, norm="bn", act="silu"):
+        super().__init__()
+        hidden_channels = int(out_channels * expansion)
+        self.bn = get_normalization(norm, out_channels)
+        self.act = get_activation(act, inplace=True)
+        self.conv1 = BaseConv(in_channels, hidden_channels, 1, stride=1, norm=norm, act=act)
+        self.conv2 = BaseConv(hidden_channels, out_channels, 3, stride=1, norm=norm, act=act)
+        self.use_add = shortcut and in_channels == out_channels
+
+    def emit(self, g, x):
+        y = self.conv1.emit(g, x)
+        return self.conv2.emit(g, y, residual=x if self.use_add else None)
+
+
+class CSPLayer(HipModule):
+    """network_blocks.py:94-131."""
+
+    def __init__(self, in_channels, out_channels, num_bottle=1, shortcut=True, expansion=0.5, norm="bn", act="silu"):
+        super().__init__()
+        hidden_channels = int(out_channels * expansion)
+        self.conv1 = BaseConv(in_channels, hidden_channels, 1, stride=1, norm=norm, act=act)
+        self.conv2 = BaseConv(in_channels, hidden_channels, 1, stride=1, norm=norm, act=act)
+        self.conv3 = BaseConv(2 * hidden_channels, out_channels, 1, stride=1, norm=norm, act=act)
+        self.m = nn.Sequential(*[Bottleneck(hidden_channels, hidden_channels, shortcut, 1.0, norm=norm, act=act) for _ in range(num_bottle)])
+
+    def emit(self, g, x):
+        x_1 = self.conv1.emit(g, x)
+        x_2 = self.conv2.emit(g, x)
+        for b in self.m:
+            x_1 = b.emit(g, x_1)
+        return self.conv3.emit(g, g.concat([x_1, x_2]))
+
+
+class SPPBottleneck(HipModule):
+    """Spatial pyramid pooling layer used in YOLOv3-SPP (network_blocks.py:134-155)."""
+
+    def __init__(self, in_channels, out_channels, kernel_sizes=(5, 9, 13), norm="bn", act="silu"):
+        super().__init__()
+        hidden_channels = in_channels // 2
+        self.conv1 = BaseConv(in_channels, hidden_channels, 1, stride=1, norm=norm, act=act)
+        self.m = nn.ModuleList([nn.MaxPool2d(kernel_size=ks, stride=1, padding=ks // 2) for ks in kernel_sizes])
+        self.kernel_sizes = tuple(kernel_sizes)
+        conv2_channels = hidden_channels * (len(kernel_sizes) + 1)
+        self.conv2 = BaseConv(conv2_channels, out_channels, 1, stride=1, act=act)  # norm arg not forwarded (line 149)
+
+    def emit(self, g, x):
+        x = self.conv1.emit(g, x)
+        pools = G.SppPoolsOp(g, x, self.kernel_sizes)
+        return self.conv2.emit(g, g.concat([x] + pools.outs))

@@ -1,0 +1,29 @@
+"""YOLOX loss plugin (reference models/losses/yolox/yolox_loss.py:7-228).
+
+Like the reference class it overrides __call__ (module hooks never fire on it) and
+switches between the training branch and the eval decode on `self.training`.
+The arithmetic is in csrc/yolox_loss.hip; this object only carries the config."""
+import torch.nn as nn
+
+from . import graph as G
+
+
+class YOLOXLoss(nn.Module):
+    def __init__(self, num_classes, strides, use_l1=False):
+        super().__init__()
+        if use_l1:
+            raise NotImplementedError("use_l1 is never enabled by the reference (build_detection.py:137-139)")
+        self.num_classes = num_classes
+        self.strides = strides
+        self.n_anchors = 1
+        self.use_l1 = use_l1
+
+    def __call__(self, inputs, labels):
+        raise RuntimeError("YOLOXLoss is driven by the detector's launch plan (OneStageD.forward); "
+                           "it has no stand-alone tensor path")
+
+    def emit(self, g, head_buffers, training):
+        if training:
+            G.YoloxLossOp(g, head_buffers)
+        else:
+            G.YoloxEvalDecodeOp(g, head_buffers)

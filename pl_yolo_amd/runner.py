@@ -1,0 +1,253 @@
+"""Runs a detector (backbone -> neck -> head -> loss) through recorded HIP launch plans.
+
+One `DetectorRunner` per OneStageD.  It
+  * adopts the module's parameters/buffers into flat fp32 device buffers (the
+    nn.Parameters become views, so state_dict / optimizers / EMA keep working, while
+    gradients land in one contiguous buffer = one RCCL all-reduce bucket);
+  * traces the module tree once per (batch, image size, label rows, mode) into a
+    `Graph`, allocates every activation / gradient / workspace buffer up front, and
+    records the forward and backward launch plans;
+  * replays the plans (optionally as captured hipGraphs) for each step.
+"""
+import ctypes as C
+import os
+
+import torch
+
+from . import _lib, graph as G
+from ._lib import BF16, F32, call, PlyoloError
+
+
+def _align(n, a=64):
+    return (n + a - 1) // a * a
+
+
+class _Session:
+    """Everything that belongs to one traced shape/mode."""
+    pass
+
+
+class DetectorRunner:
+    def __init__(self, model, dtype="bf16"):
+        self.model_ref = model
+        self.dtype = BF16 if dtype in ("bf16", BF16) else F32
+        self.sessions = {}
+        self.flat = None
+        self.use_graph = os.environ.get("PLYOLO_GRAPH", "0") == "1"
+        self.ddp = None  # set by pl_yolo_amd.ddp.attach()
+
+    def __deepcopy__(self, memo):  # ModelEMA deep-copies the module (ema.py:41)
+        return None
+
+    # ------------------------------------------------------------ flat storage
+    def _adopted_ok(self, device):
+        if self.flat is None or self.flat["device"] != device:
+            return False
+        f = self.flat
+        for p, off in ((f["params"][0], 0), (f["params"][-1], f["offs"][-1])):
+            if p.data_ptr() != f["w"].data_ptr() + off * 4:
+                return False
+        return True
+
+    def adopt(self, device):
+        """Move parameters / float buffers / counters into flat device buffers and
+        re-point the module's tensors at views of them."""
+        model = self.model_ref
+        params = list(model.parameters())
+        if not params:
+            raise PlyoloError("model has no parameters")
+        offs, n = [], 0
+        for p in params:
+            offs.append(n)
+            n += _align(p.numel())
+        w = torch.zeros(n, dtype=torch.float32, device=device)
+        gbuf = torch.zeros(n, dtype=torch.float32, device=device)
+        with torch.no_grad():
+            for p, o in zip(params, offs):
+                if p.dtype != torch.float32:
+                    raise PlyoloError("parameters must be fp32 master weights")
+                w[o:o + p.numel()].copy_(p.data.reshape(-1))
+                p.data = w[o:o + p.numel()].view(p.shape)
+        fb = [b for b in model.buffers() if b.dtype.is_floating_point]
+        ib = [b for b in model.buffers() if not b.dtype.is_floating_point]
+        boffs, nb = [], 0
+        for b in fb:
+            boffs.append(nb)
+            nb += _align(b.numel())
+        bw = torch.zeros(max(nb, 8), dtype=torch.float32, device=device)
+        iw = torch.zeros(max(len(ib), 1), dtype=torch.int64, device=device)
+        with torch.no_grad():
+            for b, o in zip(fb, boffs):
+                bw[o:o + b.numel()].copy_(b.data.reshape(-1))
+                b.data = bw[o:o + b.numel()].view(b.shape)
+            for i, b in enumerate(ib):
+                iw[i:i + 1].copy_(b.data.reshape(-1).to(torch.int64))
+                b.data = iw[i:i + 1].view(b.shape)
+        self.flat = dict(device=device, params=params, offs=offs, w=w, g=gbuf, n=n, fbuf=bw, ibuf=iw,
+                         off_of={id(p): o for p, o in zip(params, offs)})
+        self.sessions = {}
+
+    def grad_ptr_of(self, p):
+        if p is None or not p.requires_grad:
+            return None
+        return self.flat["g"].data_ptr() + self.flat["off_of"][id(p)] * 4
+
+    def grad_view(self, p):
+        o = self.flat["off_of"][id(p)]
+        return self.flat["g"][o:o + p.numel()].view(p.shape)
+
+    # ------------------------------------------------------------------ tracing
+    def _session(self, B, H, W, M, mode, device):
+        if not self._adopted_ok(device):
+            self.adopt(device)
+        key = (B, H, W, M, mode, self.dtype, self.model_ref.training)
+        s = self.sessions.get(key)
+        if s is None:
+            s = self._build(B, H, W, M, mode, device)
+            self.sessions[key] = s
+        return s
+
+    def _build(self, B, H, W, M, mode, device):
+        model = self.model_ref
+        if H % 32 or W % 32:
+            raise PlyoloError("input size must be a multiple of 32 (got %dx%d)" % (H, W))
+        training = model.training
+        g = G.Graph(self.dtype, training, device)
+        g.grad_ptr_of = self.grad_ptr_of
+        s = _Session()
+        s.g, s.mode, s.B, s.H, s.W, s.M = g, mode, B, H, W, M
+        cp = 16 if self.dtype == BF16 else 12
+        image = g.new_act(B, H // 2, W // 2, cp, "focus")
+        s.image = image
+        feats = model.backbone.emit(g, image)
+        if model.neck is not None:
+            feats = model.neck.emit(g, feats)
+        if not isinstance(feats, (list, tuple)):
+            feats = [feats]
+        nc = model.head.num_classes
+        strides = list(model.loss.strides) if model.loss is not None else [W // f.W for f in feats]
+        if len(strides) != len(feats):
+            raise PlyoloError("loss.stride has %d entries for %d feature levels" % (len(strides), len(feats)))
+        head = G.HeadBuffers(g, B, nc, [(f.H, f.W) for f in feats], strides, max(M, 1))
+        s.head = head
+        model.head.emit(g, feats, head)
+        if mode == "train":
+            head.alloc_loss()
+            model.loss.emit(g, head, True)
+        elif mode == "eval":
+            head.alloc_eval()
+            model.loss.emit(g, head, False)
+        g.allocate()
+        g.build_pack_table(self.grad_ptr_of)
+        # ---- record the forward plan
+        s.fwd = G.Plan()
+        with s.fwd:
+            call("plyolo_pack_weights", g.pack_table.data_ptr(), g.n_pack, g.dtype, g.max_pack_elems, None)
+            for op in g.ops:
+                op.fwd()
+        s.bwd = None
+        s.used_params = []
+        if mode == "train":
+            s.bwd = G.Plan()
+            with s.bwd:
+                call("plyolo_memset_async", g.dwp_arena.data_ptr(), 0, g.dwp_arena.numel() * 4, None)
+                for op in reversed(g.ops):
+                    op.bwd()
+                call("plyolo_unpack_wgrads", g.pack_table.data_ptr(), g.n_pack, g.max_pack_elems, 0, None)
+            seen = set()
+            for op in g.ops:
+                if isinstance(op, G.ConvUnitOp) and op.bn is not None:
+                    for p in (op.bn.weight, op.bn.bias):
+                        if p is not None and id(p) not in seen:
+                            seen.add(id(p))
+                            s.used_params.append(p)
+            for (_, w, b) in g.pack_entries:
+                for p in (w, b):
+                    if p is not None and id(p) not in seen:
+                        seen.add(id(p))
+                        s.used_params.append(p)
+            s.used_params = [p for p in s.used_params if p.requires_grad]
+            s.grad_views = [self.grad_view(p) for p in s.used_params]
+        return s
+
+    # ---------------------------------------------------------------- execution
+    @staticmethod
+    def _stream():
+        return torch.cuda.current_stream().cuda_stream
+
+    def _check_input(self, x):
+        if not x.is_cuda:
+            raise PlyoloError("pl_yolo_amd runs on an MI355X device tensor (got a %s tensor); there is no CPU path" % x.device.type)
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise PlyoloError("expected an image batch [B,3,H,W], got %s" % (tuple(x.shape),))
+        if x.dtype != torch.float32:
+            x = x.float()
+        return x.contiguous()
+
+    def _focus(self, s, x):
+        g = s.g
+        call("plyolo_focus_s2d", g.dtype, x.data_ptr(), s.B, s.H, s.W, g.aptr(s.image), s.image.C, self._stream())
+
+    def forward_train(self, x, labels):
+        x = self._check_input(x)
+        if labels.dim() != 3 or labels.shape[2] != 5 or labels.shape[0] != x.shape[0]:
+            raise PlyoloError("labels must be [B, M, 5] rows (cls, cx, cy, w, h); got %s" % (tuple(labels.shape),))
+        B, _, H, W = x.shape
+        s = self._session(B, H, W, labels.shape[1], "train", x.device)
+        s.head.labels.view(labels.shape).copy_(labels)
+        self._focus(s, x)
+        s.fwd.run(self._stream(), self.use_graph)
+        return s
+
+    def backward_train(self, s, gout):
+        s.head.gout[:gout.numel()].copy_(gout.reshape(-1))
+        s.bwd.run(self._stream(), self.use_graph)
+        if self.ddp is not None:
+            self.ddp.all_reduce_(self.flat["g"])
+
+    def forward_eval(self, x):
+        x = self._check_input(x)
+        B, _, H, W = x.shape
+        s = self._session(B, H, W, 1, "eval", x.device)
+        self._focus(s, x)
+        s.fwd.run(self._stream(), self.use_graph)
+        hd = s.head
+        return hd.eval_out.view(B, hd.A, hd.nch).clone()
+
+    def forward_maps(self, x):
+        x = self._check_input(x)
+        B, _, H, W = x.shape
+        s = self._session(B, H, W, 1, "maps", x.device)
+        self._focus(s, x)
+        s.fwd.run(self._stream(), self.use_graph)
+        hd = s.head
+        outs = []
+        for (h, w), r0 in zip(hd.sizes, hd.lvl_row):
+            blk = hd.raw[r0 * hd.nch:(r0 + B * h * w) * hd.nch].view(B, h, w, hd.nch)
+            outs.append(blk.permute(0, 3, 1, 2).contiguous())  # API edge: NCHW like the reference
+        return outs
+
+
+class _TrainStep(torch.autograd.Function):
+    """Whole-detector autograd node: forward replays the forward plan, backward the
+    backward plan; parameter gradients are views of the runner's flat gradient buffer."""
+
+    @staticmethod
+    def forward(ctx, runner, x, labels, *params):
+        s = runner.forward_train(x, labels)
+        ctx.runner, ctx.session = runner, s
+        return s.head.losses.clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        runner, s = ctx.runner, ctx.session
+        runner.backward_train(s, gout.contiguous().float())
+        return (None, None, None) + tuple(s.grad_views)
+
+
+def train_step(runner, x, labels):
+    x = runner._check_input(x)
+    B, _, H, W = x.shape
+    s = runner._session(B, H, W, labels.shape[1], "train", x.device)
+    out = _TrainStep.apply(runner, x, labels, *s.used_params)
+    return out

@@ -1,0 +1,236 @@
+"""-m gpu: YOLOX loss side (decode / SimOTA / losses / backward / eval decode) and the
+post-processing (conf filter + class NMS) through the C ABI, against the committed
+golden vectors (reference-generated) and the CPU oracle on seeded inputs.
+
+Bars: assignment indices bit-exact; losses within 1e-4; gradients within 1e-5 of the
+largest gradient; NMS keep lists identical."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from pl_yolo_amd._lib import BF16, F32, NmsDesc, call  # noqa: E402
+import hiputil as hu  # noqa: E402
+from conftest import load_golden  # noqa: E402
+from oracle import yolox_loss as ol, nms as onms  # noqa: E402
+
+
+def run_loss(maps, labels, strides, C_, gout=None, bf16_grads=False):
+    B = maps[0].shape[0]
+    sizes = [tuple(m.shape[2:]) for m in maps]
+    d, rows = hu.yolox_desc(B, C_, labels.shape[1], sizes, strides)
+    raw = hu.maps_to_raw([m.to(hu.DEV) for m in maps])
+    lab = labels.to(hu.DEV).float().contiguous()
+    BA = B * d.A
+    fg = torch.zeros(BA, dtype=torch.uint8, device=hu.DEV)
+    mgt = torch.zeros(BA, dtype=torch.int32, device=hu.DEV)
+    miou = torch.zeros(BA, device=hu.DEV)
+    losses = torch.zeros(8, device=hu.DEV)
+    wsb = hu._lib.lib().plyolo_yolox_workspace(C.byref(d))
+    ws = torch.zeros(wsb, dtype=torch.uint8, device=hu.DEV)
+    call("plyolo_yolox_loss_fwd", C.byref(d), raw.data_ptr(), lab.data_ptr(), fg.data_ptr(), mgt.data_ptr(), miou.data_ptr(),
+         losses.data_ptr(), ws.data_ptr(), wsb, hu.stream())
+    nch = 5 + C_
+    g = None if gout is None else gout.to(hu.DEV).float().contiguous()
+    if bf16_grads:
+        cls_ld = (C_ + 7) // 8 * 8
+        dro = torch.zeros(rows, 16, dtype=torch.bfloat16, device=hu.DEV)
+        dcl = torch.zeros(rows, cls_ld, dtype=torch.bfloat16, device=hu.DEV)
+        call("plyolo_yolox_loss_bwd", C.byref(d), raw.data_ptr(), lab.data_ptr(), fg.data_ptr(), mgt.data_ptr(), miou.data_ptr(),
+             losses.data_ptr(), g.data_ptr() if g is not None else None, None, dro.data_ptr(), dcl.data_ptr(), cls_ld, hu.stream())
+        draw = torch.cat([dro[:, :5].float(), dcl[:, :C_].float()], 1)
+    else:
+        draw = torch.zeros(rows, nch, device=hu.DEV)
+        call("plyolo_yolox_loss_bwd", C.byref(d), raw.data_ptr(), lab.data_ptr(), fg.data_ptr(), mgt.data_ptr(), miou.data_ptr(),
+             losses.data_ptr(), g.data_ptr() if g is not None else None, draw.data_ptr(), None, None, 0, hu.stream())
+    ev = torch.zeros(BA * nch, device=hu.DEV)
+    call("plyolo_yolox_eval_decode", C.byref(d), raw.data_ptr(), ev.data_ptr(), hu.stream())
+    torch.cuda.synchronize()
+    return dict(fg=fg.view(B, -1).cpu(), mgt=mgt.view(B, -1).cpu(), miou=miou.view(B, -1).cpu(), losses=losses.cpu(),
+                grads=[m.cpu() for m in hu.raw_to_maps(draw, B, sizes)], eval=ev.view(B, d.A, nch).cpu())
+
+
+def _load(case):
+    g = load_golden("loss_case_" + case)
+    maps = [torch.from_numpy(g["map%d" % i]) for i in range(int(g["nmaps"]))]
+    return g, maps, torch.from_numpy(g["labels"]), [int(s) for s in g["strides"]], int(g["num_classes"])
+
+
+@pytest.mark.parametrize("case", ["A", "B", "C", "D", "E"])
+def test_loss_vs_golden(case):
+    g, maps, labels, strides, C_ = _load(case)
+    r = run_loss(maps, labels, strides, C_)
+    assert np.array_equal(r["fg"].numpy().astype(bool), g["fg"]), "fg mask differs (%d vs %d fg)" % (int(r["fg"].sum()), int(g["fg"].sum()))
+    assert np.array_equal(r["mgt"].numpy().astype(np.int64), g["matched_gt"])
+    np.testing.assert_allclose(r["miou"].numpy(), g["matched_iou"], atol=2e-6)
+    L = r["losses"].numpy()
+    for i, k in enumerate(("loss", "loss_iou", "loss_obj", "loss_cls")):
+        print(case, k, L[i], float(g[k]))
+        assert abs(L[i] - float(g[k])) <= 1e-4 * max(1.0, abs(float(g[k]))), k
+    assert L[4] == g["fg"].sum()
+    assert abs(L[6] - float(g["proportion"])) < 1e-5
+    for i, gr in enumerate(r["grads"]):
+        ref = g["grad%d" % i]
+        assert float(np.abs(gr.numpy() - ref).max()) <= 1e-5 * max(1e-3, float(np.abs(ref).max())), i
+    np.testing.assert_allclose(r["eval"].numpy(), g["eval_decode"], rtol=2e-6, atol=2e-5)
+
+
+def _rand_case(seed, B, C_, size, counts):
+    gen = torch.Generator().manual_seed(seed)
+    sizes = [(size // s, size // s) for s in (8, 16, 32)]
+    maps = []
+    for (h, w) in sizes:
+        m = torch.randn(B, 5 + C_, h, w, generator=gen)
+        m[:, :4] *= 0.4
+        m[:, 4:] = m[:, 4:] * 2 - 2
+        maps.append(m)
+    M = max(counts) + 3
+    lab = torch.zeros(B, M, 5)
+    for b, n in enumerate(counts):
+        lab[b, :n, 0] = torch.randint(0, C_, (n,), generator=gen).float()
+        lab[b, :n, 1:3] = (0.1 + 0.8 * torch.rand(n, 2, generator=gen)) * size
+        lab[b, :n, 3:5] = 6 + torch.rand(n, 2, generator=gen) * 0.35 * size
+    return maps, lab, [8, 16, 32]
+
+
+@pytest.mark.parametrize("seed,B,C_,size,counts", [
+    (11, 4, 80, 320, [30, 1, 0, 100]),
+    (12, 2, 20, 256, [50, 7]),
+    (13, 3, 80, 640, [30, 30, 30]),      # full-size anchor set A = 8400
+])
+def test_loss_vs_oracle_random(seed, B, C_, size, counts):
+    maps, lab, strides = _rand_case(seed, B, C_, size, counts)
+    gout = torch.tensor([1.0, 0.3, -0.2, 0.5])
+    leafs = [m.clone().requires_grad_(True) for m in maps]
+    out = ol.yolox_loss(leafs, lab, strides, C_, return_assign=True)
+    a = out["_assign"]
+    (gout[0] * out["loss"] + gout[1] * out["loss_iou"] + gout[2] * out["loss_obj"] + gout[3] * out["loss_cls"]).backward()
+    r = run_loss(maps, lab, strides, C_, gout=gout)
+    same_fg = torch.equal(r["fg"].bool(), a["fg"])
+    if not same_fg:
+        diff = int((r["fg"].bool() != a["fg"]).sum())
+        print("fg differs in %d anchors, oracle boundary gap %.3g" % (diff, a["boundary_gap"]))
+    # bit-exact unless the oracle itself reports a near-tie at the k-th boundary
+    assert same_fg or a["boundary_gap"] < 1e-5
+    if same_fg:
+        assert torch.equal(r["mgt"].long(), a["matched_gt"])
+        assert float((r["miou"] - a["matched_iou"]).abs().max()) < 2e-6
+        L = r["losses"]
+        for i, k in enumerate(("loss", "loss_iou", "loss_obj", "loss_cls")):
+            assert abs(float(L[i]) - float(out[k])) <= 1e-4 * max(1.0, abs(float(out[k]))), k
+        for gr, l in zip(r["grads"], leafs):
+            assert float((gr - l.grad).abs().max()) <= 1e-5 * max(1e-3, float(l.grad.abs().max()))
+    # bf16 gradient form = rounding of the fp32 form
+    r2 = run_loss(maps, lab, strides, C_, gout=gout, bf16_grads=True)
+    for g32, g16 in zip(r["grads"], r2["grads"]):
+        assert torch.equal(g32.to(torch.bfloat16).float(), g16)
+
+
+def test_loss_edge_cases():
+    # every image empty; labels with a single row; M == 1
+    maps, lab, strides = _rand_case(21, 2, 5, 128, [0, 0])
+    r = run_loss(maps, lab, strides, 5)
+    out = ol.yolox_loss(maps, lab, strides, 5)
+    assert int(r["fg"].sum()) == 0 and float(r["losses"][4]) == 0
+    assert abs(float(r["losses"][0]) - float(out["loss"])) < 1e-4 * float(out["loss"])
+    assert float(r["losses"][6]) == 1.0  # max(num_fg,1)/max(num_gt,1)
+    maps, lab, strides = _rand_case(22, 1, 5, 128, [1])
+    r = run_loss(maps, lab[:, :1], strides, 5)
+    out = ol.yolox_loss(maps, lab[:, :1], strides, 5, return_assign=True)
+    assert torch.equal(r["fg"].bool(), out["_assign"]["fg"])
+
+
+# ----------------------------------------------------------------------- NMS
+def run_postprocess(pred, conf, nms, agnostic=False, max_nms=10000, max_det=300, numel=20000):
+    B, A, nch = pred.shape
+    d = NmsDesc()
+    d.B, d.A, d.C, d.conf_thre, d.nms_thre, d.class_agnostic = B, A, nch - 5, conf, nms, int(agnostic)
+    d.max_nms, d.max_det, d.numel_threshold = max_nms, max_det, numel
+    p = torch.as_tensor(pred, dtype=torch.float32, device=hu.DEV).contiguous()
+    wsb = hu._lib.lib().plyolo_postprocess_workspace(C.byref(d))
+    ws = torch.zeros(wsb, dtype=torch.uint8, device=hu.DEV)
+    det = torch.zeros(B, max_det, 6, device=hu.DEV)
+    cnt = torch.zeros(B, dtype=torch.int32, device=hu.DEV)
+    ncand = torch.zeros(B, dtype=torch.int32, device=hu.DEV)
+    call("plyolo_postprocess", C.byref(d), p.data_ptr(), det.data_ptr(), cnt.data_ptr(), ncand.data_ptr(), ws.data_ptr(), wsb, hu.stream())
+    torch.cuda.synchronize()
+    return [det[b, :int(cnt[b])].cpu().numpy() if int(cnt[b]) else None for b in range(B)], ncand.cpu().numpy()
+
+
+def _rand_pred(seed, B, A, C_, size=640, frac=0.2):
+    rng = np.random.default_rng(seed)
+    p = np.zeros((B, A, 5 + C_), np.float32)
+    ctr = rng.uniform(30, size - 30, (B, A // 5 + 1, 2))
+    for b in range(B):
+        c = np.repeat(ctr[b], 5, 0)[:A] + rng.normal(0, 4, (A, 2))
+        wh = np.exp(rng.uniform(np.log(16), np.log(200), (A, 2)))
+        p[b, :, 0:2] = c - wh / 2
+        p[b, :, 2:4] = c + wh / 2
+    p[..., 4] = np.where(rng.uniform(0, 1, (B, A)) < frac, rng.uniform(0.05, 1, (B, A)), 1e-4)
+    p[..., 5:] = rng.uniform(0, 1, (B, A, C_)) ** 4
+    return p
+
+
+@pytest.mark.parametrize("seed,B,A,C_,agn,numel", [
+    (1, 3, 2100, 80, False, 20000),     # coordinate-trick branch
+    (2, 2, 8400, 80, False, 20000),
+    (3, 2, 8400, 10, False, 400),       # forces the per-class ("vanilla") branch
+    (4, 2, 3000, 6, True, 20000),       # class agnostic
+])
+def test_postprocess_vs_oracle(seed, B, A, C_, agn, numel):
+    p = _rand_pred(seed, B, A, C_, frac=0.5 if A <= 3000 else 0.2)
+    want = onms.postprocess(p, 0.01, 0.65, class_agnostic=agn, numel_threshold=numel)
+    got, ncand = run_postprocess(p, 0.01, 0.65, agnostic=agn, numel=numel)
+    for b in range(B):
+        if want[b] is None:
+            assert got[b] is None
+            continue
+        print("image", b, "cand", ncand[b], "kept", len(want[b]))
+        assert got[b] is not None and got[b].shape == want[b].shape
+        np.testing.assert_array_equal(got[b], want[b])
+
+
+def test_postprocess_edges():
+    p = _rand_pred(7, 2, 500, 4)
+    p[1, :, 4] = 0.0
+    got, ncand = run_postprocess(p, 0.3, 0.5)
+    want = onms.postprocess(p, 0.3, 0.5)
+    assert got[1] is None and want[1] is None and ncand[1] == 0
+    np.testing.assert_array_equal(got[0], want[0])
+    # max_det cap and max_nms truncation (first max_nms in ANCHOR order enter NMS)
+    p = _rand_pred(8, 1, 4000, 3, frac=1.0)
+    got, ncand = run_postprocess(p, 0.0, 0.9, max_nms=1000, max_det=50)
+    want = onms.postprocess(p, 0.0, 0.9, max_nms=1000, max_det=50)
+    assert ncand[0] == 1000 and got[0].shape[0] == 50
+    np.testing.assert_array_equal(got[0], want[0])
+
+
+def test_batched_nms_entry():
+    rng = np.random.default_rng(5)
+    B, n_max = 3, 1000
+    boxes = np.zeros((B, n_max, 6), np.float32)
+    nbox = np.array([1000, 0, 517], np.int32)
+    for b in range(B):
+        c = np.repeat(rng.uniform(50, 1200, (200, 2)), 5, 0) + rng.normal(0, 4, (n_max, 2))
+        wh = np.exp(rng.uniform(np.log(16), np.log(256), (n_max, 2)))
+        boxes[b, :, 0:2], boxes[b, :, 2:4] = c - wh / 2, c + wh / 2
+        boxes[b, :, 4] = rng.uniform(0.01, 1, n_max)
+        boxes[b, :, 5] = rng.integers(0, 80, n_max)
+    d = NmsDesc()
+    d.B, d.A, d.C, d.conf_thre, d.nms_thre, d.class_agnostic, d.max_nms, d.max_det, d.numel_threshold = B, n_max, 80, 0.01, 0.65, 0, 10000, 300, 20000
+    wsb = hu._lib.lib().plyolo_postprocess_workspace(C.byref(d))
+    ws = torch.zeros(wsb, dtype=torch.uint8, device=hu.DEV)
+    bt = torch.as_tensor(boxes, device=hu.DEV)
+    nb = torch.as_tensor(nbox, device=hu.DEV)
+    det = torch.zeros(B, 300, 6, device=hu.DEV)
+    cnt = torch.zeros(B, dtype=torch.int32, device=hu.DEV)
+    call("plyolo_batched_nms", C.byref(d), bt.data_ptr(), n_max, nb.data_ptr(), det.data_ptr(), cnt.data_ptr(), ws.data_ptr(), wsb, hu.stream())
+    torch.cuda.synchronize()
+    for b in range(B):
+        bb = boxes[b, :nbox[b]]
+        keep = onms.batched_nms(bb[:, :4], bb[:, 4], bb[:, 5], 0.65)[:300]
+        assert int(cnt[b]) == len(keep)
+        np.testing.assert_array_equal(det[b, :len(keep)].cpu().numpy(), bb[keep])
