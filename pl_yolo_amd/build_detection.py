@@ -63,8 +63,10 @@ class OneStageD(nn.Module):
 
     def forward(self, x, labels=None):
         r = self.runner()
-        if labels is None:
-            return r.forward_maps(x)           # list of raw NCHW head maps (build_detection.py:51-52)
+        if labels is None:                     # list of raw NCHW head maps (build_detection.py:51-52)
+            if self.training and torch.is_grad_enabled():
+                return R.maps_step(r, x)       # differentiable w.r.t. the parameters
+            return r.forward_maps(x)
         if not self.training:
             return r.forward_eval(x)           # [B, A, 5+C]: x1,y1,x2,y2,sig(obj),sig(cls) (yolox_loss.py:25-36)
         out = R.train_step(r, x, labels)       # fp32[8], differentiable

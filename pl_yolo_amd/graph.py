@@ -478,6 +478,31 @@ class HeadBuffers:
             self.draw = torch.empty(self.rows * self.nch, dtype=torch.float32, device=dev)
             self.d_regobj = self.d_cls = None
 
+    def alloc_grad_only(self):
+        """Head-map gradient buffers for the labels=None training path (the caller's own
+        loss back-propagates into the raw maps)."""
+        g, dev = self.g, self.g.device
+        if g.dtype == BF16:
+            self.d_regobj = torch.zeros(self.rows * 16, dtype=torch.bfloat16, device=dev)
+            self.d_cls = torch.zeros(self.rows * self.cls_ld, dtype=torch.bfloat16, device=dev)
+            self.draw = None
+        else:
+            self.draw = torch.empty(self.rows * self.nch, dtype=torch.float32, device=dev)
+            self.d_regobj = self.d_cls = None
+
+    def set_map_grads(self, grads):
+        """API edge (not the hot path): NCHW fp32 gradients of the raw head maps -> the
+        level-major gradient buffers the head backward kernels read."""
+        B = self.B
+        for (h, w), r0, gm in zip(self.sizes, self.lvl_row, grads):
+            n = B * h * w
+            flat = gm.permute(0, 2, 3, 1).reshape(n, self.nch)
+            if self.draw is not None:
+                self.draw.view(self.rows, self.nch)[r0:r0 + n].copy_(flat)
+            else:
+                self.d_regobj.view(self.rows, 16)[r0:r0 + n, :5].copy_(flat[:, :5])
+                self.d_cls.view(self.rows, self.cls_ld)[r0:r0 + n, :self.nc].copy_(flat[:, 5:])
+
     def alloc_eval(self):
         self.eval_out = torch.empty(self.B * self.A * self.nch, dtype=torch.float32, device=self.g.device)
 

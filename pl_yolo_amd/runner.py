@@ -34,6 +34,7 @@ class DetectorRunner:
         self.sessions = {}
         self.flat = None
         self.use_graph = os.environ.get("PLYOLO_GRAPH", "0") == "1"
+        self._side = None  # hipGraph capture/replay needs a non-default stream
         self.ddp = None  # set by pl_yolo_amd.ddp.attach()
 
     def __deepcopy__(self, memo):  # ModelEMA deep-copies the module (ema.py:41)
@@ -137,6 +138,8 @@ class DetectorRunner:
         elif mode == "eval":
             head.alloc_eval()
             model.loss.emit(g, head, False)
+        elif mode == "maps_grad":
+            head.alloc_grad_only()
         g.allocate()
         g.build_pack_table(self.grad_ptr_of)
         # ---- record the forward plan
@@ -147,7 +150,7 @@ class DetectorRunner:
                 op.fwd()
         s.bwd = None
         s.used_params = []
-        if mode == "train":
+        if mode in ("train", "maps_grad"):
             s.bwd = G.Plan()
             with s.bwd:
                 call("plyolo_memset_async", g.dwp_arena.data_ptr(), 0, g.dwp_arena.numel() * 4, None)
@@ -175,6 +178,21 @@ class DetectorRunner:
     def _stream():
         return torch.cuda.current_stream().cuda_stream
 
+    def _run_plan(self, plan):
+        """Replay a launch plan ordered after the work already queued on torch's current
+        stream.  Eager replays go straight onto that stream; hipGraph replays use a
+        private stream (capture is not allowed on the legacy default stream) fenced with
+        events on both sides."""
+        if not self.use_graph:
+            plan.run(self._stream(), False)
+            return
+        cur = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        self._side.wait_stream(cur)
+        plan.run(self._side.cuda_stream, True)
+        cur.wait_stream(self._side)
+
     def _check_input(self, x):
         if not x.is_cuda:
             raise PlyoloError("pl_yolo_amd runs on an MI355X device tensor (got a %s tensor); there is no CPU path" % x.device.type)
@@ -196,12 +214,12 @@ class DetectorRunner:
         s = self._session(B, H, W, labels.shape[1], "train", x.device)
         s.head.labels.view(labels.shape).copy_(labels)
         self._focus(s, x)
-        s.fwd.run(self._stream(), self.use_graph)
+        self._run_plan(s.fwd)
         return s
 
     def backward_train(self, s, gout):
         s.head.gout[:gout.numel()].copy_(gout.reshape(-1))
-        s.bwd.run(self._stream(), self.use_graph)
+        self._run_plan(s.bwd)
         if self.ddp is not None:
             self.ddp.all_reduce_(self.flat["g"])
 
@@ -210,22 +228,28 @@ class DetectorRunner:
         B, _, H, W = x.shape
         s = self._session(B, H, W, 1, "eval", x.device)
         self._focus(s, x)
-        s.fwd.run(self._stream(), self.use_graph)
+        self._run_plan(s.fwd)
         hd = s.head
         return hd.eval_out.view(B, hd.A, hd.nch).clone()
 
-    def forward_maps(self, x):
+    def forward_maps(self, x, want_grad=False):
         x = self._check_input(x)
         B, _, H, W = x.shape
-        s = self._session(B, H, W, 1, "maps", x.device)
+        s = self._session(B, H, W, 1, "maps_grad" if want_grad else "maps", x.device)
         self._focus(s, x)
-        s.fwd.run(self._stream(), self.use_graph)
+        self._run_plan(s.fwd)
         hd = s.head
         outs = []
         for (h, w), r0 in zip(hd.sizes, hd.lvl_row):
             blk = hd.raw[r0 * hd.nch:(r0 + B * h * w) * hd.nch].view(B, h, w, hd.nch)
             outs.append(blk.permute(0, 3, 1, 2).contiguous())  # API edge: NCHW like the reference
-        return outs
+        return (s, outs) if want_grad else outs
+
+    def backward_maps(self, s, grads):
+        s.head.set_map_grads(grads)
+        self._run_plan(s.bwd)
+        if self.ddp is not None:
+            self.ddp.all_reduce_(self.flat["g"])
 
 
 class _TrainStep(torch.autograd.Function):
@@ -243,6 +267,29 @@ class _TrainStep(torch.autograd.Function):
         runner, s = ctx.runner, ctx.session
         runner.backward_train(s, gout.contiguous().float())
         return (None, None, None) + tuple(s.grad_views)
+
+
+class _MapsStep(torch.autograd.Function):
+    """labels=None in training mode: raw head maps out, caller's loss gradient back in."""
+
+    @staticmethod
+    def forward(ctx, runner, x, *params):
+        s, outs = runner.forward_maps(x, want_grad=True)
+        ctx.runner, ctx.session = runner, s
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        runner, s = ctx.runner, ctx.session
+        runner.backward_maps(s, [g.contiguous().float() for g in grads])
+        return (None, None) + tuple(s.grad_views)
+
+
+def maps_step(runner, x):
+    x = runner._check_input(x)
+    B, _, H, W = x.shape
+    s = runner._session(B, H, W, 1, "maps_grad", x.device)
+    return list(_MapsStep.apply(runner, x, *s.used_params))
 
 
 def train_step(runner, x, labels):
