@@ -59,6 +59,11 @@ int plyolo_plan_size(const plyolo_plan*);      /* number of recorded launches */
 int plyolo_plan_run(plyolo_plan*, void* stream); /* replay eagerly */
 int plyolo_plan_graph_instantiate(plyolo_plan*, void* stream); /* capture into a hipGraphExec */
 int plyolo_plan_graph_launch(plyolo_plan*, void* stream);
+/* Measurement aid: replay with a hipEvent pair around every launch (synchronises the
+ * stream); ms_out[i] = device time of launch i.  plan_op_info returns the launch's
+ * kernel label and its ALGORITHMIC flops / HBM bytes (what roofline.achieved is priced on). */
+int plyolo_plan_profile(plyolo_plan*, void* stream, float* ms_out, int n);
+int plyolo_plan_op_info(const plyolo_plan*, int i, char* label, int label_cap, double* flops, double* bytes);
 
 /* ------------------------------------------------------------ convolution
  * Replaces nn.Conv2d inside BaseConv (models/layers/network_blocks.py:18-26)

@@ -23,6 +23,27 @@ import torch.nn.functional as F
 BN_EPS = 1e-3
 BN_MOMENTUM = 0.03
 
+# Optional emulation of the HIP bf16 pipeline's storage roundings (forward only, used to
+# check the bf16 MFMA path tightly): bf16 weights, bf16 raw conv output `z` (the batch
+# statistics are taken from the fp32 accumulators first), bf16 activations, bf16 image
+# after the Focus gather; BatchNorm / SiLU arithmetic stays fp32, prediction convs write
+# fp32.  Enabled with `with emulate_bf16(): ...`.
+_EMU = [False]
+
+
+class emulate_bf16:
+    def __enter__(self):
+        self.prev = _EMU[0]
+        _EMU[0] = True
+
+    def __exit__(self, *exc):
+        _EMU[0] = self.prev
+        return False
+
+
+def _q(t):
+    return t.to(torch.bfloat16).to(torch.float32) if _EMU[0] else t
+
 
 def activation(x, name):
     """models/layers/activation.py:5-20 (module semantics, functional form)."""
@@ -41,13 +62,30 @@ def activation(x, name):
     raise AttributeError("Unsupported activation function type: {}".format(name))
 
 
-def conv_unit(state, prefix, x, stride, training, norm="bn", act="silu"):
+def conv_unit(state, prefix, x, stride, training, norm="bn", act="silu", residual=None):
     """One BaseConv: conv (no bias, same padding) -> BN (batch stats in
     training, running stats in eval; running buffers updated in place) -> act."""
     w = state[prefix + ".conv.weight"]
     k = w.shape[-1]
-    z = F.conv2d(x, w, state.get(prefix + ".conv.bias"), stride, (k - 1) // 2)
-    if norm is not None:
+    z = F.conv2d(x, _q(w), state.get(prefix + ".conv.bias"), stride, (k - 1) // 2)
+    if norm is not None and _EMU[0]:
+        if norm != "bn":
+            raise AttributeError("Unsupported normalization function type: {}".format(norm))
+        g, b = state[prefix + ".norm.weight"], state[prefix + ".norm.bias"]
+        rm, rv = state[prefix + ".norm.running_mean"], state[prefix + ".norm.running_var"]
+        if training:
+            mean = z.mean((0, 2, 3))
+            var = z.var((0, 2, 3), unbiased=False)
+            n = z.numel() / z.shape[1]
+            with torch.no_grad():
+                rm.mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * mean)
+                rv.mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * var * n / max(n - 1, 1))
+        else:
+            mean, var = rm, rv
+        scale = g / torch.sqrt(var + BN_EPS)
+        shift = b - mean * scale
+        z = _q(z) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    elif norm is not None:
         if norm != "bn":
             raise AttributeError("Unsupported normalization function type: {}".format(norm))
         z = F.batch_norm(
@@ -64,7 +102,10 @@ def conv_unit(state, prefix, x, stride, training, norm="bn", act="silu"):
             nbt = prefix + ".norm.num_batches_tracked"
             if nbt in state:
                 state[nbt] += 1
-    return activation(z, act)
+    out = activation(z, act)
+    if residual is not None:
+        out = out + residual  # Bottleneck shortcut (network_blocks.py:89-90)
+    return _q(out)
 
 
 def focus(x):
@@ -76,9 +117,8 @@ def focus(x):
 
 def bottleneck(state, prefix, x, shortcut, training, norm, act):
     y = conv_unit(state, prefix + ".conv1", x, 1, training, norm, act)
-    y = conv_unit(state, prefix + ".conv2", y, 1, training, norm, act)
-    use_add = shortcut and (x.shape[1] == y.shape[1])
-    return y + x if use_add else y
+    use_add = shortcut and (x.shape[1] == state[prefix + ".conv2.conv.weight"].shape[0])
+    return conv_unit(state, prefix + ".conv2", y, 1, training, norm, act, residual=x if use_add else None)
 
 
 def csp_layer(state, prefix, x, n, shortcut, training, norm, act):
@@ -102,7 +142,7 @@ def cspdarknet(state, cfg, x, training, prefix="backbone"):
     norm, act = cfg["norm"], cfg["act"]
     assert outs, "please provide output features of Darknet!"
     feats = {}
-    x = conv_unit(state, prefix + ".stem.conv", focus(x), 1, training, norm, act)
+    x = conv_unit(state, prefix + ".stem.conv", _q(focus(x)), 1, training, norm, act)
     feats["stem"] = x
     for s in (1, 2, 3):
         x = conv_unit(state, "%s.stage%d.0" % (prefix, s), x, 2, training, norm, act)
@@ -148,7 +188,7 @@ def decoupled_head(state, cfg, inputs, training, prefix="head"):
             r = conv_unit(state, "%s.reg_convs.%d.%d" % (prefix, k, j), r, 1, training, norm, act)
 
         def pred(name, t):
-            return F.conv2d(t, state["%s.%s.%d.weight" % (prefix, name, k)], state["%s.%s.%d.bias" % (prefix, name, k)])
+            return F.conv2d(t, _q(state["%s.%s.%d.weight" % (prefix, name, k)]), state["%s.%s.%d.bias" % (prefix, name, k)])
 
         outs.append(torch.cat([pred("reg_preds", r), pred("obj_preds", r), pred("cls_preds", c)], 1))
     return outs

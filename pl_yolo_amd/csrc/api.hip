@@ -19,6 +19,23 @@ void set_error(const char* fmt, ...) {
 }
 Plan* recording_plan() { return g_rec; }
 
+static thread_local std::string g_ann_label;
+static thread_local double g_ann_flops = 0.0, g_ann_bytes = 0.0;
+void annotate(const char* label, double flops, double bytes) {
+  g_ann_label = label ? label : "";
+  g_ann_flops = flops;
+  g_ann_bytes = bytes;
+}
+void take_annotation(PlanOp* op) {
+  if (op) {
+    op->label = g_ann_label.empty() ? "other" : g_ann_label;
+    op->flops = g_ann_flops;
+    op->bytes = g_ann_bytes;
+  }
+  g_ann_label.clear();
+  g_ann_flops = g_ann_bytes = 0.0;
+}
+
 int conv_mfma_stat_rows(const plyolo_conv_desc* d);
 int conv_mfma_fwd(const plyolo_conv_desc*, const void*, const void*, const float*, void*, float*, void*);
 int conv_mfma_dgrad(const plyolo_conv_desc*, const void*, const void*, void*, int, void*);
@@ -79,9 +96,9 @@ int plyolo_plan_run(plyolo_plan* p, void* stream) {
   PLY_CHECK_ARG(g_rec == nullptr, "plan_run: cannot replay while recording");
   Plan* q = (Plan*)p;
   for (size_t i = 0; i < q->ops.size(); ++i) {
-    hipError_t e = q->ops[i]((hipStream_t)stream);
+    hipError_t e = q->ops[i].fn((hipStream_t)stream);
     if (e != hipSuccess) {
-      set_error("plan_run: launch %zu failed: %s", i, hipGetErrorString(e));
+      set_error("plan_run: launch %zu (%s) failed: %s", i, q->ops[i].label.c_str(), hipGetErrorString(e));
       return -2;
     }
   }
@@ -96,7 +113,7 @@ int plyolo_plan_graph_instantiate(plyolo_plan* p, void* stream) {
   hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
   if (e != hipSuccess) { set_error("hipStreamBeginCapture: %s", hipGetErrorString(e)); return -2; }
   hipError_t le = hipSuccess;
-  for (size_t i = 0; i < q->ops.size() && le == hipSuccess; ++i) le = q->ops[i](s);
+  for (size_t i = 0; i < q->ops.size() && le == hipSuccess; ++i) le = q->ops[i].fn(s);
   e = hipStreamEndCapture(s, &q->graph);
   if (le != hipSuccess || e != hipSuccess) {
     set_error("graph capture failed: %s / %s", hipGetErrorString(le), hipGetErrorString(e));
@@ -106,6 +123,37 @@ int plyolo_plan_graph_instantiate(plyolo_plan* p, void* stream) {
   if (e != hipSuccess) { set_error("hipGraphInstantiate: %s", hipGetErrorString(e)); return -2; }
   return 0;
 }
+// Replay with a hipEvent pair around every recorded launch; ms_out[i] = device time of launch i.
+int plyolo_plan_profile(plyolo_plan* p, void* stream, float* ms_out, int n) {
+  PLY_CHECK_ARG(p != nullptr && ms_out != nullptr, "plan_profile: null argument");
+  PLY_CHECK_ARG(g_rec == nullptr, "plan_profile: cannot replay while recording");
+  Plan* q = (Plan*)p;
+  PLY_CHECK_ARG(n >= (int)q->ops.size(), "plan_profile: ms_out too small (%d < %zu)", n, q->ops.size());
+  hipStream_t s = (hipStream_t)stream;
+  std::vector<hipEvent_t> ev(q->ops.size() + 1);
+  for (auto& e : ev)
+    if (hipEventCreate(&e) != hipSuccess) { set_error("plan_profile: hipEventCreate failed"); return -2; }
+  hipError_t err = hipEventRecord(ev[0], s);
+  for (size_t i = 0; i < q->ops.size() && err == hipSuccess; ++i) {
+    err = q->ops[i].fn(s);
+    if (err == hipSuccess) err = hipEventRecord(ev[i + 1], s);
+  }
+  if (err == hipSuccess) err = hipStreamSynchronize(s);
+  if (err == hipSuccess)
+    for (size_t i = 0; i < q->ops.size(); ++i) (void)hipEventElapsedTime(&ms_out[i], ev[i], ev[i + 1]);
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  if (err != hipSuccess) { set_error("plan_profile: %s", hipGetErrorString(err)); return -2; }
+  return 0;
+}
+int plyolo_plan_op_info(const plyolo_plan* p, int i, char* label, int label_cap, double* flops, double* bytes) {
+  const Plan* q = (const Plan*)p;
+  PLY_CHECK_ARG(q && i >= 0 && i < (int)q->ops.size(), "plan_op_info: bad index");
+  if (label && label_cap > 0) snprintf(label, (size_t)label_cap, "%s", q->ops[i].label.c_str());
+  if (flops) *flops = q->ops[i].flops;
+  if (bytes) *bytes = q->ops[i].bytes;
+  return 0;
+}
+
 int plyolo_plan_graph_launch(plyolo_plan* p, void* stream) {
   Plan* q = (Plan*)p;
   PLY_CHECK_ARG(q && q->exec, "plan_graph_launch: plan has no instantiated graph");

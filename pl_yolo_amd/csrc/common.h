@@ -70,20 +70,33 @@ namespace plyolo {
 
 void set_error(const char* fmt, ...);
 
+struct PlanOp {
+  std::function<hipError_t(hipStream_t)> fn;
+  std::string label;   // kernel family / template instance, for the plan profiler
+  double flops = 0.0;  // algorithmic FLOPs of this launch (0 = not a contraction)
+  double bytes = 0.0;  // algorithmic HBM bytes of this launch
+};
 struct Plan {
-  std::vector<std::function<hipError_t(hipStream_t)>> ops;
+  std::vector<PlanOp> ops;
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
 };
 Plan* recording_plan();
+// Describe the NEXT submitted launch (label + algorithmic work); consumed by submit().
+void annotate(const char* label, double flops, double bytes);
+void take_annotation(PlanOp* op);
 
 // Either run `fn` now on `stream`, or append it to the plan being recorded.
 template <typename F> int submit(void* stream, F&& fn) {
   Plan* p = recording_plan();
   if (p) {
-    p->ops.emplace_back(std::forward<F>(fn));
+    PlanOp op;
+    op.fn = std::forward<F>(fn);
+    take_annotation(&op);
+    p->ops.emplace_back(std::move(op));
     return 0;
   }
+  take_annotation(nullptr);
   hipError_t e = fn((hipStream_t)stream);
   if (e != hipSuccess) {
     set_error("HIP launch failed: %s", hipGetErrorString(e));

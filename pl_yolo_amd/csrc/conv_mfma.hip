@@ -368,6 +368,12 @@ int conv_mfma_fwd(const plyolo_conv_desc* d, const void* x, const void* wp, cons
   int BN, CK;
   pick_tiles(p.Cin, p.Cout, p.si, d->ksize, d->y_f32 != 0, &BN, &CK);
   const bool f32 = d->y_f32 != 0;
+  {
+    char lab[64];
+    snprintf(lab, sizeof(lab), "conv_mfma_fwd<BN%d,CK%d>%s", BN, CK, f32 ? "f32out" : "");
+    const double M = (double)p.N * p.OHf * p.OWf;
+    annotate(lab, 2.0 * M * d->Cout * d->Cin * d->ksize * d->ksize, M * (d->Cout * (f32 ? 4.0 : 2.0)) + (double)d->N * d->H * d->W * d->Cin * 2.0);
+  }
   return submit(stream, [=](hipStream_t s) { return f32 ? launch_bn<true>(p, BN, CK, s) : launch_bn<false>(p, BN, CK, s); });
 }
 
@@ -412,6 +418,12 @@ int conv_mfma_dgrad(const plyolo_conv_desc* d, const void* dy, const void* wpd, 
     set_grid(p);
     int BN, CK;
     pick_tiles(p.Cin, p.Cout, 1, d->ksize, false, &BN, &CK);
+    {
+      char lab[64];
+      snprintf(lab, sizeof(lab), "conv_mfma_dgrad<BN%d,CK%d>", BN, CK);
+      const double Mo = (double)d->N * OH * OW, Mi = (double)d->N * d->H * d->W;
+      annotate(lab, 2.0 * Mo * d->Cout * d->Cin * d->ksize * d->ksize, (Mo * Kc + Mi * d->Cin * (accumulate ? 2.0 : 1.0)) * 2.0);
+    }
     rc = submit(stream, [=](hipStream_t s) { return launch_bn<false>(p, BN, CK, s); });
     return rc;
   }
@@ -452,6 +464,13 @@ int conv_mfma_dgrad(const plyolo_conv_desc* d, const void* dy, const void* wpd, 
       set_grid(p);
       int BN, CK;
       pick_tiles(p.Cin, p.Cout, 1, 2, false, &BN, &CK);
+      {
+        char lab[64];
+        snprintf(lab, sizeof(lab), "conv_mfma_dgrad_s2<BN%d,CK%d>", BN, CK);
+        const double Mo = (double)d->N * OH * OW, Mi = (double)d->N * d->H * d->W;
+        // one quarter of the layer's algorithmic work per parity-class launch
+        annotate(lab, 0.25 * 2.0 * Mo * d->Cout * d->Cin * d->ksize * d->ksize, 0.25 * (Mo * Kc + Mi * d->Cin * (accumulate ? 2.0 : 1.0)) * 2.0);
+      }
       rc = submit(stream, [=](hipStream_t s) { return launch_bn<false>(p, BN, CK, s); });
     }
   return rc;

@@ -185,6 +185,12 @@ int conv_mfma_wgrad(const plyolo_conv_desc* d, const void* x, const void* dy, fl
   if (S > p.ntiles) S = p.ntiles;
   p.Cout = true_cout;
   const int ks = d->ksize;
+  {
+    char lab[64];
+    snprintf(lab, sizeof(lab), "conv_wgrad<%dx%d,k%d>", CO_T, CI_T, ks);
+    const double Mo = (double)p.N * p.OH * p.OW, Mi = (double)p.N * p.H * p.W;
+    annotate(lab, 2.0 * Mo * d->Cout * d->Cin * ks * ks, (Mo * d->Cout + Mi * d->Cin) * 2.0 + 4.0 * ks * ks * d->Cout * d->Cin);
+  }
   return submit(stream, [=](hipStream_t s) -> hipError_t {
     if (wide) return ks == 3 ? launch_wg<128, 32, 3>(p, S, s) : launch_wg<128, 32, 1>(p, S, s);
     return ks == 3 ? launch_wg<64, 64, 3>(p, S, s) : launch_wg<64, 64, 1>(p, S, s);

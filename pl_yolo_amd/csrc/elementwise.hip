@@ -508,6 +508,7 @@ extern "C" {
 
 int plyolo_bn_finalize(const float* stats, int rows, int C, double count, const float* gamma, const float* beta, float eps,
                        float momentum, float* running_mean, float* running_var, int64_t* nbt, float* coef, void* stream) {
+  plyolo::annotate("bn_finalize", 0.0, 8.0 * rows * C);
   return submit(stream, [=](hipStream_t s) -> hipError_t {
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, s, stats, rows, C, count, gamma, beta, eps, momentum,
                        running_mean, running_var, nbt, coef);
@@ -525,6 +526,7 @@ int plyolo_bn_eval_coef(int C, const float* gamma, const float* beta, const floa
 
 int plyolo_bn_act_fwd(int dtype, int M, int C, const void* z, int z_ld, const float* coef, int act, const void* res, int r_ld,
                       void* out, int o_ld, void* stream) {
+  plyolo::annotate("bn_act_fwd", 0.0, (double)M * C * (dtype == PLYOLO_BF16 ? 2.0 : 4.0) * (res ? 3.0 : 2.0));
   const int V = dtype == PLYOLO_BF16 ? 8 : 4;
   PLY_CHECK_ARG(C % V == 0 && z_ld % V == 0 && o_ld % V == 0 && (!res || r_ld % V == 0), "bn_act_fwd: C/ld must be multiples of %d", V);
   const size_t work = (size_t)M * (C / V);
@@ -544,6 +546,7 @@ int plyolo_bn_bwd_rows(int M) {
 
 int plyolo_bn_act_bwd_reduce(int dtype, int M, int C, const void* dout, int d_ld, const void* z, int z_ld, const float* coef,
                              int act, float* partial, void* stream) {
+  plyolo::annotate("bn_act_bwd_reduce", 0.0, (double)M * C * (dtype == PLYOLO_BF16 ? 2.0 : 4.0) * 2.0);
   const int V = dtype == PLYOLO_BF16 ? 8 : 4;
   PLY_CHECK_ARG(C % V == 0 && z_ld % V == 0 && d_ld % V == 0, "bn_act_bwd_reduce: C/ld must be multiples of %d", V);
   const int rows = plyolo_bn_bwd_rows(M);
@@ -556,6 +559,7 @@ int plyolo_bn_act_bwd_reduce(int dtype, int M, int C, const void* dout, int d_ld
 
 int plyolo_bn_bwd_finalize(const float* partial, int rows, int C, double count, const float* gamma, const float* coef,
                            float* dgamma, float* dbeta, int accumulate, float* bcoef, void* stream) {
+  plyolo::annotate("bn_bwd_finalize", 0.0, 8.0 * rows * C);
   return submit(stream, [=](hipStream_t s) -> hipError_t {
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, s, partial, rows, C, count, gamma, coef, dgamma, dbeta,
                        accumulate, bcoef);
@@ -565,6 +569,7 @@ int plyolo_bn_bwd_finalize(const float* partial, int rows, int C, double count, 
 
 int plyolo_bn_act_bwd_dz(int dtype, int M, int C, const void* dout, int d_ld, const void* z, int z_ld, const float* coef,
                          const float* bcoef, int act, void* dz, int dz_ld, void* stream) {
+  plyolo::annotate("bn_act_bwd_dz", 0.0, (double)M * C * (dtype == PLYOLO_BF16 ? 2.0 : 4.0) * 3.0);
   const int V = dtype == PLYOLO_BF16 ? 8 : 4;
   PLY_CHECK_ARG(C % V == 0 && z_ld % V == 0 && d_ld % V == 0 && dz_ld % V == 0, "bn_act_bwd_dz: C/ld must be multiples of %d", V);
   const size_t work = (size_t)M * (C / V);
@@ -576,6 +581,7 @@ int plyolo_bn_act_bwd_dz(int dtype, int M, int C, const void* dout, int d_ld, co
 }
 
 int plyolo_focus_s2d(int dtype, const float* img, int N, int H, int W, void* out, int Cp, void* stream) {
+  plyolo::annotate("focus_s2d", 0.0, (double)N * H * W * 3 * 4.0 + (double)N * H * W / 4 * Cp * 2.0);
   PLY_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && Cp >= 12, "focus: H,W must be even and Cp >= 12");
   const size_t work = (size_t)N * (H / 2) * (W / 2);
   return submit(stream, [=](hipStream_t s) -> hipError_t {
@@ -585,6 +591,7 @@ int plyolo_focus_s2d(int dtype, const float* img, int N, int H, int W, void* out
 }
 
 int plyolo_copy_add(int dtype, int M, int C, const void* in, int i_ld, void* out, int o_ld, int accumulate, void* stream) {
+  plyolo::annotate("copy_add", 0.0, (double)M * C * (dtype == PLYOLO_BF16 ? 2.0 : 4.0) * (accumulate ? 3.0 : 2.0));
   const int V = dtype == PLYOLO_BF16 ? 8 : 4;
   PLY_CHECK_ARG(C % V == 0 && i_ld % V == 0 && o_ld % V == 0, "copy_add: C/ld must be multiples of %d", V);
   const size_t work = (size_t)M * (C / V);
@@ -596,6 +603,7 @@ int plyolo_copy_add(int dtype, int M, int C, const void* in, int i_ld, void* out
 }
 
 int plyolo_upsample2x_fwd(int dtype, int N, int H, int W, int C, const void* in, int i_ld, void* out, int o_ld, void* stream) {
+  plyolo::annotate("upsample2x_fwd", 0.0, (double)N * H * W * C * (dtype == PLYOLO_BF16 ? 2.0 : 4.0) * 5.0);
   const int V = dtype == PLYOLO_BF16 ? 8 : 4;
   PLY_CHECK_ARG(C % V == 0 && i_ld % V == 0 && o_ld % V == 0, "upsample: C/ld must be multiples of %d", V);
   const size_t work = (size_t)N * 4 * H * W * (C / V);
@@ -608,6 +616,7 @@ int plyolo_upsample2x_fwd(int dtype, int N, int H, int W, int C, const void* in,
 
 int plyolo_upsample2x_bwd(int dtype, int N, int H, int W, int C, const void* dout, int d_ld, void* din, int i_ld, int accumulate,
                           void* stream) {
+  plyolo::annotate("upsample2x_bwd", 0.0, (double)N * H * W * C * (dtype == PLYOLO_BF16 ? 2.0 : 4.0) * 5.0);
   const int V = dtype == PLYOLO_BF16 ? 8 : 4;
   PLY_CHECK_ARG(C % V == 0 && i_ld % V == 0 && d_ld % V == 0, "upsample: C/ld must be multiples of %d", V);
   const size_t work = (size_t)N * H * W * (C / V);
@@ -619,6 +628,7 @@ int plyolo_upsample2x_bwd(int dtype, int N, int H, int W, int C, const void* dou
 }
 
 int plyolo_maxpool_s1_fwd(int dtype, int N, int H, int W, int C, int k, const void* in, int i_ld, void* out, int o_ld, void* stream) {
+  plyolo::annotate("maxpool_s1_fwd", 0.0, (double)N * H * W * C * (dtype == PLYOLO_BF16 ? 2.0 : 4.0) * 2.0);
   const int V = dtype == PLYOLO_BF16 ? 8 : 4;
   PLY_CHECK_ARG(C % V == 0 && i_ld % V == 0 && o_ld % V == 0 && (k & 1), "maxpool: C/ld must be multiples of %d, k odd", V);
   const size_t work = (size_t)N * H * W * (C / V);
@@ -631,6 +641,7 @@ int plyolo_maxpool_s1_fwd(int dtype, int N, int H, int W, int C, int k, const vo
 
 int plyolo_maxpool_s1_bwd(int dtype, int N, int H, int W, int C, int k, const void* in, int i_ld, const void* dout, int d_ld,
                           float* din_f32, void* stream) {
+  plyolo::annotate("maxpool_s1_bwd", 0.0, (double)N * H * W * C * (dtype == PLYOLO_BF16 ? 2.0 : 4.0) * 3.0);
   const int V = dtype == PLYOLO_BF16 ? 8 : 4;
   PLY_CHECK_ARG(C % V == 0 && i_ld % V == 0 && d_ld % V == 0 && (k & 1), "maxpool: C/ld must be multiples of %d, k odd", V);
   const size_t work = (size_t)N * H * W * (C / V);
@@ -642,6 +653,7 @@ int plyolo_maxpool_s1_bwd(int dtype, int N, int H, int W, int C, int k, const vo
 }
 
 int plyolo_f32_to_act(int dtype, int M, int C, const float* in, void* out, int o_ld, int accumulate, void* stream) {
+  plyolo::annotate("f32_to_act", 0.0, (double)M * C * 6.0);
   const size_t work = (size_t)M * C;
   return submit(stream, [=](hipStream_t s) -> hipError_t {
     DISPATCH_T(dtype, hipLaunchKernelGGL(f32_to_act_kernel<T>, dim3(grid_for(work)), dim3(256), 0, s, (size_t)M, C, in, (T*)out, o_ld,
@@ -651,6 +663,7 @@ int plyolo_f32_to_act(int dtype, int M, int C, const float* in, void* out, int o
 }
 
 int plyolo_memset_async(void* p, int value, size_t bytes, void* stream) {
+  plyolo::annotate("memset", 0.0, (double)bytes);
   return submit(stream, [=](hipStream_t s) -> hipError_t { return hipMemsetAsync(p, value, bytes, s); });
 }
 
@@ -671,6 +684,7 @@ int plyolo_nchw_f32_to_nhwc(int dtype, int N, int H, int W, int C, const float* 
 }
 
 int plyolo_pack_weights(const plyolo_pack_entry* table_dev, int n, int dtype, int max_elems, void* stream) {
+  plyolo::annotate("pack_weights", 0.0, 0.0);
   int gy = cdiv(max_elems, 256 * 8);
   if (gy < 1) gy = 1;
   if (gy > 64) gy = 64;
@@ -681,6 +695,7 @@ int plyolo_pack_weights(const plyolo_pack_entry* table_dev, int n, int dtype, in
 }
 
 int plyolo_unpack_wgrads(const plyolo_pack_entry* table_dev, int n, int max_elems, int accumulate, void* stream) {
+  plyolo::annotate("unpack_wgrads", 0.0, 0.0);
   int gy = cdiv(max_elems, 256 * 8);
   if (gy < 1) gy = 1;
   if (gy > 64) gy = 64;
@@ -691,6 +706,7 @@ int plyolo_unpack_wgrads(const plyolo_pack_entry* table_dev, int n, int max_elem
 }
 
 int plyolo_bias_grad(int dtype, const void* dy, int M, int C, int ld, float* dbias, void* stream) {
+  plyolo::annotate("bias_grad", 0.0, (double)M * C * 2.0);
   return submit(stream, [=](hipStream_t s) -> hipError_t {
     DISPATCH_T(dtype, hipLaunchKernelGGL(bias_grad_kernel<T>, dim3(C), dim3(256), 0, s, (const T*)dy, M, C, ld, dbias);)
     return hipGetLastError();

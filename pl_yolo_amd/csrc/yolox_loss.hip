@@ -539,6 +539,7 @@ int plyolo_yolox_loss_fwd(const plyolo_yolox_desc* dp, const float* raw, const f
   PLY_CHECK_ARG(ws_bytes >= need, "yolox_loss: workspace too small (%zu < %zu)", ws_bytes, need);
   const size_t BA = (size_t)d.B * d.A;
   const int nblk = (int)((BA + 255) / 256);
+  plyolo::annotate("yolox_loss_fwd", 0.0, (double)BA * (5 + d.C) * 4.0 * 2.0);
   return submit(stream, [=](hipStream_t s) -> hipError_t {
     hipError_t e = hipMemsetAsync(ws.cnt, 0, BA * 4, s);
     if (e != hipSuccess) return e;
@@ -558,6 +559,7 @@ int plyolo_yolox_loss_bwd(const plyolo_yolox_desc* dp, const float* raw, const f
   PLY_CHECK_ARG((draw_f32 != nullptr) != (d_regobj != nullptr && d_cls != nullptr), "yolox_loss_bwd: give draw_f32 OR (d_regobj, d_cls)");
   const size_t total = (size_t)d.B * d.A * (5 + d.C);
   const unsigned grid = (unsigned)cdivz(total, 256);
+  plyolo::annotate("yolox_loss_bwd", 0.0, (double)total * 6.0);
   return submit(stream, [=](hipStream_t s) -> hipError_t {
     if (draw_f32)
       hipLaunchKernelGGL(k_bwd<false>, dim3(grid), dim3(256), 0, s, d, raw, labels, fg, matched_gt, matched_iou, losses, gout, draw_f32,

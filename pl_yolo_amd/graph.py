@@ -564,6 +564,20 @@ class Plan:
         else:
             call("plyolo_plan_run", self.h, stream)
 
+    def profile(self, stream):
+        """Replay with a hipEvent pair around every launch.  Returns a list of
+        (label, ms, algorithmic_flops, algorithmic_bytes), one entry per launch."""
+        n = self.size()
+        ms = (C.c_float * max(n, 1))()
+        call("plyolo_plan_profile", self.h, stream, C.cast(ms, C.c_void_p), n)
+        out = []
+        buf = C.create_string_buffer(96)
+        fl, by = C.c_double(), C.c_double()
+        for i in range(n):
+            call("plyolo_plan_op_info", self.h, i, buf, 96, C.byref(fl), C.byref(by))
+            out.append((buf.value.decode(), float(ms[i]), fl.value, by.value))
+        return out
+
     def __del__(self):
         try:
             if self.h:

@@ -109,3 +109,8 @@ def relerr(a, b):
 def cossim(a, b):
     a, b = a.flatten().double(), b.flatten().double()
     return float((a @ b) / (a.norm() * b.norm() + 1e-30))
+
+
+def relrms(a, b):
+    a, b = a.float(), b.float()
+    return float((a - b).pow(2).mean().sqrt() / (b.pow(2).mean().sqrt() + 1e-30))
