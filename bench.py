@@ -212,8 +212,10 @@ def main():
         if args.profile_out:
             os.makedirs(os.path.dirname(os.path.abspath(args.profile_out)), exist_ok=True)
             with open(args.profile_out, "w") as f:
+                nf = s.fwd.size()
+                ops = [[("fwd" if i < nf else "bwd"), l, sum(r[i][1] for r in prof) / nrep, fl, by] for i, (l, _, fl, by) in enumerate(prof[0])]
                 json.dump({"columns": ["kernel", "launches", "total_ms", "algo_flops", "algo_bytes"], "rows": table,
-                           "sum_ms": total_ms}, f, indent=1)
+                           "sum_ms": total_ms, "ops_columns": ["plan", "kernel", "ms", "algo_flops", "algo_bytes"], "ops": ops}, f, indent=1)
         result = {
             "metric": "images/sec fwd+bwd YOLOX-s 640x640 bs32", "value": value, "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,

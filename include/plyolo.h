@@ -125,7 +125,12 @@ int plyolo_unpack_wgrads(const plyolo_pack_entry* table_dev, int n, int max_elem
  * (unbiased var) and num_batches_tracked (int64) when non-NULL. */
 int plyolo_bn_finalize(const float* stats, int rows, int C, double count, const float* gamma,
                        const float* beta, float eps, float momentum, float* running_mean,
-                       float* running_var, int64_t* num_batches_tracked, float* coef, void* stream);
+                       float* running_var, int64_t* num_batches_tracked, float* coef,
+                       void* workspace, size_t ws_bytes, void* stream);
+/* workspace: chunk partials + arrival counters; must be ZEROED once by the caller (the
+ * counters reset themselves after every launch) and may be shared by all layers that
+ * run on one stream. */
+size_t plyolo_bn_finalize_workspace(int C);
 /* eval mode: coef from running statistics */
 int plyolo_bn_eval_coef(int C, const float* gamma, const float* beta, const float* running_mean,
                         const float* running_var, float eps, float* coef, void* stream);

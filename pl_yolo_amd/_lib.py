@@ -68,7 +68,8 @@ SIGNATURES = {
     "plyolo_bias_grad": (_i, [_i, _vp, _i, _i, _i, _vp, _vp]),
     "plyolo_pack_weights": (_i, [_vp, _i, _i, _i, _vp]),
     "plyolo_unpack_wgrads": (_i, [_vp, _i, _i, _i, _vp]),
-    "plyolo_bn_finalize": (_i, [_vp, _i, _i, _d, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "plyolo_bn_finalize": (_i, [_vp, _i, _i, _d, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "plyolo_bn_finalize_workspace": (_sz, [_i]),
     "plyolo_bn_eval_coef": (_i, [_i, _vp, _vp, _vp, _vp, _f, _vp, _vp]),
     "plyolo_bn_act_fwd": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp]),
     "plyolo_bn_bwd_rows": (_i, [_i]),

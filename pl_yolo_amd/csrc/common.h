@@ -65,6 +65,45 @@ DEVINL float act_grad(float u, int act) {
   }
 }
 
+// 16-byte vector access to activation rows (8 x bf16 or 4 x fp32), fp32 math in registers
+template <typename T> struct Vec;
+template <> struct Vec<bf16_t> {
+  static constexpr int N = 8;
+  static DEVINL void load(const bf16_t* p, float* f) {
+    const u32x4 v = *(const u32x4*)p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[2 * i] = __uint_as_float(v[i] << 16);
+      f[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
+    }
+  }
+  static DEVINL void store(bf16_t* p, const float* f) {
+    u32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = pack2bf(f[2 * i], f[2 * i + 1]);
+    *(u32x4*)p = v;
+  }
+  static constexpr bool precise = false;
+};
+template <> struct Vec<float> {
+  static constexpr int N = 4;
+  static DEVINL void load(const float* p, float* f) {
+    const f32x4 v = *(const f32x4*)p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = v[i];
+  }
+  static DEVINL void store(float* p, const float* f) {
+    f32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = f[i];
+    *(f32x4*)p = v;
+  }
+  static constexpr bool precise = true;
+};
+
+template <bool PRECISE> DEVINL float actf(float u, int act) { return PRECISE ? act_fwd_precise(u, act) : act_fwd(u, act); }
+
+
 // ---------------------------------------------------------------- host side
 namespace plyolo {
 

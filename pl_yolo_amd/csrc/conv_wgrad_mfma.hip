@@ -179,8 +179,12 @@ int conv_mfma_wgrad(const plyolo_conv_desc* d, const void* x, const void* dy, fl
   const int CO_T = wide ? 128 : 64, CI_T = wide ? 32 : 64;
   p.nci = (p.Cin + CI_T - 1) / CI_T;
   const int nco = (p.Cout + CO_T - 1) / CO_T;
-  int S = 768 / (nco * p.nci);
-  if (S > 48) S = 48;
+  // spatial split: enough workgroups to cover the chip several times over, but the fp32
+  // atomic combine moves S * |dW| bytes at ~1.3 TB/s chip-wide, so cap it at ~24 MB
+  const double dw_bytes = 4.0 * d->ksize * d->ksize * (double)d->Cout * d->Cin;
+  int S = 2048 / (nco * p.nci);
+  const int s_budget = (int)(24.0e6 / dw_bytes);
+  if (S > s_budget) S = s_budget;
   if (S < 1) S = 1;
   if (S > p.ntiles) S = p.ntiles;
   p.Cout = true_cout;

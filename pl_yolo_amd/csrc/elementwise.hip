@@ -10,222 +10,6 @@
 
 namespace {
 
-template <typename T> struct Vec;
-template <> struct Vec<bf16_t> {
-  static constexpr int N = 8;
-  static DEVINL void load(const bf16_t* p, float* f) {
-    const u32x4 v = *(const u32x4*)p;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      f[2 * i] = __uint_as_float(v[i] << 16);
-      f[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
-    }
-  }
-  static DEVINL void store(bf16_t* p, const float* f) {
-    u32x4 v;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = pack2bf(f[2 * i], f[2 * i + 1]);
-    *(u32x4*)p = v;
-  }
-  static constexpr bool precise = false;
-};
-template <> struct Vec<float> {
-  static constexpr int N = 4;
-  static DEVINL void load(const float* p, float* f) {
-    const f32x4 v = *(const f32x4*)p;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) f[i] = v[i];
-  }
-  static DEVINL void store(float* p, const float* f) {
-    f32x4 v;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = f[i];
-    *(f32x4*)p = v;
-  }
-  static constexpr bool precise = true;
-};
-
-template <bool PRECISE> DEVINL float actf(float u, int act) { return PRECISE ? act_fwd_precise(u, act) : act_fwd(u, act); }
-
-// ------------------------------------------------------------------ BatchNorm
-__global__ void bn_finalize_kernel(const float* stats, int rows, int C, double count, const float* gamma,
-                                   const float* beta, float eps, float momentum, float* rmean, float* rvar,
-                                   int64_t* nbt, float* coef) {
-  // 32 channels x 8 row-slices per block
-  __shared__ double red[2][8][32];
-  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
-  double s = 0.0, ss = 0.0;
-  if (c < C)
-    for (int r = sl; r < rows; r += 8) {
-      s += stats[(size_t)r * C + c];
-      ss += stats[((size_t)rows + r) * C + c];
-    }
-  red[0][sl][cl] = s;
-  red[1][sl][cl] = ss;
-  __syncthreads();
-  if (sl == 0 && c < C) {
-    for (int k = 1; k < 8; ++k) { s += red[0][k][cl]; ss += red[1][k][cl]; }
-    const double mean = s / count;
-    double var = ss / count - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-    const float scale = g * invstd;
-    coef[c] = scale;
-    coef[C + c] = b - (float)mean * scale;
-    coef[2 * C + c] = (float)mean;
-    coef[3 * C + c] = invstd;
-    if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
-    if (rvar) {
-      const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-      rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
-    }
-  }
-  if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
-}
-
-__global__ void bn_eval_coef_kernel(int C, const float* gamma, const float* beta, const float* rmean, const float* rvar,
-                                    float eps, float* coef) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const float invstd = 1.0f / sqrtf(rvar[c] + eps);
-  const float scale = (gamma ? gamma[c] : 1.f) * invstd;
-  coef[c] = scale;
-  coef[C + c] = (beta ? beta[c] : 0.f) - rmean[c] * scale;
-  coef[2 * C + c] = rmean[c];
-  coef[3 * C + c] = invstd;
-}
-
-template <typename T>
-__global__ void bn_act_fwd_kernel(size_t M, int C, const T* z, int z_ld, const float* coef, int act, const T* res,
-                                  int r_ld, T* out, int o_ld) {
-  constexpr int V = Vec<T>::N;
-  const int cvn = C / V;
-  const size_t total = M * cvn;
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    const size_t m = idx / cvn;
-    const int c = (int)(idx - m * cvn) * V;
-    float f[V], r[V];
-    Vec<T>::load(z + m * z_ld + c, f);
-    if (res) Vec<T>::load(res + m * r_ld + c, r);
-#pragma unroll
-    for (int i = 0; i < V; ++i) {
-      float u = coef ? fmaf(f[i], coef[c + i], coef[C + c + i]) : f[i];
-      u = actf<Vec<T>::precise>(u, act);
-      f[i] = res ? u + r[i] : u;
-    }
-    Vec<T>::store(out + m * o_ld + c, f);
-  }
-}
-
-// partial[0][row][c] = sum du ; partial[1][row][c] = sum du * zhat
-template <typename T>
-__global__ void bn_act_bwd_reduce_kernel(size_t M, int C, const T* dout, int d_ld, const T* z, int z_ld, const float* coef,
-                                         int act, float* partial, int rows) {
-  constexpr int V = Vec<T>::N;
-  __shared__ float red[256 * 2 * V];
-  const int cvn = C / V;
-  const int cols = cvn < 256 ? cvn : 256;
-  const int rg = 256 / cols;
-  const int tcol = threadIdx.x % cols, trow = threadIdx.x / cols;
-  const int row = blockIdx.x;
-  const size_t chunk = (M + rows - 1) / rows;
-  const size_t m0 = (size_t)row * chunk, m1 = m0 + chunk < M ? m0 + chunk : M;
-  for (int cv0 = 0; cv0 < cvn; cv0 += cols) {
-    const int cv = cv0 + tcol;
-    float s1[V], s2[V];
-#pragma unroll
-    for (int i = 0; i < V; ++i) s1[i] = s2[i] = 0.f;
-    if (trow < rg && cv < cvn) {
-      const int c = cv * V;
-      float sc[V], sh[V], mu[V], is[V];
-#pragma unroll
-      for (int i = 0; i < V; ++i) { sc[i] = coef[c + i]; sh[i] = coef[C + c + i]; mu[i] = coef[2 * C + c + i]; is[i] = coef[3 * C + c + i]; }
-      for (size_t m = m0 + trow; m < m1; m += rg) {
-        float d[V], zz[V];
-        Vec<T>::load(dout + m * d_ld + c, d);
-        Vec<T>::load(z + m * z_ld + c, zz);
-#pragma unroll
-        for (int i = 0; i < V; ++i) {
-          const float u = fmaf(zz[i], sc[i], sh[i]);
-          const float du = d[i] * act_grad(u, act);
-          s1[i] += du;
-          s2[i] += du * ((zz[i] - mu[i]) * is[i]);
-        }
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < V; ++i) { red[(threadIdx.x * 2 + 0) * V + i] = s1[i]; red[(threadIdx.x * 2 + 1) * V + i] = s2[i]; }
-    __syncthreads();
-    if (trow == 0 && cv < cvn) {
-      for (int k = 1; k < rg; ++k)
-#pragma unroll
-        for (int i = 0; i < V; ++i) {
-          s1[i] += red[((k * cols + tcol) * 2 + 0) * V + i];
-          s2[i] += red[((k * cols + tcol) * 2 + 1) * V + i];
-        }
-#pragma unroll
-      for (int i = 0; i < V; ++i) {
-        partial[(size_t)row * C + cv * V + i] = s1[i];
-        partial[((size_t)rows + row) * C + cv * V + i] = s2[i];
-      }
-    }
-  }
-}
-
-__global__ void bn_bwd_finalize_kernel(const float* partial, int rows, int C, double count, const float* gamma,
-                                       const float* coef, float* dgamma, float* dbeta, int accumulate, float* bcoef) {
-  __shared__ double red[2][8][32];
-  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
-  double s = 0.0, ss = 0.0;
-  if (c < C)
-    for (int r = sl; r < rows; r += 8) {
-      s += partial[(size_t)r * C + c];
-      ss += partial[((size_t)rows + r) * C + c];
-    }
-  red[0][sl][cl] = s;
-  red[1][sl][cl] = ss;
-  __syncthreads();
-  if (sl == 0 && c < C) {
-    for (int k = 1; k < 8; ++k) { s += red[0][k][cl]; ss += red[1][k][cl]; }
-    const float db = (float)s, dg = (float)ss;
-    if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + db;
-    if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + dg;
-    const float mean = coef[2 * C + c], invstd = coef[3 * C + c];
-    const float A = (gamma ? gamma[c] : 1.f) * invstd;
-    const float B = (float)(-(double)A * (ss / count) * (double)invstd);
-    const float Cc = (float)(-(double)A * (s / count) - (double)B * (double)mean);
-    bcoef[c] = A;
-    bcoef[C + c] = B;
-    bcoef[2 * C + c] = Cc;
-  }
-}
-
-template <typename T>
-__global__ void bn_act_bwd_dz_kernel(size_t M, int C, const T* dout, int d_ld, const T* z, int z_ld, const float* coef,
-                                     const float* bcoef, int act, T* dz, int dz_ld) {
-  constexpr int V = Vec<T>::N;
-  const int cvn = C / V;
-  const size_t total = M * cvn;
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    const size_t m = idx / cvn;
-    const int c = (int)(idx - m * cvn) * V;
-    float d[V], zz[V];
-    Vec<T>::load(dout + m * d_ld + c, d);
-    Vec<T>::load(z + m * z_ld + c, zz);
-#pragma unroll
-    for (int i = 0; i < V; ++i) {
-      const float u = fmaf(zz[i], coef[c + i], coef[C + c + i]);
-      const float du = d[i] * act_grad(u, act);
-      d[i] = fmaf(bcoef[c + i], du, fmaf(bcoef[C + c + i], zz[i], bcoef[2 * C + c + i]));
-    }
-    Vec<T>::store(dz + m * dz_ld + c, d);
-  }
-}
-
 // ------------------------------------------------------------- data movement
 template <typename T>
 __global__ void focus_kernel(const float* img, int N, int H, int W, T* out, int Cp) {
@@ -453,19 +237,25 @@ __global__ void unpack_wgrads_kernel(const plyolo_pack_entry* table, int accumul
     for (int i = threadIdx.x; i < e.Cout; i += blockDim.x) e.db[i] = (accumulate ? e.db[i] : 0.f) + e.dbp[e.co_off + i];
 }
 
+// dbias[c] += sum over rows; block = (row slices) x (channels), one atomic per channel per block
 template <typename T>
 __global__ void bias_grad_kernel(const T* dy, int M, int C, int ld, float* db) {
-  const int c = blockIdx.x;
-  __shared__ double red[256];
-  double s = 0.0;
-  for (int m = threadIdx.x; m < M; m += blockDim.x) s += (double)ActT<T>::ld(dy + (size_t)m * ld + c);
-  red[threadIdx.x] = s;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+  __shared__ float red[256];
+  const int cols = C < 256 ? C : 256, rg = 256 / cols;
+  const int tcol = threadIdx.x % cols, trow = threadIdx.x / cols;
+  for (int c0 = 0; c0 < C; c0 += cols) {
+    const int c = c0 + tcol;
+    float s = 0.f;
+    if (trow < rg && c < C)
+      for (int m = blockIdx.x * rg + trow; m < M; m += gridDim.x * rg) s += ActT<T>::ld(dy + (size_t)m * ld + c);
     __syncthreads();
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (trow == 0 && c < C) {
+      for (int k = 1; k < rg; ++k) s += red[k * cols + tcol];
+      atomicAdd(db + c, s);
+    }
   }
-  if (threadIdx.x == 0) db[c] = (float)red[0];
 }
 
 // ------------------------------------------------------------------ optimizer
@@ -505,80 +295,6 @@ using plyolo::submit;
   else { typedef float T; __VA_ARGS__ }
 
 extern "C" {
-
-int plyolo_bn_finalize(const float* stats, int rows, int C, double count, const float* gamma, const float* beta, float eps,
-                       float momentum, float* running_mean, float* running_var, int64_t* nbt, float* coef, void* stream) {
-  plyolo::annotate("bn_finalize", 0.0, 8.0 * rows * C);
-  return submit(stream, [=](hipStream_t s) -> hipError_t {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, s, stats, rows, C, count, gamma, beta, eps, momentum,
-                       running_mean, running_var, nbt, coef);
-    return hipGetLastError();
-  });
-}
-
-int plyolo_bn_eval_coef(int C, const float* gamma, const float* beta, const float* running_mean, const float* running_var,
-                        float eps, float* coef, void* stream) {
-  return submit(stream, [=](hipStream_t s) -> hipError_t {
-    hipLaunchKernelGGL(bn_eval_coef_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, C, gamma, beta, running_mean, running_var, eps, coef);
-    return hipGetLastError();
-  });
-}
-
-int plyolo_bn_act_fwd(int dtype, int M, int C, const void* z, int z_ld, const float* coef, int act, const void* res, int r_ld,
-                      void* out, int o_ld, void* stream) {
-  plyolo::annotate("bn_act_fwd", 0.0, (double)M * C * (dtype == PLYOLO_BF16 ? 2.0 : 4.0) * (res ? 3.0 : 2.0));
-  const int V = dtype == PLYOLO_BF16 ? 8 : 4;
-  PLY_CHECK_ARG(C % V == 0 && z_ld % V == 0 && o_ld % V == 0 && (!res || r_ld % V == 0), "bn_act_fwd: C/ld must be multiples of %d", V);
-  const size_t work = (size_t)M * (C / V);
-  return submit(stream, [=](hipStream_t s) -> hipError_t {
-    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_fwd_kernel<T>, dim3(grid_for(work)), dim3(256), 0, s, (size_t)M, C, (const T*)z, z_ld,
-                                         coef, act, (const T*)res, r_ld, (T*)out, o_ld);)
-    return hipGetLastError();
-  });
-}
-
-int plyolo_bn_bwd_rows(int M) {
-  int r = M / 128;
-  if (r < 1) r = 1;
-  if (r > 512) r = 512;
-  return r;
-}
-
-int plyolo_bn_act_bwd_reduce(int dtype, int M, int C, const void* dout, int d_ld, const void* z, int z_ld, const float* coef,
-                             int act, float* partial, void* stream) {
-  plyolo::annotate("bn_act_bwd_reduce", 0.0, (double)M * C * (dtype == PLYOLO_BF16 ? 2.0 : 4.0) * 2.0);
-  const int V = dtype == PLYOLO_BF16 ? 8 : 4;
-  PLY_CHECK_ARG(C % V == 0 && z_ld % V == 0 && d_ld % V == 0, "bn_act_bwd_reduce: C/ld must be multiples of %d", V);
-  const int rows = plyolo_bn_bwd_rows(M);
-  return submit(stream, [=](hipStream_t s) -> hipError_t {
-    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<T>, dim3(rows), dim3(256), 0, s, (size_t)M, C, (const T*)dout, d_ld,
-                                         (const T*)z, z_ld, coef, act, partial, rows);)
-    return hipGetLastError();
-  });
-}
-
-int plyolo_bn_bwd_finalize(const float* partial, int rows, int C, double count, const float* gamma, const float* coef,
-                           float* dgamma, float* dbeta, int accumulate, float* bcoef, void* stream) {
-  plyolo::annotate("bn_bwd_finalize", 0.0, 8.0 * rows * C);
-  return submit(stream, [=](hipStream_t s) -> hipError_t {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, s, partial, rows, C, count, gamma, coef, dgamma, dbeta,
-                       accumulate, bcoef);
-    return hipGetLastError();
-  });
-}
-
-int plyolo_bn_act_bwd_dz(int dtype, int M, int C, const void* dout, int d_ld, const void* z, int z_ld, const float* coef,
-                         const float* bcoef, int act, void* dz, int dz_ld, void* stream) {
-  plyolo::annotate("bn_act_bwd_dz", 0.0, (double)M * C * (dtype == PLYOLO_BF16 ? 2.0 : 4.0) * 3.0);
-  const int V = dtype == PLYOLO_BF16 ? 8 : 4;
-  PLY_CHECK_ARG(C % V == 0 && z_ld % V == 0 && d_ld % V == 0 && dz_ld % V == 0, "bn_act_bwd_dz: C/ld must be multiples of %d", V);
-  const size_t work = (size_t)M * (C / V);
-  return submit(stream, [=](hipStream_t s) -> hipError_t {
-    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_bwd_dz_kernel<T>, dim3(grid_for(work)), dim3(256), 0, s, (size_t)M, C, (const T*)dout,
-                                         d_ld, (const T*)z, z_ld, coef, bcoef, act, (T*)dz, dz_ld);)
-    return hipGetLastError();
-  });
-}
 
 int plyolo_focus_s2d(int dtype, const float* img, int N, int H, int W, void* out, int Cp, void* stream) {
   plyolo::annotate("focus_s2d", 0.0, (double)N * H * W * 3 * 4.0 + (double)N * H * W / 4 * Cp * 2.0);
@@ -708,7 +424,12 @@ int plyolo_unpack_wgrads(const plyolo_pack_entry* table_dev, int n, int max_elem
 int plyolo_bias_grad(int dtype, const void* dy, int M, int C, int ld, float* dbias, void* stream) {
   plyolo::annotate("bias_grad", 0.0, (double)M * C * 2.0);
   return submit(stream, [=](hipStream_t s) -> hipError_t {
-    DISPATCH_T(dtype, hipLaunchKernelGGL(bias_grad_kernel<T>, dim3(C), dim3(256), 0, s, (const T*)dy, M, C, ld, dbias);)
+    hipError_t e = hipMemsetAsync(dbias, 0, (size_t)C * 4, s);
+    if (e != hipSuccess) return e;
+    int nb = M / 64;
+    if (nb < 1) nb = 1;
+    if (nb > 1024) nb = 1024;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bias_grad_kernel<T>, dim3(nb), dim3(256), 0, s, (const T*)dy, M, C, ld, dbias);)
     return hipGetLastError();
   });
 }

@@ -113,6 +113,8 @@ class Graph:
             st.tensor = torch.empty(st.rows * st.ld, dtype=self.tdtype, device=dev)
         self.scratch = torch.empty(max(self.scratch_elems, 8), dtype=self.tdtype, device=dev)
         self.scratch32 = torch.zeros(max(self.scratch_f32, 8), dtype=torch.float32, device=dev)
+        cmax = max([c.Cout_total for c in self.convs] + [8])
+        self.fin_ws = torch.zeros(_lib.lib().plyolo_bn_finalize_workspace(cmax), dtype=torch.uint8, device=dev)
         # weight arenas
         wp_n = sum(_align(c.wp_elems) for c in self.convs)
         wpd_n = sum(_align(c.wpd_elems) for c in self.convs)
@@ -298,7 +300,7 @@ class ConvUnitOp:
             if g.training:
                 call("plyolo_bn_finalize", self.stats.data_ptr(), self.stat_rows, self.Cout, float(self.out.M),
                      ptr(bn.weight), ptr(bn.bias), float(bn.eps), float(bn.momentum), ptr(bn.running_mean),
-                     ptr(bn.running_var), ptr(bn.num_batches_tracked), coef, None)
+                     ptr(bn.running_var), ptr(bn.num_batches_tracked), coef, g.fin_ws.data_ptr(), g.fin_ws.numel(), None)
             else:
                 call("plyolo_bn_eval_coef", self.Cout, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
                      ptr(bn.running_var), float(bn.eps), coef, None)

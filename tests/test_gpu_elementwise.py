@@ -47,15 +47,19 @@ def test_bn_act_fwd_bwd(dt, act):
     resm = hu.to_nhwc(res, dt, Cc + 8)
     # statistics partials as the conv epilogue would produce them (3 row blocks)
     zz = zm.float()
-    rows = 3
+    rows = 200  # > 64 rows per chunk -> several chunk workgroups + last-arriver reduction
     stats = torch.zeros(2, rows, Cc, device=hu.DEV)
     for r, chunk in enumerate(torch.chunk(zz, rows, 0)):
         stats[0, r] = chunk.sum(0)
         stats[1, r] = (chunk * chunk).sum(0)
     coef = torch.zeros(4 * Cc, device=hu.DEV)
     nbt = torch.zeros(1, dtype=torch.int64, device=hu.DEV)
-    call("plyolo_bn_finalize", stats.data_ptr(), rows, Cc, float(M), gamma.data_ptr(), beta.data_ptr(), 1e-3, 0.03,
-         rm.data_ptr(), rv.data_ptr(), nbt.data_ptr(), coef.data_ptr(), hu.stream())
+    wsb = hu._lib.lib().plyolo_bn_finalize_workspace(Cc)
+    fws = torch.zeros(wsb, dtype=torch.uint8, device=hu.DEV)
+    for _ in range(2):  # second launch checks the self-resetting arrival counters
+        rm.zero_(); rv.fill_(1.0); nbt.zero_()
+        call("plyolo_bn_finalize", stats.data_ptr(), rows, Cc, float(M), gamma.data_ptr(), beta.data_ptr(), 1e-3, 0.03,
+             rm.data_ptr(), rv.data_ptr(), nbt.data_ptr(), coef.data_ptr(), fws.data_ptr(), wsb, hu.stream())
     out = torch.full((M, Cc + 16), 2.0, dtype=hu.tdtype(dt), device=hu.DEV)
     call("plyolo_bn_act_fwd", dt, M, Cc, zm.data_ptr(), Cc, coef.data_ptr(), hu._lib.ACT[act], resm.data_ptr(), Cc + 8,
          out.data_ptr(), Cc + 16, hu.stream())
