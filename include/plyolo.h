@@ -144,7 +144,7 @@ int plyolo_bn_act_bwd_reduce(int dtype, int M, int C, const void* dout, int d_ld
 /* dgamma/dbeta (+)=; bcoef[0:C]=A, [C:2C]=B, [2C:3C]=Cc so that dz = A*du + B*z + Cc */
 int plyolo_bn_bwd_finalize(const float* partial, int rows, int C, double count, const float* gamma,
                            const float* coef, float* dgamma, float* dbeta, int accumulate, float* bcoef,
-                           void* stream);
+                           void* workspace, size_t ws_bytes, void* stream); /* workspace: as bn_finalize */
 int plyolo_bn_act_bwd_dz(int dtype, int M, int C, const void* dout, int d_ld, const void* z, int z_ld,
                          const float* coef, const float* bcoef, int act, void* dz, int dz_ld, void* stream);
 

@@ -74,7 +74,7 @@ SIGNATURES = {
     "plyolo_bn_act_fwd": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp]),
     "plyolo_bn_bwd_rows": (_i, [_i]),
     "plyolo_bn_act_bwd_reduce": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp]),
-    "plyolo_bn_bwd_finalize": (_i, [_vp, _i, _i, _d, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "plyolo_bn_bwd_finalize": (_i, [_vp, _i, _i, _d, _vp, _vp, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "plyolo_bn_act_bwd_dz": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp]),
     "plyolo_focus_s2d": (_i, [_i, _vp, _i, _i, _i, _vp, _i, _vp]),
     "plyolo_copy_add": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _i, _vp]),

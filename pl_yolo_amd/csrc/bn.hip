@@ -198,14 +198,19 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(int M, int C, co
   }
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* partial, int rows, int C, double count, const float* gamma,
-                                       const float* coef, float* dgamma, float* dbeta, int accumulate, float* bcoef) {
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* partial, int rows, int C, double count, const float* gamma,
+                                                              const float* coef, float* dgamma, float* dbeta, int accumulate, float* bcoef,
+                                                              FinWs ws, int nchunk) {
+  // same chunked last-arriver reduction as bn_finalize_kernel
   __shared__ double red[2][8][32];
+  __shared__ int s_last;
   const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
+  const int per = (rows + nchunk - 1) / nchunk;
+  const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
   double s = 0.0, ss = 0.0;
   if (c < C)
-    for (int r = sl; r < rows; r += 8) {
+    for (int r = r0 + sl; r < r1; r += 8) {
       s += partial[(size_t)r * C + c];
       ss += partial[((size_t)rows + r) * C + c];
     }
@@ -214,6 +219,25 @@ __global__ void bn_bwd_finalize_kernel(const float* partial, int rows, int C, do
   __syncthreads();
   if (sl == 0 && c < C) {
     for (int k = 1; k < 8; ++k) { s += red[0][k][cl]; ss += red[1][k][cl]; }
+    ws.part[((size_t)blockIdx.y * 2 + 0) * C + c] = s;
+    ws.part[((size_t)blockIdx.y * 2 + 1) * C + c] = ss;
+  }
+  __threadfence();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = atomicAdd(&ws.counter[blockIdx.x], 1u);
+    s_last = (t == (unsigned)nchunk - 1u) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  if (sl == 0 && c < C) {
+    s = 0.0; ss = 0.0;
+    for (int k = 0; k < nchunk; ++k) {
+      s += ws.part[((size_t)k * 2 + 0) * C + c];
+      ss += ws.part[((size_t)k * 2 + 1) * C + c];
+    }
     const float db = (float)s, dg = (float)ss;
     if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + db;
     if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + dg;
@@ -225,6 +249,7 @@ __global__ void bn_bwd_finalize_kernel(const float* partial, int rows, int C, do
     bcoef[C + c] = B;
     bcoef[2 * C + c] = Cc;
   }
+  if (threadIdx.x == 0) ws.counter[blockIdx.x] = 0u;
 }
 
 template <typename T>
@@ -286,7 +311,7 @@ int plyolo_bn_finalize(const float* stats, int rows, int C, double count, const 
   FinWs ws;
   ws.part = (double*)workspace;
   ws.counter = (unsigned*)((unsigned char*)workspace + (size_t)FIN_CHUNKS * 2 * C * sizeof(double));
-  int nchunk = rows / 64;
+  int nchunk = rows / 32;
   if (nchunk < 1) nchunk = 1;
   if (nchunk > FIN_CHUNKS) nchunk = FIN_CHUNKS;
   plyolo::annotate("bn_finalize", 0.0, 8.0 * rows * C);
@@ -339,11 +364,18 @@ int plyolo_bn_act_bwd_reduce(int dtype, int M, int C, const void* dout, int d_ld
 }
 
 int plyolo_bn_bwd_finalize(const float* partial, int rows, int C, double count, const float* gamma, const float* coef,
-                           float* dgamma, float* dbeta, int accumulate, float* bcoef, void* stream) {
+                           float* dgamma, float* dbeta, int accumulate, float* bcoef, void* workspace, size_t ws_bytes, void* stream) {
+  PLY_CHECK_ARG(workspace != nullptr && ws_bytes >= plyolo_bn_finalize_workspace(C), "bn_bwd_finalize: workspace too small");
+  FinWs ws;
+  ws.part = (double*)workspace;
+  ws.counter = (unsigned*)((unsigned char*)workspace + (size_t)FIN_CHUNKS * 2 * C * sizeof(double));
+  int nchunk = rows / 32;
+  if (nchunk < 1) nchunk = 1;
+  if (nchunk > FIN_CHUNKS) nchunk = FIN_CHUNKS;
   plyolo::annotate("bn_bwd_finalize", 0.0, 8.0 * rows * C);
   return submit(stream, [=](hipStream_t s) -> hipError_t {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, s, partial, rows, C, count, gamma, coef, dgamma, dbeta,
-                       accumulate, bcoef);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32), nchunk), dim3(256), 0, s, partial, rows, C, count, gamma, coef, dgamma,
+                       dbeta, accumulate, bcoef, ws, nchunk);
     return hipGetLastError();
   });
 }

@@ -17,6 +17,8 @@
 // The same kernel serves dgrad: stride-1 dgrad is a forward conv with the tap table
 // mirrored; stride-2 dgrad is four launches, one per output parity class, each with
 // the 1/2/2/4 taps that reach that class (so no zero-stuffing and no atomics).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -39,8 +41,17 @@ struct ConvP {
   int tiles_y, tiles_x, nmb;
   int accumulate;
   int w_ld, wtap_stride;
-  signed char tap_dy[9], tap_dx[9], tap_w[9];
+  signed char tap_dy[9], tap_dx[9], tap_w[9];  // host-side table
+  // the same table packed 8 bits per tap (dy | dx<<2 | w<<4): decoded with scalar shifts in the
+  // kernel -- indexing a kernarg ARRAY with a runtime tap index makes hipcc emit VMEM byte loads,
+  // whose s_waitcnt vmcnt(0) would also drain the in-flight weight prefetch every tap
+  unsigned long long taps_lo;
+  unsigned int taps_hi;
 };
+
+DEVINL unsigned tap_code(const ConvP& p, int t) {
+  return t < 8 ? (unsigned)((p.taps_lo >> (8 * t)) & 0xffull) : (p.taps_hi & 0xffu);
+}
 
 DEVINL u32x4 add_bf16x8(u32x4 a, u32x4 b) {
   u32x4 r;
@@ -109,7 +120,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvP p) {
   auto load_w = [&](int phase) {
     const int chunk = phase / p.ntaps, t = phase - chunk * p.ntaps;
     const int c0 = chunk * CK;
-    const bf16_t* wt = p.w + (size_t)p.tap_w[t] * p.wtap_stride;
+    const bf16_t* wt = p.w + (size_t)(tap_code(p, t) >> 4) * p.wtap_stride;
 #pragma unroll
     for (int v = 0; v < WV; ++v) {
       const int idx = tid + v * 256;
@@ -140,27 +151,48 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvP p) {
     const int c0 = chunk * CK;
     __syncthreads();  // every wave is done reading the previous chunk's halo tile
     {
+      // halo tile: issue a whole batch of 16-byte loads before the first LDS write so that
+      // HV loads per thread are in flight at once (a load->wait->write loop serialises them)
+      constexpr int HV = 6;
       const int nvec = p.ITH * p.ITW * CV;
       const bf16_t* xn = p.x + (size_t)n * p.H * p.W * p.x_ld;
-      for (int idx = tid; idx < nvec; idx += 256) {
-        const int pix = idx / CV, cv = idx - pix * CV;
-        const int iy = pix / p.ITW, ix = pix - iy * p.ITW;
-        const int gy = iy0 + iy, gx = ix0 + ix, c = c0 + cv * 8;
-        u32x4 val = {0u, 0u, 0u, 0u};
-        if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && c < p.Cin)
-          val = *(const u32x4*)(xn + ((size_t)gy * p.W + gx) * p.x_ld + c);
-        *(u32x4*)(smem + pix * ROWB + cv * 16) = val;
+      for (int base = 0; base < nvec; base += HV * 256) {
+        u32x4 hv[HV];
+#pragma unroll
+        for (int v = 0; v < HV; ++v) {
+          const int idx = base + tid + v * 256;
+          u32x4 val = {0u, 0u, 0u, 0u};
+          if (idx < nvec) {
+            const int pix = idx / CV, cv = idx - pix * CV;
+            const int iy = pix / p.ITW, ix = pix - iy * p.ITW;
+            const int gy = iy0 + iy, gx = ix0 + ix, c = c0 + cv * 8;
+            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && c < p.Cin)
+              val = *(const u32x4*)(xn + ((size_t)gy * p.W + gx) * p.x_ld + c);
+          }
+          hv[v] = val;
+        }
+#pragma unroll
+        for (int v = 0; v < HV; ++v) {
+          const int idx = base + tid + v * 256;
+          if (idx < nvec) {
+            const int pix = idx / CV, cv = idx - pix * CV;
+            *(u32x4*)(smem + pix * ROWB + cv * 16) = hv[v];
+          }
+        }
       }
     }
-    int ksteps = (p.Cin - c0 < CK ? p.Cin - c0 : CK);
-    ksteps = (ksteps + 15) >> 4;
+    // the chunk tail (Cin % CK) is zero-filled in LDS, so every chunk runs all CK/16 k-steps
+    // and the loop fully unrolls (fragment loads of step k+1 overlap the MFMAs of step k)
+    constexpr int ksteps = CK / 16;
     for (int t = 0; t < p.ntaps; ++t, ++phase) {
       const int buf = phase & 1;
       store_w(buf);
       __syncthreads();  // halo tile + this tap's weights visible
       if (phase + 1 < total) load_w(phase + 1);
-      const int toff = (p.tap_dy[t] * p.ITW + p.tap_dx[t]) * ROWB;
+      const unsigned tc = tap_code(p, t);
+      const int toff = ((int)(tc & 3u) * p.ITW + (int)((tc >> 2) & 3u)) * ROWB;
       const unsigned char* wb = wbase + buf * (BN * ROWB);
+#pragma unroll
       for (int kk = 0; kk < ksteps; ++kk) {
         bf16x8 a[MT], b[NT];
 #pragma unroll
@@ -307,11 +339,20 @@ void pick_tiles(int Cin, int Cout, int si, int ext, bool out_f32, int* BN, int* 
   if (out_f32 && bn > 64) bn = 64;
   int ck = Cin >= 64 ? 64 : (Cin >= 32 ? 32 : 16);
   if (si == 2 && ext > 1 && ck > 32) ck = 32;  // stride-2 halo tile is 17x33 pixels
+  if (const char* e = getenv("PLYOLO_FORCE_CK")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) ck = v < ck ? v : ck; }
+  if (const char* e = getenv("PLYOLO_FORCE_BN")) { const int v = atoi(e); if (v == 32 || v == 64 || v == 128) bn = v < bn ? v : bn; }
   *BN = bn;
   *CK = ck;
 }
 
 void set_grid(ConvP& p) {
+  p.taps_lo = 0ull;
+  p.taps_hi = 0u;
+  for (int t = 0; t < p.ntaps; ++t) {
+    const unsigned code = (unsigned)p.tap_dy[t] | ((unsigned)p.tap_dx[t] << 2) | ((unsigned)p.tap_w[t] << 4);
+    if (t < 8) p.taps_lo |= (unsigned long long)code << (8 * t);
+    else p.taps_hi = code;
+  }
   p.tiles_y = (p.OHt + TH - 1) / TH;
   p.tiles_x = (p.OWt + TW - 1) / TW;
   p.nmb = p.N * p.tiles_y * p.tiles_x;

@@ -74,24 +74,57 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
     const int iy0 = oy0 * p.si - p.pad, ix0 = ox0 * p.si - p.pad;
     __syncthreads();  // previous tile fully consumed
     {
+      // stage both tiles with all 16-byte loads of a batch in flight before the first LDS write
       const bf16_t* dyn = p.dy + (size_t)n * p.OH * p.OW * p.dy_ld;
-      for (int idx = tid; idx < TH * TW * DZV; idx += 256) {
-        const int m = idx / DZV, v = idx - m * DZV;
-        const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15), co = co0 + v * 8;
+      constexpr int DV = (TH * TW * DZV + 255) / 256;
+      u32x4 dv[DV];
+#pragma unroll
+      for (int v = 0; v < DV; ++v) {
+        const int idx = tid + v * 256;
         u32x4 val = {0u, 0u, 0u, 0u};
-        if (oy < p.OH && ox < p.OW && co < p.Cout) val = *(const u32x4*)(dyn + ((size_t)oy * p.OW + ox) * p.dy_ld + co);
-        *(u32x4*)(dz_s + m * DZB + v * 16) = val;
+        if (idx < TH * TW * DZV) {
+          const int m = idx / DZV, vv = idx - m * DZV;
+          const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15), co = co0 + vv * 8;
+          if (oy < p.OH && ox < p.OW && co < p.Cout) val = *(const u32x4*)(dyn + ((size_t)oy * p.OW + ox) * p.dy_ld + co);
+        }
+        dv[v] = val;
       }
       const bf16_t* xn = p.x + (size_t)n * p.H * p.W * p.x_ld;
       const int nvec = p.ITH * p.ITW * XV;
-      for (int idx = tid; idx < nvec; idx += 256) {
-        const int pix = idx / XV, v = idx - pix * XV;
-        const int iy = pix / p.ITW, ix = pix - iy * p.ITW;
-        const int gy = iy0 + iy, gx = ix0 + ix, ci = ci0 + v * 8;
-        u32x4 val = {0u, 0u, 0u, 0u};
-        if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && ci < p.Cin)
-          val = *(const u32x4*)(xn + ((size_t)gy * p.W + gx) * p.x_ld + ci);
-        *(u32x4*)(x_s + pix * XB + v * 16) = val;
+      constexpr int HV = 6;
+      for (int base = 0; base < nvec; base += HV * 256) {
+        u32x4 hv[HV];
+#pragma unroll
+        for (int v = 0; v < HV; ++v) {
+          const int idx = base + tid + v * 256;
+          u32x4 val = {0u, 0u, 0u, 0u};
+          if (idx < nvec) {
+            const int pix = idx / XV, vv = idx - pix * XV;
+            const int iy = pix / p.ITW, ix = pix - iy * p.ITW;
+            const int gy = iy0 + iy, gx = ix0 + ix, ci = ci0 + vv * 8;
+            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && ci < p.Cin)
+              val = *(const u32x4*)(xn + ((size_t)gy * p.W + gx) * p.x_ld + ci);
+          }
+          hv[v] = val;
+        }
+        if (base == 0) {
+#pragma unroll
+          for (int v = 0; v < DV; ++v) {
+            const int idx = tid + v * 256;
+            if (idx < TH * TW * DZV) {
+              const int m = idx / DZV, vv = idx - m * DZV;
+              *(u32x4*)(dz_s + m * DZB + vv * 16) = dv[v];
+            }
+          }
+        }
+#pragma unroll
+        for (int v = 0; v < HV; ++v) {
+          const int idx = base + tid + v * 256;
+          if (idx < nvec) {
+            const int pix = idx / XV, vv = idx - pix * XV;
+            *(u32x4*)(x_s + pix * XB + vv * 16) = hv[v];
+          }
+        }
       }
     }
     __syncthreads();

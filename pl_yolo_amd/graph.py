@@ -322,7 +322,8 @@ class ConvUnitOp:
         call("plyolo_bn_act_bwd_reduce", g.dtype, M, Cout, dout, self.out.ld, zt, Cout, self.coef.data_ptr(), self.act,
              self.bpartial.data_ptr(), None)
         call("plyolo_bn_bwd_finalize", self.bpartial.data_ptr(), self.brows, Cout, float(M), ptr(bn.weight),
-             self.coef.data_ptr(), g.grad_ptr_of(bn.weight), g.grad_ptr_of(bn.bias), 0, self.bcoef.data_ptr(), None)
+             self.coef.data_ptr(), g.grad_ptr_of(bn.weight), g.grad_ptr_of(bn.bias), 0, self.bcoef.data_ptr(),
+             g.fin_ws.data_ptr(), g.fin_ws.numel(), None)
         dz = g.scratch.data_ptr()
         call("plyolo_bn_act_bwd_dz", g.dtype, M, Cout, dout, self.out.ld, zt, Cout, self.coef.data_ptr(),
              self.bcoef.data_ptr(), self.act, dz, Cout, None)

@@ -252,6 +252,20 @@ class DetectorRunner:
             self.ddp.all_reduce_(self.flat["g"])
 
 
+def _publish_grads(s):
+    """The backward plan has written every parameter gradient into the runner's flat
+    buffer; expose them as `.grad` WITHOUT a copy (returning them through autograd would
+    make AccumulateGrad clone all ~240 tensors every step).  Semantics match autograd
+    for the reference's loop (optimizer.zero_grad() -> .grad is None before backward); a
+    pre-existing foreign .grad tensor is accumulated into, like autograd would."""
+    for p, gv in zip(s.used_params, s.grad_views):
+        g = p.grad
+        if g is None or g.data_ptr() == gv.data_ptr():
+            p.grad = gv
+        else:
+            g.add_(gv)
+
+
 class _TrainStep(torch.autograd.Function):
     """Whole-detector autograd node: forward replays the forward plan, backward the
     backward plan; parameter gradients are views of the runner's flat gradient buffer."""
@@ -266,7 +280,8 @@ class _TrainStep(torch.autograd.Function):
     def backward(ctx, gout):
         runner, s = ctx.runner, ctx.session
         runner.backward_train(s, gout.contiguous().float())
-        return (None, None, None) + tuple(s.grad_views)
+        _publish_grads(s)
+        return (None, None, None) + (None,) * len(s.used_params)
 
 
 class _MapsStep(torch.autograd.Function):
@@ -282,7 +297,8 @@ class _MapsStep(torch.autograd.Function):
     def backward(ctx, *grads):
         runner, s = ctx.runner, ctx.session
         runner.backward_maps(s, [g.contiguous().float() for g in grads])
-        return (None, None) + tuple(s.grad_views)
+        _publish_grads(s)
+        return (None, None) + (None,) * len(s.used_params)
 
 
 def maps_step(runner, x):

@@ -79,7 +79,7 @@ def test_bn_act_fwd_bwd(dt, act):
     dz = torch.zeros(M, Cc, dtype=hu.tdtype(dt), device=hu.DEV)
     call("plyolo_bn_act_bwd_reduce", dt, M, Cc, dm.data_ptr(), Cc + 8, zm.data_ptr(), Cc, coef.data_ptr(), hu._lib.ACT[act], part.data_ptr(), hu.stream())
     call("plyolo_bn_bwd_finalize", part.data_ptr(), brows, Cc, float(M), gamma.data_ptr(), coef.data_ptr(), dg.data_ptr(), db.data_ptr(), 0,
-         bcoef.data_ptr(), hu.stream())
+         bcoef.data_ptr(), fws.data_ptr(), wsb, hu.stream())
     call("plyolo_bn_act_bwd_dz", dt, M, Cc, dm.data_ptr(), Cc + 8, zm.data_ptr(), Cc, coef.data_ptr(), bcoef.data_ptr(), hu._lib.ACT[act],
          dz.data_ptr(), Cc, hu.stream())
     torch.cuda.synchronize()
