@@ -47,6 +47,7 @@ struct ConvP {
   // whose s_waitcnt vmcnt(0) would also drain the in-flight weight prefetch every tap
   unsigned long long taps_lo;
   unsigned int taps_hi;
+  int ablate;  // diagnostic builds only (PLYOLO_ABLATE): 1 skip stores, 2 skip stats, 4 skip halo loads, 8 skip MFMA, 16 skip weight loads
 };
 
 DEVINL unsigned tap_code(const ConvP& p, int t) {
@@ -145,12 +146,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvP p) {
     }
   };
 
+  const int abl = p.ablate;
   load_w(0);
   int phase = 0;
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     const int c0 = chunk * CK;
     __syncthreads();  // every wave is done reading the previous chunk's halo tile
-    {
+    if (!(abl & 4) || chunk == 0) {
       // halo tile: issue a whole batch of 16-byte loads before the first LDS write so that
       // HV loads per thread are in flight at once (a load->wait->write loop serialises them)
       constexpr int HV = 6;
@@ -188,10 +190,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvP p) {
       const int buf = phase & 1;
       store_w(buf);
       __syncthreads();  // halo tile + this tap's weights visible
-      if (phase + 1 < total) load_w(phase + 1);
+      if (phase + 1 < total && !(abl & 16)) load_w(phase + 1);
       const unsigned tc = tap_code(p, t);
       const int toff = ((int)(tc & 3u) * p.ITW + (int)((tc >> 2) & 3u)) * ROWB;
       const unsigned char* wb = wbase + buf * (BN * ROWB);
+      if (!(abl & 8))
 #pragma unroll
       for (int kk = 0; kk < ksteps; ++kk) {
         bf16x8 a[MT], b[NT];
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvP p) {
   constexpr int SROW = OUT_F32 ? (BN + 4) * 4 : (BN * 2 + 16);  // staging row pitch (bytes)
   float* red = (float*)(smem + BM * SROW);                       // [WM][2][BN]
 
-  if (p.stats != nullptr) {
+  if (p.stats != nullptr && !(abl & 2)) {
     float s1[NT], s2[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) s1[nt] = s2[nt] = 0.f;
@@ -256,7 +259,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvP p) {
       }
   __syncthreads();
 
-  if (p.stats != nullptr && tid < BN) {
+  if (abl & 1) return;
+  if (p.stats != nullptr && !(abl & 2) && tid < BN) {
     float s = 0.f, ss = 0.f;
 #pragma unroll
     for (int w = 0; w < WM; ++w) {
@@ -346,6 +350,7 @@ void pick_tiles(int Cin, int Cout, int si, int ext, bool out_f32, int* BN, int* 
 }
 
 void set_grid(ConvP& p) {
+  if (const char* e = getenv("PLYOLO_ABLATE")) p.ablate = atoi(e);
   p.taps_lo = 0ull;
   p.taps_hi = 0u;
   for (int t = 0; t < p.ntaps; ++t) {

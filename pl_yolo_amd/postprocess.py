@@ -1,0 +1,57 @@
+"""Eval post-processing with the reference's call signature
+(reference models/evaluators/postprocess.py:7-48):
+
+    postprocess(predictions, conf_thre=0.7, nms_thre=0.45, class_agnostic=False)
+        -> list (one entry per image) of Tensor[n, 6] (x1, y1, x2, y2, conf, cls) or None
+
+`predictions` is the [B, A, 5+C] tensor OneStageD returns in eval mode.  The whole
+batch is handled by one device launch sequence (csrc/nms.hip): class max, confidence
+filter, ordered compaction (first 10 000 in anchor order), stable score sort,
+torchvision-rule batched NMS, first 300 -- followed by ONE device->host copy of the
+per-image counts to cut the ragged result list (the reference syncs once per image).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import NmsDesc, call, PlyoloError
+
+MAX_DET = 300     # postprocess.py:8
+MAX_NMS = 10000   # postprocess.py:9
+NUMEL_THRESHOLD = 20000  # torchvision batched_nms: coordinate trick up to 20 000 box coordinates on GPU
+
+_ws_cache = {}
+
+
+def postprocess_device(predictions, conf_thre=0.7, nms_thre=0.45, class_agnostic=False):
+    """Device-resident result: (det [B, 300, 6], count int32[B]) -- no host sync."""
+    if not predictions.is_cuda:
+        raise PlyoloError("postprocess runs on an MI355X device tensor; there is no CPU path")
+    if predictions.dim() != 3 or predictions.shape[2] < 6:
+        raise PlyoloError("predictions must be [B, A, 5+C]")
+    p = predictions.contiguous().float()
+    B, A, nch = p.shape
+    d = NmsDesc()
+    d.B, d.A, d.C, d.conf_thre, d.nms_thre, d.class_agnostic = B, A, nch - 5, float(conf_thre), float(nms_thre), int(bool(class_agnostic))
+    d.max_nms, d.max_det, d.numel_threshold = MAX_NMS, MAX_DET, NUMEL_THRESHOLD
+    key = (B, A, nch, p.device)
+    ws = _ws_cache.get(key)
+    if ws is None:
+        nbytes = _lib.lib().plyolo_postprocess_workspace(C.byref(d))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=p.device)
+        _ws_cache.clear()
+        _ws_cache[key] = ws
+    det = torch.empty(B, MAX_DET, 6, dtype=torch.float32, device=p.device)
+    count = torch.empty(B, dtype=torch.int32, device=p.device)
+    call("plyolo_postprocess", C.byref(d), p.data_ptr(), det.data_ptr(), count.data_ptr(), None, ws.data_ptr(), ws.numel(),
+         torch.cuda.current_stream().cuda_stream)
+    return det, count
+
+
+def postprocess(predictions, conf_thre=0.7, nms_thre=0.45, class_agnostic=False):
+    if predictions.shape[0] == 0:
+        return []
+    det, count = postprocess_device(predictions, conf_thre, nms_thre, class_agnostic)
+    counts = count.tolist()  # the only host sync
+    return [det[i, :n] if n > 0 else None for i, n in enumerate(counts)]
