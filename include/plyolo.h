@@ -86,6 +86,32 @@ typedef struct plyolo_conv_desc {
 int plyolo_conv2d_fwd(const plyolo_conv_desc* d, const void* x, const void* wp, const float* bias,
                       void* y, float* stats, void* stream);
 int plyolo_conv2d_stat_rows(const plyolo_conv_desc* d);
+/* Forward conv with the train-mode BatchNorm statistics FINISHED inside the launch
+ * (BaseConv = conv -> bn -> act, network_blocks.py:30-37): every workgroup writes its partial
+ * row, the last workgroup of each group of 32 rows sums the group, the last group sums the
+ * groups (fixed order => bit-reproducible) and produces coef[4C] = (scale, shift, mean,
+ * invstd) + the running statistics -- no separate finalize launch.
+ *   rows   fp32 [2][plyolo_conv2d_stat_rows(d)][Cout]   (scratch, may be shared between layers)
+ *   gpart  fp32 [2][ceil(rows/32)][Cout]                (scratch, shareable)
+ *   gcnt   u32  [ceil(Cout/32)][ceil(rows/32)], fcnt u32 [ceil(Cout/32)]: zeroed ONCE by the
+ *          caller, self-resetting, shareable between layers that run on one stream.
+ * bf16 path only. */
+typedef struct plyolo_bn_fuse {
+  const float* gamma;
+  const float* beta;
+  float* running_mean;
+  float* running_var;
+  int64_t* num_batches_tracked;
+  float* coef;
+  float* rows;
+  float* gpart;
+  unsigned int* gcnt;
+  unsigned int* fcnt;
+  double count;       /* N*OH*OW */
+  float eps, momentum;
+} plyolo_bn_fuse;
+int plyolo_conv2d_fwd_bn(const plyolo_conv_desc* d, const void* x, const void* wp, void* y,
+                         const plyolo_bn_fuse* bn, void* stream);
 /* dx = conv_transpose(dy, w).  wpd: packed dgrad weights.  accumulate!=0: dx += */
 int plyolo_conv2d_dgrad(const plyolo_conv_desc* d, const void* dy, const void* wpd, void* dx,
                         int accumulate, void* stream);
@@ -141,6 +167,13 @@ int plyolo_bn_act_fwd(int dtype, int M, int C, const void* z, int z_ld, const fl
 int plyolo_bn_bwd_rows(int M);
 int plyolo_bn_act_bwd_reduce(int dtype, int M, int C, const void* dout, int d_ld, const void* z, int z_ld,
                              const float* coef, int act, float* partial, void* stream);
+/* bn_act_bwd_reduce with the finish fused in (same hierarchical last-arriver reduction as
+ * plyolo_conv2d_fwd_bn): writes dgamma, dbeta and bcoef.  partial: fp32 [2][rows][C] scratch;
+ * gpart fp32 [2][ceil(rows/32)][C]; gcnt u32 [ceil(rows/32)], fcnt u32 [1] zeroed once. */
+int plyolo_bn_act_bwd_reduce_fin(int dtype, int M, int C, const void* dout, int d_ld, const void* z, int z_ld,
+                                 const float* coef, int act, const float* gamma, float* dgamma, float* dbeta,
+                                 float* bcoef, float* partial, float* gpart, unsigned int* gcnt,
+                                 unsigned int* fcnt, void* stream);
 /* dgamma/dbeta (+)=; bcoef[0:C]=A, [C:2C]=B, [2C:3C]=Cc so that dz = A*du + B*z + Cc */
 int plyolo_bn_bwd_finalize(const float* partial, int rows, int C, double count, const float* gamma,
                            const float* coef, float* dgamma, float* dbeta, int accumulate, float* bcoef,

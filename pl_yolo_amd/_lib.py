@@ -22,6 +22,14 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("dtype", "N", "H", "W", "Cin", "Cout", "ksize", "stride", "x_ld", "y_ld", "y_f32")]
 
 
+HIER_GROUP = 32  # rows per group of the in-kernel hierarchical reduction
+
+
+class BnFuse(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("gamma", "beta", "running_mean", "running_var", "num_batches_tracked", "coef", "rows", "gpart", "gcnt", "fcnt")] + [
+        ("count", C.c_double), ("eps", C.c_float), ("momentum", C.c_float)]
+
+
 class PackEntry(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("w", "wp", "wpd", "dwp", "dw", "b", "bp", "dbp", "db")] + [
         (n, C.c_int) for n in ("Cout", "Cin", "Cin_p", "ksize", "Cout_total", "Cout_p8", "co_off", "pad_")
@@ -63,6 +71,8 @@ SIGNATURES = {
     "plyolo_plan_op_info": (_i, [_vp, _i, C.c_char_p, _i, _P(_d), _P(_d)]),
     "plyolo_conv2d_fwd": (_i, [_P(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
     "plyolo_conv2d_stat_rows": (_i, [_P(ConvDesc)]),
+    "plyolo_conv2d_fwd_bn": (_i, [_P(ConvDesc), _vp, _vp, _vp, _P(BnFuse), _vp]),
+    "plyolo_bn_act_bwd_reduce_fin": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "plyolo_conv2d_dgrad": (_i, [_P(ConvDesc), _vp, _vp, _vp, _i, _vp]),
     "plyolo_conv2d_wgrad": (_i, [_P(ConvDesc), _vp, _vp, _vp, _vp]),
     "plyolo_bias_grad": (_i, [_i, _vp, _i, _i, _i, _vp, _vp]),

@@ -47,6 +47,7 @@ struct ConvP {
   // whose s_waitcnt vmcnt(0) would also drain the in-flight weight prefetch every tap
   unsigned long long taps_lo;
   unsigned int taps_hi;
+  plyolo_bn_fuse fin;  // fin.coef != NULL: BatchNorm statistics are finished inside this launch
   int ablate;  // diagnostic builds only (PLYOLO_ABLATE): 1 skip stores, 2 skip stats, 4 skip halo loads, 8 skip MFMA, 16 skip weight loads
 };
 
@@ -269,9 +270,45 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvP p) {
     }
     const int co = cout0 + tid;
     if (co < p.Cout) {
-      p.stats[(size_t)tile * p.Cout + co] = s;
-      p.stats[((size_t)p.nmb + tile) * p.Cout + co] = ss;
+      if (p.fin.coef != nullptr) {  // handed to another workgroup inside this launch: write-through
+        hier_store(p.stats + (size_t)tile * p.Cout + co, s);
+        hier_store(p.stats + ((size_t)p.nmb + tile) * p.Cout + co, ss);
+      } else {
+        p.stats[(size_t)tile * p.Cout + co] = s;
+        p.stats[((size_t)p.nmb + tile) * p.Cout + co] = ss;
+      }
     }
+  }
+
+  if (p.fin.coef != nullptr) {
+    // ---- BatchNorm finish inside the launch (before the bulk output stores, so the drain in
+    // hier_finish only waits for the two row stores): hierarchical last-arriver reduction of
+    // the per-workgroup partial rows, then coef / running statistics
+    __shared__ int s_flag;
+    HierRed h;
+    h.rows = p.stats; h.gpart = p.fin.gpart; h.gcnt = p.fin.gcnt; h.fcnt = p.fin.fcnt; h.nrows = p.nmb; h.C = p.Cout;
+    hier_finish(h, tile, (int)blockIdx.y, cout0, BN, &s_flag, [&](int co, double s, double ss) {
+      const double count = p.fin.count;
+      const double mean = s / count;
+      double var = ss / count - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const float invstd = (float)(1.0 / sqrt(var + (double)p.fin.eps));
+      const float g = p.fin.gamma ? p.fin.gamma[co] : 1.f, b = p.fin.beta ? p.fin.beta[co] : 0.f;
+      const float scale = g * invstd;
+      float* coef = p.fin.coef;
+      coef[co] = scale;
+      coef[p.Cout + co] = b - (float)mean * scale;
+      coef[2 * p.Cout + co] = (float)mean;
+      coef[3 * p.Cout + co] = invstd;
+      const float mom = p.fin.momentum;
+      if (p.fin.running_mean) p.fin.running_mean[co] = (1.f - mom) * p.fin.running_mean[co] + mom * (float)mean;
+      if (p.fin.running_var) {
+        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        p.fin.running_var[co] = (1.f - mom) * p.fin.running_var[co] + mom * (float)unb;
+      }
+      if (co == 0 && p.fin.num_batches_tracked) *p.fin.num_batches_tracked += 1;
+    });
+    __syncthreads();  // s_flag readers are done before the staging tile is consumed below
   }
 
   if (OUT_F32) {
@@ -303,6 +340,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvP p) {
       }
     }
   }
+
 }
 
 template <int BN, int CK, bool OUT_F32>
@@ -379,7 +417,7 @@ int conv_mfma_stat_rows(const plyolo_conv_desc* d) {
 }
 
 int conv_mfma_fwd(const plyolo_conv_desc* d, const void* x, const void* wp, const float* bias, void* y,
-                  float* stats, void* stream) {
+                  float* stats, const plyolo_bn_fuse* fin, void* stream) {
   const int pad = (d->ksize - 1) / 2;
   ConvP p{};
   p.x = (const bf16_t*)x;
@@ -387,6 +425,7 @@ int conv_mfma_fwd(const plyolo_conv_desc* d, const void* x, const void* wp, cons
   p.y = y;
   p.bias = bias;
   p.stats = stats;
+  if (fin) { p.fin = *fin; p.stats = fin->rows; }
   p.N = d->N; p.H = d->H; p.W = d->W;
   p.Cin = d->Cin; p.Cout = d->Cout; p.x_ld = d->x_ld; p.y_ld = d->y_ld;
   p.OHf = (d->H + 2 * pad - d->ksize) / d->stride + 1;

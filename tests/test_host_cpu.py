@@ -82,7 +82,7 @@ def test_plan_recording_dry_run(dtype):
     dev = torch.device("cpu")
     r.adopt(dev)
     s = r._build(2, 64, 64, 8, "train", dev)
-    assert s.fwd.size() > 150 and s.bwd.size() > 250
+    assert s.fwd.size() > 100 and s.bwd.size() > 200
     assert not [op for op in s.g.ops if isinstance(op, G.CopyOp)], "a concat fell back to a copy"
     n_params = len(list(model.parameters()))
     assert len(s.used_params) == n_params - 16  # all but the dead Bottleneck.bn pairs (network_blocks.py:81)
