@@ -115,7 +115,12 @@ int plyolo_conv2d_fwd_bn(const plyolo_conv_desc* d, const void* x, const void* w
 /* dx = conv_transpose(dy, w).  wpd: packed dgrad weights.  accumulate!=0: dx += */
 int plyolo_conv2d_dgrad(const plyolo_conv_desc* d, const void* dy, const void* wpd, void* dx,
                         int accumulate, void* stream);
-/* dwp[tap][Cout][Cin] (fp32) += sum_pixels dy (x) x.  The caller zeroes dwp. */
+/* Weight gradient, written as plyolo_conv2d_wgrad_slabs(d) partial slabs
+ * dwp[slab][tap][Cout][Cin] (fp32): slab s holds the contribution of one spatial split.
+ * plyolo_unpack_wgrads sums the slabs in a fixed order (deterministic; no fp32 atomics).
+ * bf16 path: every slab element is overwritten (no zero-fill needed).  fp32 parity path:
+ * one slab, accumulated with atomics -> the caller zeroes it first. */
+int plyolo_conv2d_wgrad_slabs(const plyolo_conv_desc* d);
 int plyolo_conv2d_wgrad(const plyolo_conv_desc* d, const void* x, const void* dy, float* dwp, void* stream);
 /* dbias[co] = sum over pixels of dy[m][co] (head prediction convs, decoupled_head.py:43-62). */
 int plyolo_bias_grad(int dtype, const void* dy, int M, int C, int ld, float* dbias, void* stream);
@@ -126,7 +131,7 @@ typedef struct plyolo_pack_entry {
   const float* w;   /* OIHW fp32 master weights (torch layout), [Cout][Cin][k][k] */
   void* wp;         /* [tap][Cout_total][Cin_p] fwd pack (bf16 or fp32) */
   void* wpd;        /* [tap][Cin_p][Cout_p8] dgrad pack, or NULL */
-  float* dwp;       /* [tap][Cout_total][Cin_p] fp32 wgrad accumulator (unpack source) */
+  float* dwp;       /* [nslab][tap][Cout_total][Cin_p] fp32 wgrad slabs (unpack source) */
   float* dw;        /* OIHW fp32 gradient (unpack destination), or NULL */
   const float* b;   /* fp32 bias [Cout] or NULL */
   float* bp;        /* packed bias [Cout_total] */
@@ -137,7 +142,7 @@ typedef struct plyolo_pack_entry {
                        packed conv: reg_preds(4)+obj_preds(1), decoupled_head.py:55-62) */
   int Cout_p8;      /* Cout_total rounded up to 8 (dgrad contraction length) */
   int co_off;       /* first packed row of this entry */
-  int pad_;
+  int nslab;        /* number of wgrad slabs to sum in unpack (>= 1) */
 } plyolo_pack_entry;
 int plyolo_pack_weights(const plyolo_pack_entry* table_dev, int n, int dtype, int max_elems, void* stream);
 /* dw (OIHW) (+)= permute(dwp) for the whole table. */

@@ -40,6 +40,7 @@ int conv_mfma_stat_rows(const plyolo_conv_desc* d);
 int conv_mfma_fwd(const plyolo_conv_desc*, const void*, const void*, const float*, void*, float*, const plyolo_bn_fuse*, void*);
 int conv_mfma_dgrad(const plyolo_conv_desc*, const void*, const void*, void*, int, void*);
 int conv_mfma_wgrad(const plyolo_conv_desc*, const void*, const void*, float*, void*);
+int conv_mfma_wgrad_slabs(const plyolo_conv_desc*);
 int conv_ref_stat_rows(const plyolo_conv_desc* d);
 int conv_ref_fwd(const plyolo_conv_desc*, const void*, const void*, const float*, void*, float*, void*);
 int conv_ref_dgrad(const plyolo_conv_desc*, const void*, const void*, void*, int, void*);
@@ -179,6 +180,10 @@ int plyolo_conv2d_fwd_bn(const plyolo_conv_desc* d, const void* x, const void* w
 int plyolo_conv2d_dgrad(const plyolo_conv_desc* d, const void* dy, const void* wpd, void* dx, int accumulate, void* stream) {
   if (check_conv(d, "conv2d_dgrad", false)) return -1;
   return d->dtype == PLYOLO_BF16 ? conv_mfma_dgrad(d, dy, wpd, dx, accumulate, stream) : conv_ref_dgrad(d, dy, wpd, dx, accumulate, stream);
+}
+int plyolo_conv2d_wgrad_slabs(const plyolo_conv_desc* d) {
+  if (check_conv(d, "conv2d_wgrad_slabs", false)) return -1;
+  return d->dtype == PLYOLO_BF16 ? conv_mfma_wgrad_slabs(d) : 1;
 }
 int plyolo_conv2d_wgrad(const plyolo_conv_desc* d, const void* x, const void* dy, float* dwp, void* stream) {
   if (check_conv(d, "conv2d_wgrad", false)) return -1;

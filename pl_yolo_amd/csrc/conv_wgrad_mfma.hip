@@ -14,6 +14,8 @@
 // tiles: per tile the dY tile and the X halo tile are staged once in LDS and used
 // for 8 k-steps x ntaps MFMAs.  Partial slabs from the spatial splits are combined
 // with fp32 atomics shaped as full 128-byte row segments.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -28,6 +30,7 @@ struct WgP {
   int si, pad, ITH, ITW;
   int tiles_y, tiles_x, ntiles;
   int nci;  // number of ci tiles (blockIdx.y = co_tile * nci + ci_tile)
+  int ablate;  // diagnostics (PLYOLO_ABLATE_WG): 1 skip atomics, 2 skip tile loads after the first, 4 skip MFMA, 8 force S
 };
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -38,137 +41,164 @@ DEVINL s16x4 tr_read(const unsigned char* p) {
 
 constexpr int pitch_for(int ch) { return ch * 2 + ((ch * 2) % 128 == 0 ? 64 : 0); }
 
-template <int CO_T, int CI_T, int KS>
+// CO_T x CI_T: dW slab of the workgroup; MTC x MTI: 32x32 MFMA tiles per wave along co / ci;
+// WK: waves that split the k-steps (tile rows) of one slab (small-channel layers); TH_: tile rows.
+template <int CO_T, int CI_T, int KS, int WK, int MTC, int MTI, int TH_, int SI>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
   constexpr int NTAPS = KS * KS;
-  constexpr int WCI = CI_T / 32;
+  constexpr int WCO = CO_T / (32 * MTC), WCI = CI_T / (32 * MTI);
+  static_assert(WCO * WCI * WK == 4, "four waves per workgroup");
   constexpr int DZB = pitch_for(CO_T), XB = pitch_for(CI_T);
   constexpr int DZV = CO_T / 8, XV = CI_T / 8;
   extern __shared__ __align__(16) unsigned char smem[];
   unsigned char* dz_s = smem;
-  unsigned char* x_s = smem + TH * TW * DZB;
+  unsigned char* x_s = smem + TH_ * TW * DZB;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wco = wave / WCI, wci = wave % WCI;
+  const int wk = wave / (WCO * WCI), wco = (wave / WCI) % WCO, wci = wave % WCI;
   const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
   const int co_tile = blockIdx.y / p.nci, ci_tile = blockIdx.y % p.nci;
   const int co0 = co_tile * CO_T, ci0 = ci_tile * CI_T;
 
   // per-lane tr-read address pieces: pixel column within the 16-wide k-step, channel column
   const int kpix = 8 * (g >> 1) + q;                 // + 4 for the second read
-  const int a_col = (wco * 32 + 16 * (g & 1) + 4 * pp) * 2;
-  const int b_col = (wci * 32 + 16 * (g & 1) + 4 * pp) * 2;
+  const int a_col = (wco * 32 * MTC + 16 * (g & 1) + 4 * pp) * 2;
+  const int b_col = (wci * 32 * MTI + 16 * (g & 1) + 4 * pp) * 2;
 
-  f32x16 acc[NTAPS];
+  f32x16 acc[NTAPS][MTC][MTI];
 #pragma unroll
   for (int t = 0; t < NTAPS; ++t)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    for (int a = 0; a < MTC; ++a)
+#pragma unroll
+      for (int b = 0; b < MTI; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][a][b][i] = 0.f;
 
-  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+  // Software pipeline over the workgroup's tiles: the 16-byte global loads of tile i+1 are issued
+  // into registers before the MFMAs of tile i and written to LDS after them.
+  constexpr int ITH_ = (TH_ - 1) * SI + KS, ITW_ = (TW - 1) * SI + KS;
+  constexpr int DV = (TH_ * TW * DZV + 255) / 256;
+  constexpr int NXV = ITH_ * ITW_ * XV;
+  constexpr int HV = (NXV + 255) / 256;
+  u32x4 dv[DV], hv[HV];
+  auto prefetch = [&](int tile) {
     const int txi = tile % p.tiles_x;
     const int t2 = tile / p.tiles_x;
     const int tyi = t2 % p.tiles_y;
     const int n = t2 / p.tiles_y;
-    const int oy0 = tyi * TH, ox0 = txi * TW;
-    const int iy0 = oy0 * p.si - p.pad, ix0 = ox0 * p.si - p.pad;
-    __syncthreads();  // previous tile fully consumed
-    {
-      // stage both tiles with all 16-byte loads of a batch in flight before the first LDS write
-      const bf16_t* dyn = p.dy + (size_t)n * p.OH * p.OW * p.dy_ld;
-      constexpr int DV = (TH * TW * DZV + 255) / 256;
-      u32x4 dv[DV];
+    const int oy0 = tyi * TH_, ox0 = txi * TW;
+    const int iy0 = oy0 * SI - p.pad, ix0 = ox0 * SI - p.pad;
+    const bf16_t* dyn = p.dy + (size_t)n * p.OH * p.OW * p.dy_ld;
 #pragma unroll
-      for (int v = 0; v < DV; ++v) {
-        const int idx = tid + v * 256;
-        u32x4 val = {0u, 0u, 0u, 0u};
-        if (idx < TH * TW * DZV) {
-          const int m = idx / DZV, vv = idx - m * DZV;
-          const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15), co = co0 + vv * 8;
-          if (oy < p.OH && ox < p.OW && co < p.Cout) val = *(const u32x4*)(dyn + ((size_t)oy * p.OW + ox) * p.dy_ld + co);
-        }
-        dv[v] = val;
+    for (int v = 0; v < DV; ++v) {
+      const int idx = tid + v * 256;
+      u32x4 val = {0u, 0u, 0u, 0u};
+      if (idx < TH_ * TW * DZV) {
+        const int m = idx / DZV, vv = idx - m * DZV;
+        const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15), co = co0 + vv * 8;
+        if (oy < p.OH && ox < p.OW && co < p.Cout) val = *(const u32x4*)(dyn + ((size_t)oy * p.OW + ox) * p.dy_ld + co);
       }
-      const bf16_t* xn = p.x + (size_t)n * p.H * p.W * p.x_ld;
-      const int nvec = p.ITH * p.ITW * XV;
-      constexpr int HV = 6;
-      for (int base = 0; base < nvec; base += HV * 256) {
-        u32x4 hv[HV];
+      dv[v] = val;
+    }
+    const bf16_t* xn = p.x + (size_t)n * p.H * p.W * p.x_ld;
 #pragma unroll
-        for (int v = 0; v < HV; ++v) {
-          const int idx = base + tid + v * 256;
-          u32x4 val = {0u, 0u, 0u, 0u};
-          if (idx < nvec) {
-            const int pix = idx / XV, vv = idx - pix * XV;
-            const int iy = pix / p.ITW, ix = pix - iy * p.ITW;
-            const int gy = iy0 + iy, gx = ix0 + ix, ci = ci0 + vv * 8;
-            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && ci < p.Cin)
-              val = *(const u32x4*)(xn + ((size_t)gy * p.W + gx) * p.x_ld + ci);
-          }
-          hv[v] = val;
-        }
-        if (base == 0) {
+    for (int v = 0; v < HV; ++v) {
+      const int idx = tid + v * 256;
+      u32x4 val = {0u, 0u, 0u, 0u};
+      if (idx < NXV) {
+        const int pix = idx / XV, vv = idx - pix * XV;
+        const int iy = pix / ITW_, ix = pix - iy * ITW_;
+        const int gy = iy0 + iy, gx = ix0 + ix, ci = ci0 + vv * 8;
+        if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && ci < p.Cin)
+          val = *(const u32x4*)(xn + ((size_t)gy * p.W + gx) * p.x_ld + ci);
+      }
+      hv[v] = val;
+    }
+  };
+  auto commit = [&]() {
 #pragma unroll
-          for (int v = 0; v < DV; ++v) {
-            const int idx = tid + v * 256;
-            if (idx < TH * TW * DZV) {
-              const int m = idx / DZV, vv = idx - m * DZV;
-              *(u32x4*)(dz_s + m * DZB + vv * 16) = dv[v];
-            }
-          }
-        }
-#pragma unroll
-        for (int v = 0; v < HV; ++v) {
-          const int idx = base + tid + v * 256;
-          if (idx < nvec) {
-            const int pix = idx / XV, vv = idx - pix * XV;
-            *(u32x4*)(x_s + pix * XB + vv * 16) = hv[v];
-          }
-        }
+    for (int v = 0; v < DV; ++v) {
+      const int idx = tid + v * 256;
+      if (idx < TH_ * TW * DZV) {
+        const int m = idx / DZV, vv = idx - m * DZV;
+        *(u32x4*)(dz_s + m * DZB + vv * 16) = dv[v];
       }
     }
+#pragma unroll
+    for (int v = 0; v < HV; ++v) {
+      const int idx = tid + v * 256;
+      if (idx < NXV) {
+        const int pix = idx / XV, vv = idx - pix * XV;
+        *(u32x4*)(x_s + pix * XB + vv * 16) = hv[v];
+      }
+    }
+  };
+
+  if ((int)blockIdx.x < p.ntiles) prefetch(blockIdx.x);
+  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    __syncthreads();  // previous tile fully consumed
+    commit();
     __syncthreads();
+    if (tile + (int)gridDim.x < p.ntiles && !(p.ablate & 2)) prefetch(tile + gridDim.x);
+    if (!(p.ablate & 4))
 #pragma unroll 2
-    for (int j = 0; j < TH; ++j) {
-      // A = dY^T fragment: A[row = co][k = pixel (j, 8h..8h+7)]
-      s16x8 af;
-      {
-        const unsigned char* ap = dz_s + (j * TW + kpix) * DZB + a_col;
+    for (int j = wk; j < TH_; j += WK) {
+      // A = dY^T fragments: A[row = co][k = pixel (j, 8h..8h+7)]
+      s16x8 af[MTC];
+#pragma unroll
+      for (int a = 0; a < MTC; ++a) {
+        const unsigned char* ap = dz_s + (j * TW + kpix) * DZB + a_col + a * 64;
         const s16x4 lo = tr_read(ap);
         const s16x4 hi = tr_read(ap + 4 * DZB);
-        af = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        af[a] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
       }
 #pragma unroll
       for (int t = 0; t < NTAPS; ++t) {
         const int dy_ = t / KS, dx_ = t % KS;
-        const unsigned char* bp = x_s + ((j * p.si + dy_) * p.ITW + kpix * p.si + dx_) * XB + b_col;
-        const s16x4 lo = tr_read(bp);
-        const s16x4 hi = tr_read(bp + 4 * p.si * XB);
-        const s16x8 bfv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&af, *(const bf16x8*)&bfv, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int b = 0; b < MTI; ++b) {
+          const unsigned char* bp = x_s + ((j * SI + dy_) * ITW_ + kpix * SI + dx_) * XB + b_col + b * 64;
+          const s16x4 lo = tr_read(bp);
+          const s16x4 hi = tr_read(bp + 4 * SI * XB);
+          const s16x8 bfv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+          for (int a = 0; a < MTC; ++a)
+            acc[t][a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&af[a], *(const bf16x8*)&bfv, acc[t][a][b], 0, 0, 0);
+        }
       }
     }
   }
 
-  // D[row = co][col = ci]: col = lane & 31, row = (i&3) + 8*(i>>2) + 4*(lane>>5)
+  if (p.ablate & 1) { if (acc[0][0][0][0] == 123.456f) p.dw[0] = 1.f; return; }
+  // Each (spatial split, k-split wave) owns a private slab [tap][Cout][Cin]: plain 128-byte row
+  // stores (D[row = co][col = ci]: col = lane & 31, row = (i&3) + 8*(i>>2) + 4*(lane>>5)); the
+  // slabs are summed in a fixed order by plyolo_unpack_wgrads (deterministic, and no fp32
+  // atomics: same-address atomics serialise at ~1.6 us each on gfx950).
+  float* slab = p.dw + ((size_t)blockIdx.x * WK + wk) * ((size_t)NTAPS * p.Cout * p.Cin);
   const int r = lane & 31, h = lane >> 5;
-  const int ci = ci0 + wci * 32 + r;
-  if (ci < p.Cin) {
 #pragma unroll
-    for (int t = 0; t < NTAPS; ++t)
+  for (int b = 0; b < MTI; ++b) {
+    const int ci = ci0 + (wci * MTI + b) * 32 + r;
+    if (ci < p.Cin) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int co = co0 + wco * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        if (co < p.Cout) atomicAdd(p.dw + ((size_t)t * p.Cout + co) * p.Cin + ci, acc[t][i]);
-      }
+      for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+        for (int a = 0; a < MTC; ++a)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int co = co0 + (wco * MTC + a) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (co < p.Cout) slab[((size_t)t * p.Cout + co) * p.Cin + ci] = acc[t][a][b][i];
+          }
+    }
   }
 }
 
-template <int CO_T, int CI_T, int KS>
+template <int CO_T, int CI_T, int KS, int WK, int MTC, int MTI, int TH_, int SI>
 hipError_t launch_wg(const WgP& p, int S, hipStream_t s) {
   constexpr int DZB = pitch_for(CO_T), XB = pitch_for(CI_T);
-  const size_t lds = (size_t)TH * TW * DZB + (size_t)p.ITH * p.ITW * XB;
-  auto kern = conv_wgrad_kernel<CO_T, CI_T, KS>;
+  const size_t lds = (size_t)TH_ * TW * DZB + (size_t)((TH_ - 1) * SI + KS) * ((TW - 1) * SI + KS) * XB;
+  auto kern = conv_wgrad_kernel<CO_T, CI_T, KS, WK, MTC, MTI, TH_, SI>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -185,12 +215,12 @@ hipError_t launch_wg(const WgP& p, int S, hipStream_t s) {
 
 namespace plyolo {
 
-int conv_mfma_wgrad(const plyolo_conv_desc* d, const void* x, const void* dy, float* dwp, void* stream) {
+struct WgPlan { WgP p; int id, S, WK, CO_T, CI_T; };
+
+static WgPlan plan_wgrad(const plyolo_conv_desc* d) {
   const int pad = (d->ksize - 1) / 2;
-  WgP p{};
-  p.x = (const bf16_t*)x;
-  p.dy = (const bf16_t*)dy;
-  p.dw = dwp;
+  WgPlan w{};
+  WgP& p = w.p;
   p.N = d->N; p.H = d->H; p.W = d->W;
   p.OH = (d->H + 2 * pad - d->ksize) / d->stride + 1;
   p.OW = (d->W + 2 * pad - d->ksize) / d->stride + 1;
@@ -201,36 +231,77 @@ int conv_mfma_wgrad(const plyolo_conv_desc* d, const void* x, const void* dy, fl
     const int rows = (int)((size_t)d->N * d->H * d->W / TW);
     p.N = 1; p.H = rows; p.W = TW; p.OH = rows; p.OW = TW;
   }
-  p.ITH = (TH - 1) * p.si + d->ksize;
+  // ---- variant selection (slab shape, waves splitting k, tile rows)
+  //  id 0: 3x3  64x64 slab                      (Cin >= 64, stride 1)
+  //  id 1: 3x3 128x32 slab                      (stride 2 or Cin <= 32, Cout > 64): small halo tile
+  //  id 2: 3x3  64x32 slab, 2 waves split k     (Cout <= 64, Cin <= 32 or stride 2)
+  //  id 3: 3x3  32x32 slab, 4 waves split k     (Cout <= 32, Cin <= 32)
+  //  id 4: 1x1  64x64 slab
+  //  id 5: 1x1 128x128 slab, 64-pixel tiles     (both operands read once)
+  const int true_cout = d->Cout;
+  int th = TH;
+  w.WK = 1;
+  if (d->ksize == 3) {
+    const bool narrow = d->stride == 2 || d->Cin <= 32;
+    if (!narrow) { w.id = 0; w.CO_T = 64; w.CI_T = 64; }  // stride 1 only
+    else if (true_cout <= 32 && d->Cin <= 32) { w.id = 3; w.CO_T = 32; w.CI_T = 32; w.WK = 4; }
+    else if (true_cout <= 64) { w.id = 2; w.CO_T = 64; w.CI_T = 32; w.WK = 2; }
+    else { w.id = 1; w.CO_T = 128; w.CI_T = 32; }
+  } else {
+    if (true_cout >= 128 && d->Cin >= 128 && d->stride == 1) { w.id = 5; w.CO_T = 128; w.CI_T = 128; th = 4; }
+    else { w.id = 4; w.CO_T = 64; w.CI_T = 64; }
+  }
+  p.ITH = (th - 1) * p.si + d->ksize;
   p.ITW = (TW - 1) * p.si + d->ksize;
-  p.tiles_y = (p.OH + TH - 1) / TH;
+  p.tiles_y = (p.OH + th - 1) / th;
   p.tiles_x = (p.OW + TW - 1) / TW;
   p.ntiles = p.N * p.tiles_y * p.tiles_x;
-  // NOTE: dwp is [tap][Cout][Cin] with the TRUE Cout of the conv; rows >= Cout never get written
-  const int true_cout = d->Cout;
-  const bool wide = (d->stride == 2 && d->ksize == 3) || d->Cin <= 32;  // 128x32 slab keeps the s2 halo tile small
-  const int CO_T = wide ? 128 : 64, CI_T = wide ? 32 : 64;
-  p.nci = (p.Cin + CI_T - 1) / CI_T;
-  const int nco = (p.Cout + CO_T - 1) / CO_T;
-  // spatial split: enough workgroups to cover the chip several times over, but the fp32
-  // atomic combine moves S * |dW| bytes at ~1.3 TB/s chip-wide, so cap it at ~24 MB
+  p.nci = (p.Cin + w.CI_T - 1) / w.CI_T;
+  const int nco = (p.Cout + w.CO_T - 1) / w.CO_T;
+  // spatial split: a few workgroups per CU; every split writes a private fp32 slab (S*WK*|dW|
+  // bytes stored once and read once by the unpack pass), capped at ~32 MB and 256 slabs per layer
   const double dw_bytes = 4.0 * d->ksize * d->ksize * (double)d->Cout * d->Cin;
-  int S = 2048 / (nco * p.nci);
-  const int s_budget = (int)(24.0e6 / dw_bytes);
+  int S = 768 / (nco * p.nci * w.WK);
+  if (S * w.WK > 256) S = 256 / w.WK;
+  const int s_budget = (int)(32.0e6 / (dw_bytes * w.WK));
   if (S > s_budget) S = s_budget;
   if (S < 1) S = 1;
   if (S > p.ntiles) S = p.ntiles;
-  p.Cout = true_cout;
-  const int ks = d->ksize;
+  if (const char* e = getenv("PLYOLO_WG_S")) { const int v = atoi(e); if (v > 0) S = v < p.ntiles ? v : p.ntiles; }
+  if (const char* e = getenv("PLYOLO_ABLATE_WG")) p.ablate = atoi(e);
+  p.Cout = true_cout;  // slabs are [tap][Cout][Cin] with the TRUE Cout
+  w.S = S;
+  return w;
+}
+
+int conv_mfma_wgrad_slabs(const plyolo_conv_desc* d) {
+  const WgPlan w = plan_wgrad(d);
+  return w.S * w.WK;
+}
+
+int conv_mfma_wgrad(const plyolo_conv_desc* d, const void* x, const void* dy, float* dwp, void* stream) {
+  WgPlan w = plan_wgrad(d);
+  WgP p = w.p;
+  p.x = (const bf16_t*)x;
+  p.dy = (const bf16_t*)dy;
+  p.dw = dwp;
+  const int id = w.id, S = w.S, ks = d->ksize;
   {
     char lab[64];
-    snprintf(lab, sizeof(lab), "conv_wgrad<%dx%d,k%d>", CO_T, CI_T, ks);
+    snprintf(lab, sizeof(lab), "conv_wgrad<%dx%d,k%d>", w.CO_T, w.CI_T, ks);
     const double Mo = (double)p.N * p.OH * p.OW, Mi = (double)p.N * p.H * p.W;
     annotate(lab, 2.0 * Mo * d->Cout * d->Cin * ks * ks, (Mo * d->Cout + Mi * d->Cin) * 2.0 + 4.0 * ks * ks * d->Cout * d->Cin);
   }
   return submit(stream, [=](hipStream_t s) -> hipError_t {
-    if (wide) return ks == 3 ? launch_wg<128, 32, 3>(p, S, s) : launch_wg<128, 32, 1>(p, S, s);
-    return ks == 3 ? launch_wg<64, 64, 3>(p, S, s) : launch_wg<64, 64, 1>(p, S, s);
+    const bool s2 = p.si == 2;
+    switch (id) {
+      case 0: return launch_wg<64, 64, 3, 1, 1, 1, 8, 1>(p, S, s);
+      case 1: return s2 ? launch_wg<128, 32, 3, 1, 1, 1, 8, 2>(p, S, s) : launch_wg<128, 32, 3, 1, 1, 1, 8, 1>(p, S, s);
+      case 2: return s2 ? launch_wg<64, 32, 3, 2, 1, 1, 8, 2>(p, S, s) : launch_wg<64, 32, 3, 2, 1, 1, 8, 1>(p, S, s);
+      case 3: return s2 ? launch_wg<32, 32, 3, 4, 1, 1, 8, 2>(p, S, s) : launch_wg<32, 32, 3, 4, 1, 1, 8, 1>(p, S, s);
+      case 4: return s2 ? launch_wg<64, 64, 1, 1, 1, 1, 8, 2>(p, S, s) : launch_wg<64, 64, 1, 1, 1, 1, 8, 1>(p, S, s);
+      default: return launch_wg<128, 128, 1, 1, 2, 2, 4, 1>(p, S, s);
+    }
   });
 }
 

@@ -225,13 +225,20 @@ __global__ void unpack_wgrads_kernel(const plyolo_pack_entry* table, int accumul
   const plyolo_pack_entry e = table[blockIdx.x];
   if (!e.dw) return;
   const int taps = e.ksize * e.ksize;
-  const int n = e.Cout * e.Cin * taps;
-  for (int idx = blockIdx.y * blockDim.x + threadIdx.x; idx < n; idx += gridDim.y * blockDim.x) {
-    const int t = idx % taps;
-    const int ci = (idx / taps) % e.Cin;
-    const int co = idx / (taps * e.Cin);
-    const float g = e.dwp[((size_t)t * e.Cout_total + e.co_off + co) * e.Cin_p + ci];
-    e.dw[idx] = (accumulate ? e.dw[idx] : 0.f) + g;
+  // walk the PACKED index space so that the nslab partial slabs are read coalesced; the
+  // permuted OIHW store is the strided side (|dW| bytes once)
+  const int slab = taps * e.Cout_total * e.Cin_p;
+  for (int idx = blockIdx.y * blockDim.x + threadIdx.x; idx < slab; idx += gridDim.y * blockDim.x) {
+    const int ci = idx % e.Cin_p;
+    const int row = (idx / e.Cin_p) % e.Cout_total;
+    const int t = idx / (e.Cin_p * e.Cout_total);
+    const int co = row - e.co_off;
+    if (ci >= e.Cin || co < 0 || co >= e.Cout) continue;
+    float g = 0.f;
+#pragma unroll 8
+    for (int sl = 0; sl < e.nslab; ++sl) g += e.dwp[(size_t)sl * slab + idx];  // fixed order: deterministic
+    float* dst = e.dw + ((size_t)co * e.Cin + ci) * taps + t;
+    *dst = (accumulate ? *dst : 0.f) + g;
   }
   if (e.db && blockIdx.y == 0)
     for (int i = threadIdx.x; i < e.Cout; i += blockDim.x) e.db[i] = (accumulate ? e.db[i] : 0.f) + e.dbp[e.co_off + i];

@@ -128,23 +128,25 @@ class Graph:
         self.bn_fcnt = torch.zeros(cmax // 32 + 2, dtype=torch.int32, device=dev)
         # weight arenas
         wp_n = sum(_align(c.wp_elems) for c in self.convs)
+        dwp_n = sum(_align(c.wp_elems * c.nslab) for c in self.convs)
         wpd_n = sum(_align(c.wpd_elems) for c in self.convs)
         self.wp_arena = torch.zeros(max(wp_n, 8), dtype=self.tdtype, device=dev)
         self.wpd_arena = torch.zeros(max(wpd_n, 8), dtype=self.tdtype, device=dev)
-        self.dwp_arena = torch.zeros(max(wp_n, 8), dtype=torch.float32, device=dev)
+        self.dwp_arena = torch.zeros(max(dwp_n, 8), dtype=torch.float32, device=dev)
         nb = sum(_align(c.Cout_total) for c in self.convs)
         self.bias_arena = torch.zeros(max(nb, 8), dtype=torch.float32, device=dev)
         self.dbias_arena = torch.zeros(max(nb, 8), dtype=torch.float32, device=dev)
-        o1 = o2 = o3 = 0
+        o1 = o2 = o3 = o4 = 0
         entries = []
         self.max_pack_elems = 8
         for c in self.convs:
             c.wp = self.wp_arena.data_ptr() + o1 * self.esize
-            c.dwp = self.dwp_arena.data_ptr() + o1 * 4
+            c.dwp = self.dwp_arena.data_ptr() + o4 * 4
             c.wpd = self.wpd_arena.data_ptr() + o2 * self.esize if c.need_dgrad else None
             c.bp = self.bias_arena.data_ptr() + o3 * 4
             c.dbp = self.dbias_arena.data_ptr() + o3 * 4
             o1 += _align(c.wp_elems)
+            o4 += _align(c.wp_elems * c.nslab)
             o2 += _align(c.wpd_elems)
             o3 += _align(c.Cout_total)
             for (w, b, co_off) in c.sources:
@@ -155,7 +157,7 @@ class Graph:
                 e.b = b.data_ptr() if b is not None else None
                 e.bp, e.dbp, e.db = c.bp, c.dbp, None
                 e.Cout, e.Cin, e.Cin_p, e.ksize = w.shape[0], w.shape[1], c.Cin_p, c.ksize
-                e.Cout_total, e.Cout_p8, e.co_off, e.pad_ = c.Cout_total, c.Cout_p8, co_off, 0
+                e.Cout_total, e.Cout_p8, e.co_off, e.nslab = c.Cout_total, c.Cout_p8, co_off, c.nslab
                 entries.append((e, w, b))
                 self.max_pack_elems = max(self.max_pack_elems, c.ksize * c.ksize * w.shape[0] * c.Cin_p)
         self.pack_entries = entries
@@ -231,8 +233,16 @@ class PackedConv:
         self.wp_elems = taps * self.Cout_total * Cin_p
         self.wpd_elems = taps * Cin_p * self.Cout_p8
         self.need_dgrad = need_dgrad
+        self.nslab = 1
         self.wp = self.wpd = self.dwp = self.bp = self.dbp = None
         g.convs.append(self)
+
+    def set_slabs(self, desc):
+        """Number of private wgrad slabs the backward launch of `desc` writes."""
+        n = _lib.lib().plyolo_conv2d_wgrad_slabs(C.byref(desc))
+        if n <= 0:
+            _lib.check(-1, "plyolo_conv2d_wgrad_slabs")
+        self.nslab = n
 
 
 def conv_desc(g, N, H, W, Cin, Cout, k, stride, x_ld, y_ld, y_f32=0):
@@ -278,7 +288,8 @@ class ConvUnitOp:
         self.z = Storage(x.N, self.OH, self.OW, Cout, "z")
         g.storages.append(self.z)
         self.Cout = Cout
-        self.desc = conv_desc(g, x.N, x.H, x.W, self.Cin_p, Cout, k, stride, 0, Cout)
+        self.desc = conv_desc(g, x.N, x.H, x.W, self.Cin_p, Cout, k, stride, self.Cin_p, Cout)
+        self.pc.set_slabs(self.desc)
         g.scratch_elems = max(g.scratch_elems, self.z.rows * Cout)
         # upper bound of the per-workgroup partial rows (8x16 output tiles / 64-pixel bwd rows)
         tiles = x.N * ((self.OH + 7) // 8) * ((self.OW + 15) // 16)
@@ -428,8 +439,11 @@ class HeadPredOp:
         self.pc_cls = PackedConv(g, [(cls_conv.weight, cls_conv.bias, 0)], 1, Cin)
         self.pc_ro = PackedConv(g, [(reg_conv.weight, reg_conv.bias, 0), (obj_conv.weight, obj_conv.bias, 4)], 1, Cin)
         N, H, W = cls_feat.N, cls_feat.H, cls_feat.W
-        self.d_cls = conv_desc(g, N, H, W, Cin, self.nc, 1, 1, 0, head.nch, 1)
-        self.d_ro = conv_desc(g, N, H, W, Cin, 5, 1, 1, 0, head.nch, 1)
+        self.d_cls = conv_desc(g, N, H, W, Cin, self.nc, 1, 1, Cin, head.nch, 1)
+        self.d_ro = conv_desc(g, N, H, W, Cin, 5, 1, 1, Cin, head.nch, 1)
+        if g.dtype == BF16:
+            self.pc_ro.set_slabs(conv_desc(g, N, H, W, Cin, 5, 1, 1, Cin, 16, 0))
+            self.pc_cls.set_slabs(conv_desc(g, N, H, W, Cin, self.nc, 1, 1, Cin, head.cls_ld, 0))
         g.ops.append(self)
 
     def fwd(self):

@@ -153,7 +153,8 @@ class DetectorRunner:
         if mode in ("train", "maps_grad"):
             s.bwd = G.Plan()
             with s.bwd:
-                call("plyolo_memset_async", g.dwp_arena.data_ptr(), 0, g.dwp_arena.numel() * 4, None)
+                if g.dtype != BF16:  # the fp32 parity wgrad accumulates with atomics; the MFMA path overwrites its slabs
+                    call("plyolo_memset_async", g.dwp_arena.data_ptr(), 0, g.dwp_arena.numel() * 4, None)
                 for op in reversed(g.ops):
                     op.bwd()
                 call("plyolo_unpack_wgrads", g.pack_table.data_ptr(), g.n_pack, g.max_pack_elems, 0, None)

@@ -38,7 +38,7 @@ def rnd_bf16(x):
 class Packed:
     """Pack one conv weight (+bias) through plyolo_pack_weights."""
 
-    def __init__(self, w, dt, bias=None, cin_p=None):
+    def __init__(self, w, dt, bias=None, cin_p=None, nslab=64):
         Cout, Cin, k, _ = w.shape
         self.w = w.contiguous()
         self.Cin_p = cin_p or Cin
@@ -47,7 +47,8 @@ class Packed:
         dev = w.device
         self.wp = torch.zeros(taps * Cout * self.Cin_p, dtype=tdtype(dt), device=dev)
         self.wpd = torch.zeros(taps * self.Cin_p * self.Cout_p8, dtype=tdtype(dt), device=dev)
-        self.dwp = torch.zeros(taps * Cout * self.Cin_p, dtype=torch.float32, device=dev)
+        self.nslab = nslab  # room for the wgrad slabs; set_slabs(desc) before unpack()
+        self.dwp = torch.zeros(nslab * taps * Cout * self.Cin_p, dtype=torch.float32, device=dev)
         self.dw = torch.zeros_like(self.w)
         self.bias = bias.contiguous() if bias is not None else None
         self.bp = torch.zeros(max(Cout, 8), dtype=torch.float32, device=dev)
@@ -58,11 +59,20 @@ class Packed:
         e.b = self.bias.data_ptr() if bias is not None else None
         e.bp, e.dbp, e.db = self.bp.data_ptr(), self.dbp.data_ptr(), self.db.data_ptr() if bias is not None else None
         e.Cout, e.Cin, e.Cin_p, e.ksize = Cout, Cin, self.Cin_p, k
-        e.Cout_total, e.Cout_p8, e.co_off, e.pad_ = Cout, self.Cout_p8, 0, 0
+        e.Cout_total, e.Cout_p8, e.co_off, e.nslab = Cout, self.Cout_p8, 0, 1
+        self.entry = e
         arr = (PackEntry * 1)(e)
         self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
         self.nelem = taps * Cout * self.Cin_p
         call("plyolo_pack_weights", self.table.data_ptr(), 1, dt, self.nelem, stream())
+
+    def set_slabs(self, desc):
+        n = _lib.lib().plyolo_conv2d_wgrad_slabs(C.byref(desc))
+        assert 0 < n <= self.nslab, n
+        self.entry.nslab = n
+        arr = (PackEntry * 1)(self.entry)
+        self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.w.device)
+        return n
 
     def unpack(self, accumulate=0):
         call("plyolo_unpack_wgrads", self.table.data_ptr(), 1, self.nelem, accumulate, stream())

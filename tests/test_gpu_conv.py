@@ -157,6 +157,7 @@ def test_conv_wgrad(dt, shape):
     xm, dym = hu.to_nhwc(x, dt, x_ld), hu.to_nhwc(dy, dt, y_ld)
     pk = hu.Packed(w.detach(), dt)
     d = hu.conv_desc(dt, N, H, W, Cin, Cout, k, s, x_ld, y_ld)
+    pk.set_slabs(d)
     call("plyolo_conv2d_wgrad", C.byref(d), xm.data_ptr(), dym.data_ptr(), pk.dwp.data_ptr(), hu.stream())
     got = pk.unpack()
     torch.cuda.synchronize()
@@ -185,6 +186,7 @@ def test_head_pred_backward_bf16(cout):
     d = hu.conv_desc(BF16, N, H, W, Cin, cout, 1, 1, Cin, ld)
     dx = torch.zeros(N * H * W, Cin, dtype=torch.bfloat16, device=hu.DEV)
     call("plyolo_conv2d_dgrad", C.byref(d), dym.data_ptr(), pk.wpd.data_ptr(), dx.data_ptr(), 0, hu.stream())
+    pk.set_slabs(d)
     call("plyolo_conv2d_wgrad", C.byref(d), xm.data_ptr(), dym.data_ptr(), pk.dwp.data_ptr(), hu.stream())
     call("plyolo_bias_grad", BF16, dym.data_ptr(), N * H * W, cout, ld, pk.dbp.data_ptr(), hu.stream())
     dw = pk.unpack()

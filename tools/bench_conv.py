@@ -28,6 +28,7 @@ LAYERS = [
     ("pw_1024_512_20", 32, 20, 20, 1024, 512, 1, 1),
 ]
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
+ENVS = [dict(kv.split("=") for kv in e.split(",")) if e else {} for e in (sys.argv[3].split(";") if len(sys.argv) > 3 else [""])]
 what = sys.argv[2].split(",") if len(sys.argv) > 2 else ["fwd", "dgrad", "wgrad"]
 reps = 20
 def timeit(fn):
@@ -39,29 +40,35 @@ def timeit(fn):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
 print("%-16s %8s %22s %22s %22s" % ("layer", "GFLOP", "fwd us (TF/s)", "dgrad us (TF/s)", "wgrad us (TF/s)"))
-for (name, N, H, W, Cin, Cout, k, s) in LAYERS:
-    if flt and flt not in name: continue
+for env in ENVS:
+  for k_ in [k for k in os.environ if k.startswith("PLYOLO_")]: del os.environ[k_]
+  os.environ.update(env)
+  if env: print("ENV", env)
+  for (name, N, H, W, Cin, Cout, k, s) in LAYERS:
+    if flt and not any(f in name for f in flt.split("|")): continue
     pad = (k - 1) // 2
     OH, OW = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
     x = torch.randn(N * H * W, Cin, device="cuda").to(torch.bfloat16)
     w = torch.randn(Cout, Cin, k, k, device="cuda") / (Cin * k * k) ** 0.5
-    pk = hu.Packed(w, BF16)
     y = torch.empty(N * OH * OW, Cout, dtype=torch.bfloat16, device="cuda")
     dy = torch.randn(N * OH * OW, Cout, device="cuda").to(torch.bfloat16)
     dx = torch.empty(N * H * W, Cin, dtype=torch.bfloat16, device="cuda")
     d = hu.conv_desc(BF16, N, H, W, Cin, Cout, k, s, Cin, Cout)
+    pk = hu.Packed(w, BF16, nslab=hu._lib.lib().plyolo_conv2d_wgrad_slabs(C.byref(d)))
+    pk.set_slabs(d)
     rows = hu._lib.lib().plyolo_conv2d_stat_rows(C.byref(d))
     stats = torch.empty(2 * rows * Cout, device="cuda")
     st = hu.stream()
     gf = 2.0 * N * OH * OW * Cout * Cin * k * k / 1e9
     res = []
     if "fwd" in what:
-        t = timeit(lambda: call("plyolo_conv2d_fwd", C.byref(d), x.data_ptr(), pk.wp.data_ptr(), None, y.data_ptr(), stats.data_ptr(), st)); res.append(t)
+          t = timeit(lambda: call("plyolo_conv2d_fwd", C.byref(d), x.data_ptr(), pk.wp.data_ptr(), None, y.data_ptr(), stats.data_ptr(), st)); res.append(t)
     else: res.append(float("nan"))
     if "dgrad" in what:
-        t = timeit(lambda: call("plyolo_conv2d_dgrad", C.byref(d), dy.data_ptr(), pk.wpd.data_ptr(), dx.data_ptr(), 0, st)); res.append(t)
+          t = timeit(lambda: call("plyolo_conv2d_dgrad", C.byref(d), dy.data_ptr(), pk.wpd.data_ptr(), dx.data_ptr(), 0, st)); res.append(t)
     else: res.append(float("nan"))
     if "wgrad" in what:
-        t = timeit(lambda: call("plyolo_conv2d_wgrad", C.byref(d), x.data_ptr(), dy.data_ptr(), pk.dwp.data_ptr(), st)); res.append(t)
+          t = timeit(lambda: call("plyolo_conv2d_wgrad", C.byref(d), x.data_ptr(), dy.data_ptr(), pk.dwp.data_ptr(), st)); res.append(t)
+          tu = timeit(lambda: pk.unpack()); print("    unpack %.1f us (%d slabs)" % (tu, pk.entry.nslab))
     else: res.append(float("nan"))
     print("%-16s %8.1f %s" % (name, gf, " ".join("%12.1f (%7.1f)" % (t, gf / t * 1e3) for t in res)))
