@@ -205,6 +205,23 @@ int plyolo_maxpool_s1_fwd(int dtype, int N, int H, int W, int C, int k, const vo
                           int o_ld, void* stream);
 int plyolo_maxpool_s1_bwd(int dtype, int N, int H, int W, int C, int k, const void* in, int i_ld,
                           const void* dout, int d_ld, float* din_f32, void* stream);
+/* MaxPool2d(2, stride 2) of the YOLOv7 Transition blocks (models/backbones/eelan.py:126-141,
+ * models/necks/yolov7_neck.py:149-164); bwd routes to the first maximum (ATen rule). */
+int plyolo_maxpool2x2_fwd(int dtype, int N, int H, int W, int C, const void* in, int i_ld, void* out, int o_ld,
+                          void* stream);
+int plyolo_maxpool2x2_bwd(int dtype, int N, int H, int W, int C, const void* in, int i_ld, const void* dout,
+                          int d_ld, void* din, int di_ld, int accumulate, void* stream);
+/* ImplicitHead pieces (models/heads/implicit_head.py:5-62): y = m * (W(x + a) + b).
+ * implicit_bias: out[co] = b[co] + sum_ci W[co][ci]*a[ci];  scale_channels: y = m*u;
+ * implicit_bwd: du = m*dy (activation dtype, pitch du_ld) + per-block partials of dm = sum dy*u;
+ * implicit_param_grads: dm, da = W^T sdu, dW += sdu (x) a, db = sdu  (sdu = column sums of du). */
+int plyolo_implicit_bias(const float* W, const float* a, const float* b, float* out, int Cout, int Cin, void* stream);
+int plyolo_scale_channels(const float* u, const float* m, float* y, size_t rows, int C, void* stream);
+int plyolo_implicit_bwd_blocks(size_t rows);
+int plyolo_implicit_bwd(int dtype, const float* dy, const float* u, const float* m, void* du, int du_ld,
+                        float* partial, size_t rows, int C, void* stream);
+int plyolo_implicit_param_grads(const float* partial, int nblk, const float* W, const float* a, const float* sdu,
+                                float* dm, float* da, float* dW, float* db, int Cout, int Cin, void* stream);
 /* out (pitch o_ld) (+)= convert(in fp32 [M][C]) */
 int plyolo_f32_to_act(int dtype, int M, int C, const float* in, void* out, int o_ld, int accumulate, void* stream);
 int plyolo_memset_async(void* p, int value, size_t bytes, void* stream);
@@ -247,6 +264,11 @@ int plyolo_yolox_loss_bwd(const plyolo_yolox_desc* d, const float* raw, const fl
                           void* stream);
 /* eval branch (yolox_loss.py:25-36): out [B,A,5+C] batch-major = (x1,y1,x2,y2,sig(obj),sig(cls)) */
 int plyolo_yolox_eval_decode(const plyolo_yolox_desc* d, const float* raw, float* out, void* stream);
+
+/* YOLOv7 eval branch (models/losses/yolov7/yolov7_loss.py:50-78), one call per level:
+ * raw_level fp32 [B,h,w,na*(5+C)] -> rows [lvl_off, lvl_off+na*h*w) of out [B,A_total,5+C]. */
+int plyolo_yolov7_eval_decode(const float* raw_level, int B, int h, int w, int na, int nc, int stride,
+                              const float* anchors_dev, float* out, int A_total, int lvl_off, void* stream);
 
 /* ----------------------------------------------------------- postprocess
  * Replaces postprocess() (models/evaluators/postprocess.py:7-48) including

@@ -93,6 +93,13 @@ SIGNATURES = {
     "plyolo_upsample2x_bwd": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp]),
     "plyolo_maxpool_s1_fwd": (_i, [_i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
     "plyolo_maxpool_s1_bwd": (_i, [_i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp]),
+    "plyolo_maxpool2x2_fwd": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
+    "plyolo_maxpool2x2_bwd": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp]),
+    "plyolo_implicit_bias": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "plyolo_scale_channels": (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
+    "plyolo_implicit_bwd_blocks": (_i, [_sz]),
+    "plyolo_implicit_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _sz, _i, _vp]),
+    "plyolo_implicit_param_grads": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "plyolo_f32_to_act": (_i, [_i, _i, _i, _vp, _vp, _i, _i, _vp]),
     "plyolo_memset_async": (_i, [_vp, _i, _sz, _vp]),
     "plyolo_nhwc_to_nchw_f32": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
@@ -101,6 +108,7 @@ SIGNATURES = {
     "plyolo_yolox_loss_fwd": (_i, [_P(YoloxDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "plyolo_yolox_loss_bwd": (_i, [_P(YoloxDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "plyolo_yolox_eval_decode": (_i, [_P(YoloxDesc), _vp, _vp, _vp]),
+    "plyolo_yolov7_eval_decode": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp]),
     "plyolo_postprocess_workspace": (_sz, [_P(NmsDesc)]),
     "plyolo_postprocess": (_i, [_P(NmsDesc), _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "plyolo_batched_nms": (_i, [_P(NmsDesc), _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),

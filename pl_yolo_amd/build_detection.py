@@ -17,10 +17,10 @@ import torch
 import torch.nn as nn
 
 from ._lib import PlyoloError
-from .backbones import CSPDarkNet
-from .necks import CSPPAFPN
-from .heads import DecoupledHead
-from .losses import YOLOXLoss
+from .backbones import CSPDarkNet, EELAN
+from .necks import CSPPAFPN, YOLOv7NECK
+from .heads import DecoupledHead, ImplicitHead
+from .losses import YOLOXLoss, YOLOv7Loss
 from . import runner as R
 
 
@@ -85,6 +85,22 @@ def cspdarknet(cfg):
     return CSPDarkNet(cfg['depths'], cfg['channels'], cfg['outputs'], cfg['norm'], cfg['act'])
 
 
+def eelan(cfg):
+    return EELAN(cfg['depths'], cfg['channels'], cfg['outputs'], cfg['norm'], cfg['act'])
+
+
+def yolov7neck(cfg):
+    return YOLOv7NECK(cfg['depths'], cfg['channels'], cfg['norm'], cfg['act'])
+
+
+def implicit_head(cfg, num_classes):
+    return ImplicitHead(num_classes, cfg['num_anchor'], cfg['channels'])
+
+
+def yolov7(cfg, num_classes):
+    return YOLOv7Loss(num_classes, cfg['stride'], cfg['anchors'])
+
+
 def csppafpn(cfg):
     return CSPPAFPN(cfg['depths'], cfg['channels'], cfg['norm'], cfg['act'])
 
@@ -101,10 +117,10 @@ def yolox(cfg, num_classes):
     return YOLOXLoss(num_classes, cfg['stride'])
 
 
-_REGISTRY = {f.__name__: f for f in (cspdarknet, csppafpn, none, decoupled_head, yolox)}
+_REGISTRY = {f.__name__: f for f in (cspdarknet, eelan, csppafpn, yolov7neck, none, decoupled_head, implicit_head, yolox, yolov7)}
 # reference plugins that exist upstream but are outside this build's hot path
-_KNOWN_UNBUILT = ("cspmobilenext", "eelan", "ecmnet", "shufflenetv2", "mobilenetv3s", "mobilenetv3l",
-                  "vision_transformer", "swin_transformer", "al_pafpn", "yolov7neck", "implicit_head", "yolov7")
+_KNOWN_UNBUILT = ("cspmobilenext", "ecmnet", "shufflenetv2", "mobilenetv3s", "mobilenetv3l",
+                  "vision_transformer", "swin_transformer", "al_pafpn")
 
 
 def _plugin(name):

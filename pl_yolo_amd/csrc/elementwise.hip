@@ -161,6 +161,126 @@ __global__ void maxpool_bwd_kernel(int N, int H, int W, int C, int k, const T* i
   }
 }
 
+// MaxPool2d(kernel 2, stride 2) of the YOLOv7 Transition blocks (reference
+// models/backbones/eelan.py:129, models/necks/yolov7_neck.py:152): forward, and the backward
+// that routes dout to the FIRST maximum of each 2x2 window in row-major order (ATen rule).
+template <typename T>
+__global__ void maxpool2x2_fwd_kernel(int N, int H, int W, int C, const T* in, int i_ld, T* out, int o_ld) {
+  constexpr int V = Vec<T>::N;
+  const int cvn = C / V, OH = H / 2, OW = W / 2;
+  const size_t total = (size_t)N * OH * OW * cvn;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % cvn) * V;
+    size_t t = idx / cvn;
+    const int x = (int)(t % OW);
+    t /= OW;
+    const int y = (int)(t % OH);
+    const int n = (int)(t / OH);
+    float best[V], a[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) best[i] = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      Vec<T>::load(in + ((size_t)(n * H + 2 * y + (k >> 1)) * W + 2 * x + (k & 1)) * i_ld + c, a);
+#pragma unroll
+      for (int i = 0; i < V; ++i) best[i] = a[i] > best[i] ? a[i] : best[i];
+    }
+    Vec<T>::store(out + ((size_t)(n * OH + y) * OW + x) * o_ld + c, best);
+  }
+}
+
+template <typename T>
+__global__ void maxpool2x2_bwd_kernel(int N, int H, int W, int C, const T* in, int i_ld, const T* dout, int d_ld, T* din, int di_ld,
+                                      int accumulate) {
+  constexpr int V = Vec<T>::N;
+  const int cvn = C / V, OH = H / 2, OW = W / 2;
+  const size_t total = (size_t)N * OH * OW * cvn;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % cvn) * V;
+    size_t t = idx / cvn;
+    const int x = (int)(t % OW);
+    t /= OW;
+    const int y = (int)(t % OH);
+    const int n = (int)(t / OH);
+    float a[4][V], g[V];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) Vec<T>::load(in + ((size_t)(n * H + 2 * y + (k >> 1)) * W + 2 * x + (k & 1)) * i_ld + c, a[k]);
+    Vec<T>::load(dout + ((size_t)(n * OH + y) * OW + x) * d_ld + c, g);
+    int arg[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      float best = a[0][i];
+      arg[i] = 0;
+#pragma unroll
+      for (int k = 1; k < 4; ++k)
+        if (a[k][i] > best) { best = a[k][i]; arg[i] = k; }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      T* dst = din + ((size_t)(n * H + 2 * y + (k >> 1)) * W + 2 * x + (k & 1)) * di_ld + c;
+      float o[V];
+      if (accumulate) Vec<T>::load(dst, o);
+#pragma unroll
+      for (int i = 0; i < V; ++i) o[i] = (accumulate ? o[i] : 0.f) + (arg[i] == k ? g[i] : 0.f);
+      Vec<T>::store(dst, o);
+    }
+  }
+}
+
+// ---- ImplicitHead (reference models/heads/implicit_head.py:5-62): y = m * (W (x + a) + b)
+// bias_eff[co] = b[co] + sum_ci W[co][ci] * a[ci]
+__global__ void implicit_bias_kernel(const float* W, const float* a, const float* b, float* out, int Cout, int Cin) {
+  const int co = blockIdx.x;
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int ci = threadIdx.x; ci < Cin; ci += 256) s += W[(size_t)co * Cin + ci] * a[ci];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[co] = b[co] + red[0];
+}
+// y[r][c] = m[c] * u[r][c]
+__global__ void scale_channels_kernel(const float* u, const float* m, float* y, size_t rows, int C) {
+  const size_t total = rows * C;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x)
+    y[idx] = u[idx] * m[idx % C];
+}
+// du = m * dy  (fp32 [rows][C] -> activation dtype [rows][du_ld], pad columns untouched);
+// dm partial[blk][c] = sum over the block's rows of dy*u
+template <typename T>
+__global__ void implicit_bwd_kernel(const float* dy, const float* u, const float* m, T* du, int du_ld, float* partial, size_t rows, int C) {
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float mc = m[c];
+    float s = 0.f;
+    for (size_t r = blockIdx.x; r < rows; r += gridDim.x) {
+      const float g = dy[r * C + c];
+      s += g * u[r * C + c];
+      ActT<T>::st(du + r * du_ld + c, g * mc);
+    }
+    partial[(size_t)blockIdx.x * C + c] = s;
+  }
+}
+// dm[c] = sum_blk partial ; da[ci] = sum_co W[co][ci]*sdu[co] ; dW[co][ci] += sdu[co]*a[ci] ; db[co] = sdu[co]
+__global__ void implicit_param_grads_kernel(const float* partial, int nblk, const float* W, const float* a, const float* sdu, float* dm,
+                                            float* da, float* dW, float* db, int Cout, int Cin) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid < Cout) {
+    float s = 0.f;
+    for (int k = 0; k < nblk; ++k) s += partial[(size_t)k * Cout + tid];
+    dm[tid] = s;
+    db[tid] = sdu[tid];
+  }
+  if (tid < Cin) {
+    float s = 0.f;
+    for (int co = 0; co < Cout; ++co) s += W[(size_t)co * Cin + tid] * sdu[co];
+    da[tid] = s;
+  }
+  for (int idx = tid; idx < Cout * Cin; idx += gridDim.x * blockDim.x) dW[idx] += sdu[idx / Cin] * a[idx % Cin];
+}
+
 template <typename T>
 __global__ void f32_to_act_kernel(size_t M, int C, const float* in, T* out, int o_ld, int accumulate) {
   const size_t total = M * C;
@@ -371,6 +491,70 @@ int plyolo_maxpool_s1_bwd(int dtype, int N, int H, int W, int C, int k, const vo
   return submit(stream, [=](hipStream_t s) -> hipError_t {
     DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(grid_for(work)), dim3(256), 0, s, N, H, W, C, k, (const T*)in, i_ld,
                                          (const T*)dout, d_ld, din_f32);)
+    return hipGetLastError();
+  });
+}
+
+int plyolo_maxpool2x2_fwd(int dtype, int N, int H, int W, int C, const void* in, int i_ld, void* out, int o_ld, void* stream) {
+  const int V = dtype == PLYOLO_BF16 ? 8 : 4;
+  PLY_CHECK_ARG(C % V == 0 && i_ld % V == 0 && o_ld % V == 0 && H % 2 == 0 && W % 2 == 0, "maxpool2x2: C/ld multiples of %d, even H/W", V);
+  const size_t work = (size_t)N * (H / 2) * (W / 2) * (C / V);
+  plyolo::annotate("maxpool2x2_fwd", 0.0, (double)N * H * W * C * (dtype == PLYOLO_BF16 ? 2.0 : 4.0) * 1.25);
+  return submit(stream, [=](hipStream_t s) -> hipError_t {
+    DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool2x2_fwd_kernel<T>, dim3(grid_for(work)), dim3(256), 0, s, N, H, W, C, (const T*)in, i_ld,
+                                         (T*)out, o_ld);)
+    return hipGetLastError();
+  });
+}
+
+int plyolo_maxpool2x2_bwd(int dtype, int N, int H, int W, int C, const void* in, int i_ld, const void* dout, int d_ld, void* din,
+                          int di_ld, int accumulate, void* stream) {
+  const int V = dtype == PLYOLO_BF16 ? 8 : 4;
+  PLY_CHECK_ARG(C % V == 0 && i_ld % V == 0 && d_ld % V == 0 && di_ld % V == 0 && H % 2 == 0 && W % 2 == 0, "maxpool2x2: C/ld multiples of %d, even H/W", V);
+  const size_t work = (size_t)N * (H / 2) * (W / 2) * (C / V);
+  plyolo::annotate("maxpool2x2_bwd", 0.0, (double)N * H * W * C * (dtype == PLYOLO_BF16 ? 2.0 : 4.0) * 2.25);
+  return submit(stream, [=](hipStream_t s) -> hipError_t {
+    DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool2x2_bwd_kernel<T>, dim3(grid_for(work)), dim3(256), 0, s, N, H, W, C, (const T*)in, i_ld,
+                                         (const T*)dout, d_ld, (T*)din, di_ld, accumulate);)
+    return hipGetLastError();
+  });
+}
+
+int plyolo_implicit_bias(const float* W, const float* a, const float* b, float* out, int Cout, int Cin, void* stream) {
+  plyolo::annotate("implicit_bias", 0.0, 4.0 * Cout * Cin);
+  return submit(stream, [=](hipStream_t s) -> hipError_t {
+    hipLaunchKernelGGL(implicit_bias_kernel, dim3(Cout), dim3(256), 0, s, W, a, b, out, Cout, Cin);
+    return hipGetLastError();
+  });
+}
+
+int plyolo_scale_channels(const float* u, const float* m, float* y, size_t rows, int C, void* stream) {
+  plyolo::annotate("scale_channels", 0.0, 8.0 * rows * C);
+  return submit(stream, [=](hipStream_t s) -> hipError_t {
+    hipLaunchKernelGGL(scale_channels_kernel, dim3(grid_for(rows * C)), dim3(256), 0, s, u, m, y, rows, C);
+    return hipGetLastError();
+  });
+}
+
+int plyolo_implicit_bwd_blocks(size_t rows) { return rows < 512 ? (int)(rows < 1 ? 1 : rows) : 512; }
+
+int plyolo_implicit_bwd(int dtype, const float* dy, const float* u, const float* m, void* du, int du_ld, float* partial, size_t rows,
+                        int C, void* stream) {
+  const int nblk = plyolo_implicit_bwd_blocks(rows);
+  plyolo::annotate("implicit_bwd", 0.0, 10.0 * rows * C);
+  return submit(stream, [=](hipStream_t s) -> hipError_t {
+    DISPATCH_T(dtype, hipLaunchKernelGGL(implicit_bwd_kernel<T>, dim3(nblk), dim3(256), 0, s, dy, u, m, (T*)du, du_ld, partial, rows, C);)
+    return hipGetLastError();
+  });
+}
+
+int plyolo_implicit_param_grads(const float* partial, int nblk, const float* W, const float* a, const float* sdu, float* dm, float* da,
+                                float* dW, float* db, int Cout, int Cin, void* stream) {
+  plyolo::annotate("implicit_param_grads", 0.0, 8.0 * Cout * Cin);
+  const int n = Cout > Cin ? Cout : Cin;
+  return submit(stream, [=](hipStream_t s) -> hipError_t {
+    hipLaunchKernelGGL(implicit_param_grads_kernel, dim3(cdiv(n, 256) > 64 ? cdiv(n, 256) : 64), dim3(256), 0, s, partial, nblk, W, a, sdu, dm, da,
+                       dW, db, Cout, Cin);
     return hipGetLastError();
   });
 }

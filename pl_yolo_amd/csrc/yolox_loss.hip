@@ -498,6 +498,37 @@ __global__ void k_eval_decode(const plyolo_yolox_desc d, const float* raw, float
   out[idx] = v;
 }
 
+// YOLOv7 eval branch (reference models/losses/yolov7/yolov7_loss.py:50-78) for ONE level:
+// raw [B,h,w,na*(5+C)] (channel = a*(5+C)+c) -> out[b][lvl_off + (a*h+gy)*w+gx][5+C] =
+// (x1,y1,x2,y2, sig(obj), sig(cls..)),  xy = (sig*2-0.5+grid)*stride, wh = (sig*2)^2*anchor
+__global__ void k_v7_eval_decode(const float* raw, int B, int h, int w, int na, int nc, float stride, const float* anchors, float* out,
+                                 int A_total, int lvl_off) {
+  const int ch = 5 + nc;
+  const size_t total = (size_t)B * h * w * na * ch;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % ch);
+  size_t t = idx / ch;
+  const int a = (int)(t % na);
+  t /= na;
+  const int gx = (int)(t % w);
+  t /= w;
+  const int gy = (int)(t % h);
+  const int b = (int)(t / h);
+  const float* r = raw + (((size_t)(b * h + gy) * w + gx) * na + a) * ch;
+  float v;
+  if (c >= 4) {
+    v = sigmoidf_(r[c]);
+  } else {
+    const int ax = c & 1;
+    const float ctr = (sigmoidf_(r[ax]) * 2.0f - 0.5f + (float)(ax ? gy : gx)) * stride;
+    const float e = sigmoidf_(r[2 + ax]) * 2.0f;
+    const float ext = e * e * anchors[a * 2 + ax];
+    v = (c < 2) ? ctr - ext / 2 : ctr + ext / 2;
+  }
+  out[((size_t)b * A_total + lvl_off + ((size_t)a * h + gy) * w + gx) * ch + c] = v;
+}
+
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 LossWs carve(const plyolo_yolox_desc* d, void* workspace, size_t* used) {
@@ -576,6 +607,17 @@ int plyolo_yolox_eval_decode(const plyolo_yolox_desc* dp, const float* raw, floa
   const size_t total = (size_t)d.B * d.A * (5 + d.C);
   return submit(stream, [=](hipStream_t s) -> hipError_t {
     hipLaunchKernelGGL(k_eval_decode, dim3((unsigned)cdivz(total, 256)), dim3(256), 0, s, d, raw, out);
+    return hipGetLastError();
+  });
+}
+
+int plyolo_yolov7_eval_decode(const float* raw_level, int B, int h, int w, int na, int nc, int stride, const float* anchors_dev,
+                              float* out, int A_total, int lvl_off, void* stream) {
+  const size_t total = (size_t)B * h * w * na * (5 + nc);
+  plyolo::annotate("yolov7_eval_decode", 0.0, 8.0 * total);
+  return submit(stream, [=](hipStream_t s) -> hipError_t {
+    hipLaunchKernelGGL(k_v7_eval_decode, dim3((unsigned)cdivz(total, 256)), dim3(256), 0, s, raw_level, B, h, w, na, nc, (float)stride,
+                       anchors_dev, out, A_total, lvl_off);
     return hipGetLastError();
   });
 }

@@ -39,6 +39,7 @@ class Storage:
         self.grad = None
         self.ginit = [False] * ld  # per channel: has the gradient been written yet (lowering-time state)
         self.views = 0
+        self.acts = []
 
 
 class Act:
@@ -47,6 +48,7 @@ class Act:
     def __init__(self, storage, C_, c_off=0):
         self.storage, self.C, self.c_off = storage, C_, c_off
         storage.views += 1
+        storage.acts.append(self)
         self.fixed = False  # True once something depends on the placement
 
     N = property(lambda s: s.storage.N)
@@ -57,8 +59,10 @@ class Act:
 
     def rebind(self, storage, c_off):
         self.storage.views -= 1
+        self.storage.acts.remove(self)
         self.storage, self.c_off = storage, c_off
         storage.views += 1
+        storage.acts.append(self)
 
 
 class Graph:
@@ -76,6 +80,7 @@ class Graph:
         self.scratch_elems = 0  # shared dz scratch (activation dtype)
         self.scratch_f32 = 0    # shared fp32 scratch (maxpool backward)
         self.image_act = None
+        self.post_unpack = []   # ops with work that must follow unpack_wgrads
         import os
         # in-launch BatchNorm finish (last-arriver hand-off): measured SLOWER than the separate
         # finalize launches on these short kernels (profiles/README.md), so it is opt-in
@@ -93,6 +98,7 @@ class Graph:
         a0 = acts[0]
         total = sum(a.C for a in acts)
         st = Storage(a0.N, a0.H, a0.W, total, "cat")
+        st.is_cat, st.nested = True, False
         self.storages.append(st)
         off = 0
         for a in acts:
@@ -101,6 +107,12 @@ class Graph:
                 old = a.storage
                 a.rebind(st, off)
                 a.fixed = True
+                self.storages.remove(old)
+            elif a.fixed and a.c_off == 0 and a.storage.ld == a.C and getattr(a.storage, "is_cat", False) and not a.storage.nested:
+                # nested concat: relocate the whole inner concat matrix (all its views) into this one
+                old = a.storage
+                for v in list(old.acts):
+                    v.rebind(st, off + v.c_off)
                 self.storages.remove(old)
             else:
                 dst = Act(st, a.C, off)
@@ -425,6 +437,135 @@ class SppPoolsOp:
         call("plyolo_f32_to_act", g.dtype, x.M, x.C, g.scratch32.data_ptr(), g.gptr(x), x.ld, acc, None)
 
 
+class MaxPool2x2Op:
+    """MaxPool2d(2, 2) of the YOLOv7 Transition blocks."""
+
+    def __init__(self, g, x):
+        self.g, self.x = g, x
+        self.out = g.new_act(x.N, x.H // 2, x.W // 2, x.C, "mp2")
+        g.ops.append(self)
+
+    def fwd(self):
+        g, x = self.g, self.x
+        call("plyolo_maxpool2x2_fwd", g.dtype, x.N, x.H, x.W, x.C, g.aptr(x), x.ld, g.aptr(self.out), self.out.ld, None)
+
+    def bwd(self):
+        g, x = self.g, self.x
+        if not g.grad_ready(self.out):
+            return
+        acc = g.grad_mode(x)
+        call("plyolo_maxpool2x2_bwd", g.dtype, x.N, x.H, x.W, x.C, g.aptr(x), x.ld, g.gptr(self.out), self.out.ld,
+             g.gptr(x), x.ld, acc, None)
+
+
+class ImplicitHeadOp:
+    """One level of the YOLOv7 ImplicitHead: y = im * (conv1x1(x + ia) + b)
+    (models/heads/implicit_head.py:26-36).  Lowered as  u = W x + (b + W ia)  [MFMA conv with an
+    effective bias, fp32 output]  and  y = im * u;  backward: du = im*dy feeds the ordinary
+    dgrad / wgrad / bias-grad kernels, plus a tiny launch for d(ia), d(im) and the ia term of dW."""
+
+    def __init__(self, g, head, level, x, conv, ia, im):
+        self.g, self.head, self.level, self.x = g, head, level, x
+        self.conv, self.ia, self.im = conv, ia, im
+        self.Cout, self.Cin = conv.weight.shape[0], conv.weight.shape[1]
+        self.pc = PackedConv(g, [(conv.weight, None, 0)], 1, self.Cin)  # bias handled by implicit_bias
+        N, H, W = x.N, x.H, x.W
+        self.desc = conv_desc(g, N, H, W, self.Cin, self.Cout, 1, 1, self.Cin, head.nch, 1)
+        self.du_ld = (self.Cout + 7) // 8 * 8
+        if g.dtype == BF16:
+            self.pc.set_slabs(conv_desc(g, N, H, W, self.Cin, self.Cout, 1, 1, self.Cin, self.du_ld, 0))
+        g.ops.append(self)
+        g.post_unpack.append(self)
+
+    def _rows(self):
+        return self.x.M
+
+    def fwd(self):
+        g, hd = self.g, self.head
+        r0 = hd.lvl_row[self.level]
+        self.desc.x_ld = self.x.ld
+        call("plyolo_implicit_bias", ptr(self.conv.weight), ptr(self.ia), ptr(self.conv.bias), self.pc.bp, self.Cout, self.Cin, None)
+        u = hd.u.data_ptr() + r0 * hd.nch * 4
+        call("plyolo_conv2d_fwd", C.byref(self.desc), g.aptr(self.x), self.pc.wp, self.pc.bp, u, None, None)
+        call("plyolo_scale_channels", u, ptr(self.im), hd.raw.data_ptr() + r0 * hd.nch * 4, self._rows(), self.Cout, None)
+
+    def bwd(self):
+        g, hd = self.g, self.head
+        r0 = hd.lvl_row[self.level]
+        rows = self._rows()
+        dev = g.device
+        if not hasattr(self, "du"):
+            self.du = torch.zeros(rows * self.du_ld, dtype=g.tdtype, device=dev)
+            self.nblk = _lib.lib().plyolo_implicit_bwd_blocks(rows)
+            self.partial = torch.empty(self.nblk * self.Cout, dtype=torch.float32, device=dev)
+        dy = hd.draw.data_ptr() + r0 * hd.nch * 4
+        u = hd.u.data_ptr() + r0 * hd.nch * 4
+        call("plyolo_implicit_bwd", g.dtype, dy, u, ptr(self.im), self.du.data_ptr(), self.du_ld, self.partial.data_ptr(), rows, self.Cout, None)
+        d = conv_desc(g, self.desc.N, self.desc.H, self.desc.W, self.Cin, self.Cout, 1, 1, self.x.ld, self.du_ld, 0)
+        self.keep = d
+        call("plyolo_bias_grad", g.dtype, self.du.data_ptr(), rows, self.Cout, self.du_ld, self.pc.dbp, None)
+        call("plyolo_conv2d_wgrad", C.byref(d), g.aptr(self.x), self.du.data_ptr(), self.pc.dwp, None)
+        acc = g.grad_mode(self.x)
+        call("plyolo_conv2d_dgrad", C.byref(d), self.du.data_ptr(), self.pc.wpd, g.gptr(self.x), acc, None)
+
+    def post_unpack(self):
+        """After unpack_wgrads wrote dW: d(im), d(ia), d(bias) and the ia term of dW."""
+        g = self.g
+        call("plyolo_implicit_param_grads", self.partial.data_ptr(), self.nblk, ptr(self.conv.weight), ptr(self.ia), self.pc.dbp,
+             g.grad_ptr_of(self.im), g.grad_ptr_of(self.ia), g.grad_ptr_of(self.conv.weight), g.grad_ptr_of(self.conv.bias),
+             self.Cout, self.Cin, None)
+
+
+class V7HeadBuffers:
+    """Level-major raw YOLOv7 head output: level l = dense NHWC [B, h, w, na*(5+C)]."""
+
+    def __init__(self, g, B, num_classes, na, sizes, strides, anchors):
+        self.g, self.B, self.nc, self.na = g, B, num_classes, na
+        self.ch = 5 + num_classes
+        self.nch = na * self.ch
+        self.sizes, self.strides, self.anchors = list(sizes), list(strides), anchors
+        self.lvl_row, self.lvl_off = [], []
+        r = a = 0
+        for (h, w) in sizes:
+            self.lvl_row.append(r)
+            self.lvl_off.append(a)
+            r += B * h * w
+            a += na * h * w
+        self.rows, self.A = r, a
+        dev = g.device
+        self.raw = torch.empty(self.rows * self.nch, dtype=torch.float32, device=dev)
+        self.u = torch.empty(self.rows * self.nch, dtype=torch.float32, device=dev)
+        self.draw = None
+
+    def alloc_grad_only(self):
+        self.draw = torch.zeros(self.rows * self.nch, dtype=torch.float32, device=self.g.device)
+
+    def set_map_grads(self, grads):
+        for (h, w), r0, gm in zip(self.sizes, self.lvl_row, grads):
+            n = self.B * h * w
+            self.draw.view(self.rows, self.nch)[r0:r0 + n].copy_(gm.permute(0, 2, 3, 1).reshape(n, self.nch))
+
+    def alloc_eval(self):
+        self.eval_out = torch.empty(self.B * self.A * self.ch, dtype=torch.float32, device=self.g.device)
+        self.eval_shape = (self.B, self.A, self.ch)
+        self.anchor_t = torch.tensor(self.anchors, dtype=torch.float32).reshape(-1).to(self.g.device)
+
+
+class YoloV7EvalDecodeOp:
+    def __init__(self, g, head):
+        self.g, self.head = g, head
+        g.ops.append(self)
+
+    def fwd(self):
+        hd = self.head
+        for l, ((h, w), s) in enumerate(zip(hd.sizes, hd.strides)):
+            call("plyolo_yolov7_eval_decode", hd.raw.data_ptr() + hd.lvl_row[l] * hd.nch * 4, hd.B, h, w, hd.na, hd.nc, int(s),
+                 hd.anchor_t.data_ptr() + l * hd.na * 2 * 4, hd.eval_out.data_ptr(), hd.A, hd.lvl_off[l], None)
+
+    def bwd(self):
+        pass
+
+
 class HeadPredOp:
     """The three bare 1x1 prediction convs of one DecoupledHead level
     (decoupled_head.py:43-62,86-93), packed as two convs (cls: C_cls outputs from the
@@ -551,6 +692,7 @@ class HeadBuffers:
 
     def alloc_eval(self):
         self.eval_out = torch.empty(self.B * self.A * self.nch, dtype=torch.float32, device=self.g.device)
+        self.eval_shape = (self.B, self.A, self.nch)
 
 
 class YoloxLossOp:

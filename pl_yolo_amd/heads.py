@@ -54,3 +54,41 @@ class DecoupledHead(HipModule):
                 reg_feat = m.emit(g, reg_feat)
             G.HeadPredOp(g, head_buffers, k, cls_feat, reg_feat, self.cls_preds[k], self.reg_preds[k], self.obj_preds[k])
         return head_buffers
+
+
+class ImplicitA(nn.Module):
+    def __init__(self, channel, mean=0., std=.02):
+        super().__init__()
+        self.channel, self.mean, self.std = channel, mean, std
+        self.implicit = nn.Parameter(torch.zeros(1, channel, 1, 1))
+        nn.init.normal_(self.implicit, mean=self.mean, std=self.std)
+
+
+class ImplicitM(nn.Module):
+    def __init__(self, channel, mean=0., std=.02):
+        super().__init__()
+        self.channel, self.mean, self.std = channel, mean, std
+        self.implicit = nn.Parameter(torch.ones(1, channel, 1, 1))
+        nn.init.normal_(self.implicit, mean=self.mean, std=self.std)  # mean 0 as coded upstream (implicit_head.py:53-59)
+
+
+class ImplicitHead(HipModule):
+    """YOLOv7 head (models/heads/implicit_head.py:5-36): per level  im * conv1x1(x + ia)."""
+
+    def __init__(self, num_classes, num_anchors, in_channels):
+        super().__init__()
+        self.n_anchors = num_anchors
+        self.num_classes = num_classes
+        ch = self.n_anchors * (5 + num_classes)
+        self.conv = nn.ModuleList()
+        self.ia = nn.ModuleList()
+        self.im = nn.ModuleList()
+        for i in range(len(in_channels)):
+            self.ia.append(ImplicitA(in_channels[i]))
+            self.conv.append(nn.Conv2d(in_channels[i], ch, 1))
+            self.im.append(ImplicitM(ch))
+
+    def emit(self, g, inputs, head_buffers):
+        for k, x in enumerate(inputs):
+            G.ImplicitHeadOp(g, head_buffers, k, x, self.conv[k], self.ia[k].implicit, self.im[k].implicit)
+        return head_buffers

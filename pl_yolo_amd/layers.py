@@ -136,3 +136,26 @@ class SPPBottleneck(HipModule):
         x = self.conv1.emit(g, x)
         pools = G.SppPoolsOp(g, x, self.kernel_sizes)
         return self.conv2.emit(g, g.concat([x] + pools.outs))
+
+
+class SPPCSPC(HipModule):
+    """YOLOv7 SPP-CSP block (network_blocks.py:158-175): all convs use the default bn/silu."""
+
+    def __init__(self, c1, c2, k=(5, 9, 13)):
+        super().__init__()
+        self.cv1 = BaseConv(c1, c2, 1, 1)
+        self.cv2 = BaseConv(c1, c2, 1, 1)
+        self.cv3 = BaseConv(c2, c2, 3, 1)
+        self.cv4 = BaseConv(c2, c2, 1, 1)
+        self.m = nn.ModuleList([nn.MaxPool2d(kernel_size=x, stride=1, padding=x // 2) for x in k])
+        self.kernel_sizes = tuple(k)
+        self.cv5 = BaseConv(4 * c2, c2, 1, 1)
+        self.cv6 = BaseConv(c2, c2, 3, 1)
+        self.cv7 = BaseConv(2 * c2, c2, 1, 1)
+
+    def emit(self, g, x):
+        x1 = self.cv4.emit(g, self.cv3.emit(g, self.cv1.emit(g, x)))
+        pools = G.SppPoolsOp(g, x1, self.kernel_sizes)
+        y1 = self.cv6.emit(g, self.cv5.emit(g, g.concat([x1] + pools.outs)))
+        y2 = self.cv2.emit(g, x)
+        return self.cv7.emit(g, g.concat([y1, y2]))

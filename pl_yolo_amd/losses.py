@@ -27,3 +27,26 @@ class YOLOXLoss(nn.Module):
             G.YoloxLossOp(g, head_buffers)
         else:
             G.YoloxEvalDecodeOp(g, head_buffers)
+
+
+class YOLOv7Loss(nn.Module):
+    """YOLOv7 loss plugin (reference models/losses/yolov7/yolov7_loss.py:9-415).  Eval decode
+    (:50-78) runs on the device (csrc/yolox_loss.hip: k_v7_eval_decode); the training branch
+    (find_3_positive / build_targets / CIoU loss, :80-368) is not built yet."""
+
+    def __init__(self, num_classes, strides, anchors, label_smoothing=0, focal_g=0.0):
+        super().__init__()
+        self.num_classes = num_classes
+        self.strides = strides
+        self.anchors_list = anchors
+        self.nl = len(strides)
+        self.na = len(anchors[0])
+        self.ch = 5 + num_classes
+
+    def __call__(self, inputs, targets):
+        raise RuntimeError("YOLOv7Loss is driven by the detector's launch plan (OneStageD.forward)")
+
+    def emit(self, g, head_buffers, training):
+        if training:
+            raise NotImplementedError("YOLOv7 training loss has no HIP kernel yet")
+        G.YoloV7EvalDecodeOp(g, head_buffers)

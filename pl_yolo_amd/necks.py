@@ -37,3 +37,87 @@ class CSPPAFPN(HipModule):
         n4_downsample = self.downsample_conv2.emit(g, n4)
         n5 = self.n4_n5.emit(g, g.concat([n4_downsample, p5_expand]))
         return (n3, n4, n5)
+
+
+class ELANWLayer(HipModule):
+    """The `CSPLayer` of models/necks/yolov7_neck.py:104-146 (ELAN-W: (num_bottle+3)-way concat)."""
+
+    def __init__(self, in_channel, out_channel, expansion=0.5, num_bottle=1, norm="bn", act="silu"):
+        super().__init__()
+        hi_channel = int(in_channel * expansion)
+        self.num_conv = num_bottle
+        self.conv1 = BaseConv(in_channel, hi_channel, 1, stride=1, norm=norm, act=act)
+        self.conv2 = BaseConv(in_channel, hi_channel, 1, stride=1, norm=norm, act=act)
+        self.conv3 = BaseConv(hi_channel, hi_channel // 2, 1, stride=1, norm=norm, act=act)
+        self.conv4 = nn.ModuleList([BaseConv(hi_channel // 2, hi_channel // 2, 3, stride=1, norm=norm, act=act) for _ in range(num_bottle)])
+        cat_channel = hi_channel // 2 * (num_bottle + 1) + hi_channel * 2
+        self.conv5 = BaseConv(cat_channel, out_channel, 1, stride=1, norm=norm, act=act)
+
+    def emit(self, g, x):
+        x_1 = self.conv1.emit(g, x)
+        x_2 = self.conv2.emit(g, x)
+        x_3 = self.conv3.emit(g, x_2)
+        x_all = [x_1, x_2, x_3]
+        for m in self.conv4:
+            x_3 = m.emit(g, x_3)
+            x_all.append(x_3)
+        return self.conv5.emit(g, g.concat(x_all))
+
+
+class NeckTransition(HipModule):
+    """`Transition` of models/necks/yolov7_neck.py:149-164."""
+
+    def __init__(self, in_channel, out_channel, mpk=2, norm="bn", act="silu"):
+        super().__init__()
+        if mpk != 2:
+            raise NotImplementedError("Transition max-pool kernel is 2x2 stride 2")
+        self.mp = nn.MaxPool2d(kernel_size=mpk, stride=mpk)
+        self.conv1 = BaseConv(in_channel, out_channel // 2, 1, 1)
+        self.conv2 = BaseConv(in_channel, out_channel // 2, 1, 1)
+        self.conv3 = BaseConv(out_channel // 2, out_channel // 2, 3, 2, norm=norm, act=act)
+
+    def emit(self, g, x):
+        x_1 = self.conv1.emit(g, G.MaxPool2x2Op(g, x).out)
+        x_2 = self.conv3.emit(g, self.conv2.emit(g, x))
+        return g.concat([x_2, x_1])
+
+
+class YOLOv7NECK(HipModule):
+    """models/necks/yolov7_neck.py:7-101.  (RepConv, :167-348, is defined upstream but never
+    instantiated by any config -- n3/n4/n5 are plain BaseConv, :67-69.)"""
+
+    def __init__(self, depths=(1, 1, 1, 1), in_channels=(512, 1024, 1024), norm="bn", act="silu"):
+        super().__init__()
+        from .layers import SPPCSPC
+        c = in_channels
+        self.spp = SPPCSPC(c[2], c[2] // 2, k=(5, 9, 13))
+        self.conv_for_P5 = BaseConv(c[2] // 2, c[2] // 4, 1, 1, norm=norm, act=act)
+        self.upsample = nn.Upsample(scale_factor=2, mode="nearest")
+        self.conv_for_C4 = BaseConv(c[1], c[2] // 4, 1, 1, norm=norm, act=act)
+        self.p5_p4 = ELANWLayer(c[2] // 2, c[2] // 4, expansion=0.5, num_bottle=depths[0], norm=norm, act=act)
+        self.conv_for_P4 = BaseConv(c[2] // 4, c[2] // 8, 1, 1, norm=norm, act=act)
+        self.conv_for_C3 = BaseConv(c[0], c[2] // 8, 1, 1, norm=norm, act=act)
+        self.p4_p3 = ELANWLayer(c[2] // 4, c[2] // 8, expansion=0.5, num_bottle=depths[0], norm=norm, act=act)
+        self.downsample_conv1 = NeckTransition(c[2] // 8, c[2] // 4, mpk=2, norm=norm, act=act)
+        self.n3_n4 = ELANWLayer(c[2] // 2, c[2] // 4, expansion=0.5, num_bottle=depths[0], norm=norm, act=act)
+        self.downsample_conv2 = NeckTransition(c[2] // 4, c[2] // 2, mpk=2, norm=norm, act=act)
+        self.n4_n5 = ELANWLayer(c[2], c[2] // 2, expansion=0.5, num_bottle=depths[0], norm=norm, act=act)
+        self.n3 = BaseConv(c[2] // 8, c[2] // 4, 3, 1, norm=norm, act=act)
+        self.n4 = BaseConv(c[2] // 4, c[2] // 2, 3, 1, norm=norm, act=act)
+        self.n5 = BaseConv(c[2] // 2, c[2], 3, 1, norm=norm, act=act)
+
+    def emit(self, g, inputs):
+        c3, c4, c5 = inputs
+        p5 = self.spp.emit(g, c5)
+        p5_shrink = self.conv_for_P5.emit(g, p5)
+        p5_upsample = G.UpsampleOp(g, p5_shrink).out
+        p4 = self.p5_p4.emit(g, g.concat([p5_upsample, self.conv_for_C4.emit(g, c4)]))
+        p4_shrink = self.conv_for_P4.emit(g, p4)
+        p4_upsample = G.UpsampleOp(g, p4_shrink).out
+        p3 = self.p4_p3.emit(g, g.concat([p4_upsample, self.conv_for_C3.emit(g, c3)]))
+        n3 = p3
+        n3_downsample = self.downsample_conv1.emit(g, n3)
+        n4 = self.n3_n4.emit(g, g.concat([n3_downsample, p4]))
+        n4_downsample = self.downsample_conv2.emit(g, n4)
+        n5 = self.n4_n5.emit(g, g.concat([n4_downsample, p5]))
+        return (self.n3.emit(g, n3), self.n4.emit(g, n4), self.n5.emit(g, n5))

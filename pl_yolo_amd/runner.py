@@ -117,8 +117,11 @@ class DetectorRunner:
         g.grad_ptr_of = self.grad_ptr_of
         s = _Session()
         s.g, s.mode, s.B, s.H, s.W, s.M = g, mode, B, H, W, M
-        cp = 16 if self.dtype == BF16 else 12
-        image = g.new_act(B, H // 2, W // 2, cp, "focus")
+        s.stem_kind = getattr(model.backbone, "stem_kind", "focus")
+        if s.stem_kind == "focus":   # CSPDarkNet: space-to-depth gather (12 real channels)
+            image = g.new_act(B, H // 2, W // 2, 16 if self.dtype == BF16 else 12, "focus")
+        else:                         # EELAN: plain RGB image, padded to a 16-byte channel vector
+            image = g.new_act(B, H, W, 8 if self.dtype == BF16 else 4, "rgb")
         s.image = image
         feats = model.backbone.emit(g, image)
         if model.neck is not None:
@@ -129,7 +132,16 @@ class DetectorRunner:
         strides = list(model.loss.strides) if model.loss is not None else [W // f.W for f in feats]
         if len(strides) != len(feats):
             raise PlyoloError("loss.stride has %d entries for %d feature levels" % (len(strides), len(feats)))
-        head = G.HeadBuffers(g, B, nc, [(f.H, f.W) for f in feats], strides, max(M, 1))
+        if model.head.n_anchors == 1:
+            head = G.HeadBuffers(g, B, nc, [(f.H, f.W) for f in feats], strides, max(M, 1))
+        else:
+            anchors = getattr(model.loss, "anchors_list", None)
+            if anchors is None:
+                raise PlyoloError("anchor-based head needs a loss plugin with anchors (yolov7)")
+            head = G.V7HeadBuffers(g, B, nc, model.head.n_anchors, [(f.H, f.W) for f in feats], strides, anchors)
+            if mode == "train":
+                raise NotImplementedError("the YOLOv7 training loss (models/losses/yolov7/yolov7_loss.py:80-368) has no HIP kernel "
+                                          "yet; use labels=None (raw maps, differentiable) or eval mode")
         s.head = head
         model.head.emit(g, feats, head)
         if mode == "train":
@@ -158,6 +170,8 @@ class DetectorRunner:
                 for op in reversed(g.ops):
                     op.bwd()
                 call("plyolo_unpack_wgrads", g.pack_table.data_ptr(), g.n_pack, g.max_pack_elems, 0, None)
+                for op in g.post_unpack:
+                    op.post_unpack()
             seen = set()
             for op in g.ops:
                 if isinstance(op, G.ConvUnitOp) and op.bn is not None:
@@ -168,6 +182,11 @@ class DetectorRunner:
             for (_, w, b) in g.pack_entries:
                 for p in (w, b):
                     if p is not None and id(p) not in seen:
+                        seen.add(id(p))
+                        s.used_params.append(p)
+            for op in g.post_unpack:
+                for p in (op.conv.bias, op.ia, op.im):
+                    if id(p) not in seen:
                         seen.add(id(p))
                         s.used_params.append(p)
             s.used_params = [p for p in s.used_params if p.requires_grad]
@@ -204,8 +223,16 @@ class DetectorRunner:
         return x.contiguous()
 
     def _focus(self, s, x):
+        """Stage the caller's NCHW fp32 image batch (the only per-step pointer) into the plan's
+        NHWC input matrix: Focus gather for CSPDarkNet, plain layout change for EELAN."""
         g = s.g
-        call("plyolo_focus_s2d", g.dtype, x.data_ptr(), s.B, s.H, s.W, g.aptr(s.image), s.image.C, self._stream())
+        if s.stem_kind == "focus":
+            call("plyolo_focus_s2d", g.dtype, x.data_ptr(), s.B, s.H, s.W, g.aptr(s.image), s.image.C, self._stream())
+        else:
+            if not getattr(s, "_img_zeroed", False):
+                s.image.storage.tensor.zero_()  # pad channels stay zero forever
+                s._img_zeroed = True
+            call("plyolo_nchw_f32_to_nhwc", g.dtype, s.B, s.H, s.W, 3, x.data_ptr(), g.aptr(s.image), s.image.ld, self._stream())
 
     def forward_train(self, x, labels):
         x = self._check_input(x)
@@ -231,7 +258,7 @@ class DetectorRunner:
         self._focus(s, x)
         self._run_plan(s.fwd)
         hd = s.head
-        return hd.eval_out.view(B, hd.A, hd.nch).clone()
+        return hd.eval_out.view(hd.eval_shape).clone()
 
     def forward_maps(self, x, want_grad=False):
         x = self._check_input(x)

@@ -320,7 +320,60 @@ def gen_schedule():
     save("lr_schedule", d)
 
 
+def gen_network_v7():
+    """YOLOv7 family (eelan + yolov7neck + implicit_head + yolov7 loss): tiny config."""
+    with open(os.path.join(ROOT, "configs", "model", "yolov7", "yolov7_test.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    C = 3
+    torch.manual_seed(97)
+    model = build_model(cfg, C)
+    g = torch.Generator().manual_seed(6)
+    for n, p in model.named_parameters():
+        if n.endswith(".norm.weight"):
+            p.data = 0.5 + torch.rand(p.shape, generator=g)
+        if n.endswith(".norm.bias"):
+            p.data = torch.rand(p.shape, generator=g) - 0.5
+        if ".im." in n:   # ImplicitM is N(0, .02) upstream: make the head outputs non-trivial
+            p.data = 1.0 + 0.2 * torch.randn(p.shape, generator=g)
+    gen = torch.Generator().manual_seed(4321)
+    x = torch.rand(2, 3, 64, 64, generator=gen) * 255
+    labels = torch.zeros(2, 8, 5)
+    labels[0, :3] = torch.tensor([[0, 20.0, 24.0, 18.0, 22.0], [2, 40.0, 40.0, 30.0, 26.0], [1, 50.0, 14.0, 16.0, 12.0]])
+    labels[1, :2] = torch.tensor([[1, 30.0, 30.0, 40.0, 36.0], [0, 12.0, 50.0, 14.0, 18.0]])
+    d = dict(x=x, labels=labels, num_classes=C)
+    for k, v in model.state_dict().items():
+        d["state/" + k] = v.clone()
+    model.train()
+    maps = model(x)
+    rs = [torch.randn(m.shape, generator=gen) for m in maps]
+    model.zero_grad()
+    sum((m * r).sum() for m, r in zip(maps, rs)).backward()
+    for i, (m, r) in enumerate(zip(maps, rs)):
+        d["maps_train%d" % i] = m.detach().clone()
+        d["r%d" % i] = r
+    for n, p in model.named_parameters():
+        assert p.grad is not None, n
+        d["grad/" + n] = p.grad.clone()
+    for k, v in model.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            d["state_after/" + k] = v.clone()
+    # full training loss of the reference (CPU-only as written), for the loss kernels to come
+    model.zero_grad()
+    out = model(x, labels.clone())
+    out["loss"].backward()
+    d["out/loss"] = out["loss"].detach()
+    for n, p in model.named_parameters():
+        if p.grad is not None:
+            d["lossgrad/" + n] = p.grad.clone()
+    model.eval()
+    with torch.no_grad():
+        d["eval_out"] = model(x, labels).clone()
+    print("yolov7 fixture: loss=%.6f eval %s" % (float(out["loss"]), tuple(d["eval_out"].shape)))
+    save("network_yolov7_test", d)
+
+
 if __name__ == "__main__":
+    gen_network_v7()
     gen_loss_cases()
     gen_blocks()
     gen_network()
