@@ -44,6 +44,12 @@ def synthetic(batch, size, nc, seed, num_gt=30, max_gt=100):
     return imgs, labels
 
 
+def _fresh_state(cfg, nc):
+    from oracle import net as onet
+    torch.manual_seed(96)
+    return onet.build_state(cfg, nc)
+
+
 def cpu_baseline(cfg, nc, size, budget_s=25.0):
     """The oracle (port of the reference path) on the host cores, bounded sample."""
     from oracle import net as onet, detector as odet
@@ -59,7 +65,8 @@ def cpu_baseline(cfg, nc, size, budget_s=25.0):
     for _ in range(steps):
         odet.train_step_grads(state, cfg, nc, imgs, labels)
     dt = (time.time() - t0) / steps
-    return {"value": b / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+    ref_loss = float(odet.train_step_grads(onet.build_state(cfg, nc) if False else _fresh_state(cfg, nc), cfg, nc, imgs, labels)[0]["loss"].detach())
+    return {"value": b / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port", "loss_b4": ref_loss,
             "sample": "oracle (pure-PyTorch fp32 port of OneStageD fwd+loss+bwd), %s %dx%d, batch %d, %d timed steps after 1 warm-up"
                       % (cfg.get("_name", "model"), size, size, b, steps)}
 
@@ -232,6 +239,17 @@ def main():
             result["nms"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(cfg, nc, args.size)
+            # parity spot-check at the benchmark's own resolution: same weights (seed 96), same
+            # synthetic batch of 4 -> HIP bf16 loss vs the oracle's fp32 loss
+            torch.manual_seed(96)
+            m4 = pl_yolo_amd.build_model(cfg, nc)
+            m4.compute_dtype = "bf16"
+            m4 = m4.to(dev).train()
+            i4, l4 = synthetic(4, args.size, nc, 1234)
+            hip_loss = float(m4(i4.to(dev), l4.to(dev))["loss"].detach())
+            ref_loss = result["cpu_baseline"].pop("loss_b4")
+            result["parity_check"] = {"batch": 4, "hip_bf16_loss": hip_loss, "oracle_fp32_loss": ref_loss,
+                                      "rel_diff": abs(hip_loss - ref_loss) / abs(ref_loss)}
         print(json.dumps(result))
     if dist is not None:
         dist.barrier()

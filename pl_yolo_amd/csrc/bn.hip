@@ -338,15 +338,18 @@ using plyolo::submit;
 
 extern "C" {
 
-size_t plyolo_bn_finalize_workspace(int C) { return (size_t)FIN_CHUNKS * 2 * C * sizeof(double) + ((size_t)(C + 31) / 32) * sizeof(unsigned) + 64; }
+// layout: arrival counters FIRST (fixed offset: the workspace is shared by layers of different C),
+// chunk partials after them
+constexpr size_t FIN_COUNTER_BYTES = 1024;  // up to 256 column blocks = 8192 channels
+size_t plyolo_bn_finalize_workspace(int C) { return FIN_COUNTER_BYTES + (size_t)FIN_CHUNKS * 2 * C * sizeof(double); }
 
 int plyolo_bn_finalize(const float* stats, int rows, int C, double count, const float* gamma, const float* beta, float eps,
                        float momentum, float* running_mean, float* running_var, int64_t* nbt, float* coef, void* workspace,
                        size_t ws_bytes, void* stream) {
   PLY_CHECK_ARG(workspace != nullptr && ws_bytes >= plyolo_bn_finalize_workspace(C), "bn_finalize: workspace too small");
   FinWs ws;
-  ws.part = (double*)workspace;
-  ws.counter = (unsigned*)((unsigned char*)workspace + (size_t)FIN_CHUNKS * 2 * C * sizeof(double));
+  ws.counter = (unsigned*)workspace;
+  ws.part = (double*)((unsigned char*)workspace + FIN_COUNTER_BYTES);
   int nchunk = rows / 32;
   if (nchunk < 1) nchunk = 1;
   if (nchunk > FIN_CHUNKS) nchunk = FIN_CHUNKS;
@@ -419,8 +422,8 @@ int plyolo_bn_bwd_finalize(const float* partial, int rows, int C, double count, 
                            float* dgamma, float* dbeta, int accumulate, float* bcoef, void* workspace, size_t ws_bytes, void* stream) {
   PLY_CHECK_ARG(workspace != nullptr && ws_bytes >= plyolo_bn_finalize_workspace(C), "bn_bwd_finalize: workspace too small");
   FinWs ws;
-  ws.part = (double*)workspace;
-  ws.counter = (unsigned*)((unsigned char*)workspace + (size_t)FIN_CHUNKS * 2 * C * sizeof(double));
+  ws.counter = (unsigned*)workspace;
+  ws.part = (double*)((unsigned char*)workspace + FIN_COUNTER_BYTES);
   int nchunk = rows / 32;
   if (nchunk < 1) nchunk = 1;
   if (nchunk > FIN_CHUNKS) nchunk = FIN_CHUNKS;

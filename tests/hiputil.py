@@ -38,7 +38,7 @@ def rnd_bf16(x):
 class Packed:
     """Pack one conv weight (+bias) through plyolo_pack_weights."""
 
-    def __init__(self, w, dt, bias=None, cin_p=None, nslab=64):
+    def __init__(self, w, dt, bias=None, cin_p=None, nslab=256):
         Cout, Cin, k, _ = w.shape
         self.w = w.contiguous()
         self.Cin_p = cin_p or Cin

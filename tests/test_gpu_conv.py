@@ -30,6 +30,9 @@ SHAPES = [
     (1, 12, 12, 8, 16, 1, 1),       # K tail (Cin 8 < MFMA K 16), 144 pixels (flatten ok)
     (1, 10, 10, 24, 40, 1, 1),      # 100 pixels: not a multiple of 16 -> 2-D tiling of a 1x1
     (2, 16, 16, 8, 16, 3, 2),
+    (2, 32, 32, 32, 8, 3, 2),       # Cout 8: a single 16-byte output vector per pixel
+    (2, 16, 16, 16, 8, 1, 1),
+    (1, 160, 160, 32, 8, 3, 2),
 ]
 
 

@@ -215,3 +215,26 @@ def test_sgd_ema():
     torch.cuda.synchronize()
     assert hu.relerr(p, ref_p.data) < 1e-6
     assert hu.relerr(ema, ema_ref) < 1e-6
+
+
+def test_bn_finalize_shared_workspace_across_layers():
+    """One finalize workspace serves layers of different widths back to back (as the launch
+    plans do): the arrival counters must not alias another layer's chunk partials."""
+    torch.manual_seed(8)
+    wsb = hu._lib.lib().plyolo_bn_finalize_workspace(256)
+    fws = torch.zeros(wsb, dtype=torch.uint8, device=hu.DEV)
+    for rep in range(2):
+        for Cc in (256, 64, 32, 8, 128, 32):
+            rows, M = 2000, 2000 * 128
+            stats = torch.rand(2, rows, Cc, device=hu.DEV) * 100
+            stats[1] += 200 * 128
+            g, b = torch.rand(Cc, device=hu.DEV) + 0.5, torch.rand(Cc, device=hu.DEV)
+            coef = torch.zeros(4 * Cc, device=hu.DEV)
+            call("plyolo_bn_finalize", stats.data_ptr(), rows, Cc, float(M), g.data_ptr(), b.data_ptr(), 1e-3, 0.03,
+                 None, None, None, coef.data_ptr(), fws.data_ptr(), wsb, hu.stream())
+            torch.cuda.synchronize()
+            mean = stats[0].double().sum(0) / M
+            var = stats[1].double().sum(0) / M - mean * mean
+            want = (1 / torch.sqrt(var + 1e-3)).float()
+            assert hu.relerr(coef[3 * Cc:], want) < 1e-5, (rep, Cc)
+            assert hu.relerr(coef[2 * Cc:3 * Cc], mean.float()) < 1e-5, (rep, Cc)
