@@ -207,6 +207,12 @@ int plyolo_maxpool_s1_bwd(int dtype, int N, int H, int W, int C, int k, const vo
                           const void* dout, int d_ld, float* din_f32, void* stream);
 /* MaxPool2d(2, stride 2) of the YOLOv7 Transition blocks (models/backbones/eelan.py:126-141,
  * models/necks/yolov7_neck.py:149-164); bwd routes to the first maximum (ATen rule). */
+/* Backward of all stride-1 pools of one SPP block (network_blocks.py:141-153 under autograd) in one
+ * launch: din (+)= sum_j scatter_kj(douts[j]) with ATen's first-maximum rule.  douts[j] may be NULL
+ * (that pool's output received no gradient).  Requires plyolo_spp_pools_bwd_fits(dtype,H,W). */
+int plyolo_spp_pools_bwd_fits(int dtype, int H, int W);
+int plyolo_spp_pools_bwd(int dtype, int N, int H, int W, int C, int nk, const int* ks, const void* in, int i_ld,
+                         const void* const* douts, const int* d_lds, void* din, int di_ld, int accumulate, void* stream);
 int plyolo_maxpool2x2_fwd(int dtype, int N, int H, int W, int C, const void* in, int i_ld, void* out, int o_ld,
                           void* stream);
 int plyolo_maxpool2x2_bwd(int dtype, int N, int H, int W, int C, const void* in, int i_ld, const void* dout,

@@ -161,6 +161,76 @@ __global__ void maxpool_bwd_kernel(int N, int H, int W, int C, int k, const T* i
   }
 }
 
+// Backward of ALL the stride-1 pools of one SPP block in one launch.  One workgroup owns an
+// (image, 8-channel group) plane held in LDS: the first-maximum argmax of a k x k window is
+// separable (first row holding the window maximum, first column of that row's maximum), so each
+// pool costs 2k LDS reads per element instead of k*k global reads; the routed gradients are
+// accumulated in LDS and written once (no fp32 scratch image, no global atomics).
+constexpr int SPP_CG = 8;
+template <typename T>
+__global__ __launch_bounds__(256) void spp_pools_bwd_kernel(int H, int W, int C, int nk, int k0, int k1, int k2, const T* __restrict__ in,
+                                                            int i_ld, const T* d0, const T* d1, const T* d2, int dl0, int dl1, int dl2,
+                                                            T* din, int di_ld, int accumulate) {
+  extern __shared__ __align__(16) unsigned char spp_smem[];
+  const int HW = H * W, n = blockIdx.x, c0 = blockIdx.y * SPP_CG;
+  float* gs = (float*)spp_smem;                              // [HW][8] routed gradient
+  T* xs = (T*)(gs + (size_t)HW * SPP_CG);                    // [HW][8] input plane
+  T* rv = xs + (size_t)HW * SPP_CG;                          // [HW][8] row-pass maximum
+  unsigned short* ra = (unsigned short*)(rv + (size_t)HW * SPP_CG);  // [HW][8] its column
+  const int items = HW * SPP_CG;
+  for (int it = threadIdx.x; it < items; it += 256) {
+    const int p = it / SPP_CG, ch = it % SPP_CG;
+    xs[it] = (c0 + ch < C) ? in[((size_t)n * HW + p) * i_ld + c0 + ch] : (T)0;
+    gs[it] = 0.f;
+  }
+  __syncthreads();
+  for (int j = 0; j < nk; ++j) {
+    const int k = j == 0 ? k0 : (j == 1 ? k1 : k2);
+    const T* dout = j == 0 ? d0 : (j == 1 ? d1 : d2);
+    const int dl = j == 0 ? dl0 : (j == 1 ? dl1 : dl2);
+    if (dout == nullptr) continue;
+    const int rad = k / 2;
+    for (int it = threadIdx.x; it < items; it += 256) {
+      const int p = it / SPP_CG, ch = it % SPP_CG;
+      const int y = p / W, x = p - y * W;
+      const int xa = max(0, x - rad), xb = min(W - 1, x + rad);
+      float best = ActT<T>::ld(xs + (y * W + xa) * SPP_CG + ch);
+      int ax = xa;
+      for (int xx = xa + 1; xx <= xb; ++xx) {
+        const float v = ActT<T>::ld(xs + (y * W + xx) * SPP_CG + ch);
+        if (v > best) { best = v; ax = xx; }
+      }
+      ActT<T>::st(rv + it, best);
+      ra[it] = (unsigned short)ax;
+    }
+    __syncthreads();
+    for (int it = threadIdx.x; it < items; it += 256) {
+      const int p = it / SPP_CG, ch = it % SPP_CG;
+      if (c0 + ch >= C) continue;
+      const int y = p / W, x = p - y * W;
+      const int ya = max(0, y - rad), yb = min(H - 1, y + rad);
+      float best = ActT<T>::ld(rv + (ya * W + x) * SPP_CG + ch);
+      int ay = ya;
+      for (int yy = ya + 1; yy <= yb; ++yy) {
+        const float v = ActT<T>::ld(rv + (yy * W + x) * SPP_CG + ch);
+        if (v > best) { best = v; ay = yy; }
+      }
+      const int arg = ay * W + ra[(ay * W + x) * SPP_CG + ch];
+      const float g = ActT<T>::ld(dout + ((size_t)n * HW + p) * dl + c0 + ch);
+      atomicAdd(gs + arg * SPP_CG + ch, g);
+    }
+    __syncthreads();
+  }
+  for (int it = threadIdx.x; it < items; it += 256) {
+    const int p = it / SPP_CG, ch = it % SPP_CG;
+    if (c0 + ch >= C) continue;
+    T* dst = din + ((size_t)n * HW + p) * di_ld + c0 + ch;
+    float v = gs[it];
+    if (accumulate) v += ActT<T>::ld(dst);
+    ActT<T>::st(dst, v);
+  }
+}
+
 // MaxPool2d(kernel 2, stride 2) of the YOLOv7 Transition blocks (reference
 // models/backbones/eelan.py:129, models/necks/yolov7_neck.py:152): forward, and the backward
 // that routes dout to the FIRST maximum of each 2x2 window in row-major order (ATen rule).
@@ -491,6 +561,39 @@ int plyolo_maxpool_s1_bwd(int dtype, int N, int H, int W, int C, int k, const vo
   return submit(stream, [=](hipStream_t s) -> hipError_t {
     DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(grid_for(work)), dim3(256), 0, s, N, H, W, C, k, (const T*)in, i_ld,
                                          (const T*)dout, d_ld, din_f32);)
+    return hipGetLastError();
+  });
+}
+
+static size_t spp_bwd_lds(int dtype, int H, int W) {
+  const size_t es = dtype == PLYOLO_BF16 ? 2 : 4;
+  return (size_t)H * W * SPP_CG * (4 + 2 * es + 2);
+}
+
+int plyolo_spp_pools_bwd_fits(int dtype, int H, int W) { return H * W <= 65535 && spp_bwd_lds(dtype, H, W) <= 150 * 1024 ? 1 : 0; }
+
+int plyolo_spp_pools_bwd(int dtype, int N, int H, int W, int C, int nk, const int* ks, const void* in, int i_ld,
+                         const void* const* douts, const int* d_lds, void* din, int di_ld, int accumulate, void* stream) {
+  PLY_CHECK_ARG(nk >= 1 && nk <= 3 && ks && douts && d_lds, "spp_pools_bwd: 1..3 pools");
+  PLY_CHECK_ARG(plyolo_spp_pools_bwd_fits(dtype, H, W), "spp_pools_bwd: %dx%d plane does not fit in LDS (use plyolo_maxpool_s1_bwd)", H, W);
+  int k[3] = {1, 1, 1}, dl[3] = {0, 0, 0};
+  const void* d[3] = {nullptr, nullptr, nullptr};
+  for (int j = 0; j < nk; ++j) {
+    PLY_CHECK_ARG(ks[j] & 1, "spp_pools_bwd: k must be odd");
+    k[j] = ks[j]; d[j] = douts[j]; dl[j] = d_lds[j];
+  }
+  const size_t lds = spp_bwd_lds(dtype, H, W);
+  plyolo::annotate("spp_pools_bwd", 0.0, (double)N * H * W * C * (dtype == PLYOLO_BF16 ? 2.0 : 4.0) * (2.0 + nk));
+  return submit(stream, [=](hipStream_t s) -> hipError_t {
+    DISPATCH_T(dtype, {
+      auto kern = spp_pools_bwd_kernel<T>;
+      if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+      }
+      hipLaunchKernelGGL(kern, dim3(N, cdiv(C, SPP_CG)), dim3(256), lds, s, H, W, C, nk, k[0], k[1], k[2], (const T*)in, i_ld,
+                         (const T*)d[0], (const T*)d[1], (const T*)d[2], dl[0], dl[1], dl[2], (T*)din, di_ld, accumulate);
+    })
     return hipGetLastError();
   });
 }

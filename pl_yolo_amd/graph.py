@@ -427,6 +427,14 @@ class SppPoolsOp:
         ready = [g.grad_ready(o) for o in self.outs]
         if not any(ready):
             return
+        if _lib.lib().plyolo_spp_pools_bwd_fits(g.dtype, x.H, x.W):
+            nk = len(self.ks)
+            ks = (C.c_int * nk)(*self.ks)
+            douts = (C.c_void_p * nk)(*[g.gptr(o) if r else None for o, r in zip(self.outs, ready)])
+            dlds = (C.c_int * nk)(*[o.ld for o in self.outs])
+            call("plyolo_spp_pools_bwd", g.dtype, x.N, x.H, x.W, x.C, nk, ks, g.aptr(x), x.ld, douts, dlds,
+                 g.gptr(x), x.ld, g.grad_mode(x), None)
+            return
         n = x.M * x.C
         call("plyolo_memset_async", g.scratch32.data_ptr(), 0, n * 4, None)
         for k, o, r in zip(self.ks, self.outs, ready):

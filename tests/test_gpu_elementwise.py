@@ -175,6 +175,23 @@ def test_copy_upsample_pool(dt):
         call("plyolo_maxpool_s1_bwd", dt, N, H, W, Cc, k, xm.data_ptr(), Cc + 8, gym.data_ptr(), Cc, acc.data_ptr(), hu.stream())
         torch.cuda.synchronize()
         assert hu.relerr(acc.reshape(N, H, W, Cc).permute(0, 3, 1, 2), gx) <= 1e-5, k
+    # all three SPP pools routed in one launch (with ties: bf16 inputs repeat values), accumulate on/off
+    import ctypes as C
+    gys, want = [], torch.zeros_like(x)
+    for k in (5, 9, 13):
+        xr = x.clone().requires_grad_(True)
+        y = F.max_pool2d(xr, k, 1, k // 2)
+        gy = hu.rnd_bf16(torch.randn_like(y)) if dt == BF16 else torch.randn_like(y)
+        want += torch.autograd.grad(y, xr, gy)[0]
+        gys.append(hu.to_nhwc(gy, dt, Cc + 8))
+    assert hu._lib.lib().plyolo_spp_pools_bwd_fits(dt, H, W) == 1
+    for accumulate in (0, 1):
+        din = hu.to_nhwc(torch.ones_like(x), dt, Cc)
+        call("plyolo_spp_pools_bwd", dt, N, H, W, Cc, 3, (C.c_int * 3)(5, 9, 13), xm.data_ptr(), Cc + 8,
+             (C.c_void_p * 3)(*[t.data_ptr() for t in gys]), (C.c_int * 3)(Cc + 8, Cc + 8, Cc + 8), din.data_ptr(), Cc,
+             accumulate, hu.stream())
+        torch.cuda.synchronize()
+        assert hu.relerr(hu.from_nhwc(din, N, H, W, Cc), want + accumulate) <= _tol(dt, 1e-5, 2.0 ** -6), accumulate
     # cascade identity used by the SPP forward: pool9(x) == pool5(pool5(x))
     p5 = torch.zeros(N * H * W, Cc, dtype=hu.tdtype(dt), device=hu.DEV)
     p9 = torch.zeros_like(p5)
