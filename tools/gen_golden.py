@@ -372,7 +372,75 @@ def gen_network_v7():
     save("network_yolov7_test", d)
 
 
+V7_ANCHORS = [[[12, 16], [19, 36], [40, 28]], [[36, 75], [76, 55], [72, 146]], [[142, 110], [192, 243], [459, 401]]]
+
+
+def _v7_case(name, B, nc, H, W, labels, seed, scale=1.5):
+    """Run the reference YOLOv7Loss (train branch) on seeded head maps; record what build_targets
+    returned, the loss and d loss / d head maps."""
+    from models.losses.yolov7.yolov7_loss import YOLOv7Loss
+    strides = [8, 16, 32]
+    loss = YOLOv7Loss(nc, strides, V7_ANCHORS)
+    loss.train()
+    gen = torch.Generator().manual_seed(seed)
+    maps = [(torch.randn(B, 3 * (5 + nc), H // s, W // s, generator=gen) * scale).requires_grad_(True) for s in strides]
+    rec = {}
+    orig = loss.build_targets
+
+    def spy(predictions, targets):
+        r = orig(predictions, targets)
+        rec["r"] = r
+        return r
+
+    loss.build_targets = spy
+    out = loss([m for m in maps], labels.clone())
+    out["loss"].backward()
+    d = dict(labels=labels, num_classes=nc, strides=np.asarray(strides), anchors=np.asarray(V7_ANCHORS), loss=out["loss"].detach())
+    for i, m in enumerate(maps):
+        d["map%d" % i] = m.detach()
+        d["dmap%d" % i] = m.grad
+    bs, as_, gjs, gis, tg, an = rec["r"]
+    for i in range(3):
+        d["m%d_b" % i] = bs[i].long(); d["m%d_a" % i] = as_[i].long(); d["m%d_gj" % i] = gjs[i].long(); d["m%d_gi" % i] = gis[i].long()
+        d["m%d_t" % i] = tg[i].reshape(-1, 6) if tg[i].numel() else torch.zeros(0, 6)
+        d["m%d_anch" % i] = an[i].reshape(-1, 2) if an[i].numel() else torch.zeros(0, 2)
+    print(name, "loss %.6f matched per level" % float(out["loss"]), [int(b.shape[0]) for b in bs])
+    save(name, d)
+
+
+def gen_v7loss_cases():
+    # A: hand-placed GTs: overlapping pair in one cell, border boxes (index clamps), a 2x2 px box that
+    #    no anchor accepts, an image without GTs
+    lab = torch.zeros(3, 10, 5)
+    lab[0, :6] = torch.tensor([[0, 40.0, 44.0, 30.0, 36.0], [2, 42.0, 46.0, 26.0, 40.0], [1, 120.0, 30.0, 60.0, 50.0],
+                               [4, 4.0, 150.0, 14.0, 18.0], [3, 156.0, 156.0, 20.0, 16.0], [0, 80.0, 80.0, 150.0, 140.0]])
+    lab[2, :3] = torch.tensor([[1, 60.0, 100.0, 90.0, 40.0], [2, 100.0, 20.0, 2.0, 2.0], [0, 30.0, 30.0, 12.0, 16.0]])
+    _v7_case("v7loss_case_A", 3, 5, 160, 160, lab, 11)
+    # B: random, 80 classes, up to 20 GTs
+    gen = torch.Generator().manual_seed(5)
+    Bn, M, S = 3, 24, 192
+    lab = torch.zeros(Bn, M, 5)
+    for b, n in enumerate([20, 7, 13]):
+        lab[b, :n, 0] = torch.randint(0, 20, (n,), generator=gen).float()
+        lab[b, :n, 1:3] = torch.rand(n, 2, generator=gen) * S * 0.9 + S * 0.05
+        lab[b, :n, 3:5] = torch.exp(torch.rand(n, 2, generator=gen) * 3.2 + 1.8)
+    _v7_case("v7loss_case_B", Bn, 20, S, S, lab, 12)
+    # E: near-zero logits (decoded boxes = anchors at cell centres) so IoUs are large and dynamic k > 1
+    _v7_case("v7loss_case_E", Bn, 20, S, S, lab, 15, scale=0.3)
+    # C: no GT anywhere (objectness negatives only)
+    _v7_case("v7loss_case_C", 2, 3, 64, 64, torch.zeros(2, 4, 5), 13)
+    # D: non-square input, confident (large-magnitude) logits
+    lab = torch.zeros(2, 6, 5)
+    lab[0, :4] = torch.tensor([[1, 30.0, 60.0, 40.0, 30.0], [0, 170.0, 100.0, 36.0, 80.0], [2, 96.0, 64.0, 100.0, 90.0], [1, 185.0, 10.0, 20.0, 16.0]])
+    lab[1, :2] = torch.tensor([[0, 96.0, 64.0, 180.0, 120.0], [2, 10.0, 120.0, 18.0, 14.0]])
+    _v7_case("v7loss_case_D", 2, 3, 128, 192, lab, 14, scale=3.0)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "v7loss":
+        gen_v7loss_cases()
+        sys.exit(0)
+    gen_v7loss_cases()
     gen_network_v7()
     gen_loss_cases()
     gen_blocks()
