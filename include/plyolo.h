@@ -276,6 +276,28 @@ int plyolo_yolox_eval_decode(const plyolo_yolox_desc* d, const float* raw, float
 int plyolo_yolov7_eval_decode(const float* raw_level, int B, int h, int w, int na, int nc, int stride,
                               const float* anchors_dev, float* out, int A_total, int lvl_off, void* stream);
 
+/* YOLOv7 training loss (models/losses/yolov7/yolov7_loss.py:80-153 with build_targets :155-306,
+ * find_3_positive :308-368, bbox_iou(CIoU) :376-410) on the level-major raw head output
+ * (level l = dense fp32 NHWC [B, h_l, w_l, na*(5+C)] starting at row lvl_row[l]).
+ * labels [B,M,5] rows (cls,cx,cy,w,h) in pixels, zero padded.  losses[4] = loss, box, obj, cls
+ * (already weighted: 0.05 / 1 / 0.5*C/80).  loss_bwd: draw (same layout as raw) = gout * dloss/draw.
+ * Ties among equal costs/IoUs go to the lowest candidate index (the reference's torch.topk leaves
+ * them unspecified); candidates are enumerated in the reference's order. */
+typedef struct plyolo_yolov7_desc {
+  int B, M, C, na, nlevels;              /* na = 3, nlevels = 3 */
+  int lvl_h[3], lvl_w[3], lvl_stride[3], lvl_row[3];
+  float anchors[3][3][2];                /* pixels, [level][anchor][w,h] */
+  int cand_cap;                          /* per-image candidate capacity, >= 45*M */
+} plyolo_yolov7_desc;
+size_t plyolo_yolov7_workspace(const plyolo_yolov7_desc* d);
+int plyolo_yolov7_loss_fwd(const plyolo_yolov7_desc* d, const float* raw, const float* labels, float* losses,
+                           void* workspace, size_t ws_bytes, void* stream);
+int plyolo_yolov7_loss_bwd(const plyolo_yolov7_desc* d, const float* raw, const float* labels, float gout, float* draw,
+                           void* workspace, size_t ws_bytes, void* stream);
+/* diagnostics/tests: counts[B] and entries[B][cand_cap][6] = (level, anchor, gj, gi, gt row, last) */
+int plyolo_yolov7_matched(const plyolo_yolov7_desc* d, const void* workspace, int32_t* counts_dev, int32_t* entries_dev,
+                          void* stream);
+
 /* ----------------------------------------------------------- postprocess
  * Replaces postprocess() (models/evaluators/postprocess.py:7-48) including
  * torchvision.ops.batched_nms / nms (un-vendored third party; algorithm per

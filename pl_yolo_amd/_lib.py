@@ -44,6 +44,30 @@ class YoloxDesc(C.Structure):
     ]
 
 
+class YoloV7Desc(C.Structure):
+    _fields_ = [
+        ("B", C.c_int), ("M", C.c_int), ("C", C.c_int), ("na", C.c_int), ("nlevels", C.c_int),
+        ("lvl_h", C.c_int * 3), ("lvl_w", C.c_int * 3), ("lvl_stride", C.c_int * 3), ("lvl_row", C.c_int * 3),
+        ("anchors", C.c_float * 18), ("cand_cap", C.c_int),
+    ]
+
+
+def yolov7_desc(B, M, num_classes, sizes, strides, anchors):
+    """sizes [(h,w)]*3, anchors [3][3][2] pixels -> YoloV7Desc for the level-major raw layout."""
+    d = YoloV7Desc()
+    d.B, d.M, d.C, d.na, d.nlevels = B, M, num_classes, 3, 3
+    r = 0
+    for l, ((h, w), s) in enumerate(zip(sizes, strides)):
+        d.lvl_h[l], d.lvl_w[l], d.lvl_stride[l], d.lvl_row[l] = h, w, int(s), r
+        r += B * h * w
+    flat = [float(v) for lv in anchors for a in lv for v in a]
+    assert len(flat) == 18, "yolov7: 3 levels x 3 anchors expected"
+    for i, v in enumerate(flat):
+        d.anchors[i] = v
+    d.cand_cap = 45 * M
+    return d
+
+
 class NmsDesc(C.Structure):
     _fields_ = [
         ("B", C.c_int), ("A", C.c_int), ("C", C.c_int), ("conf_thre", C.c_float), ("nms_thre", C.c_float),
@@ -110,6 +134,10 @@ SIGNATURES = {
     "plyolo_yolox_loss_fwd": (_i, [_P(YoloxDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "plyolo_yolox_loss_bwd": (_i, [_P(YoloxDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "plyolo_yolox_eval_decode": (_i, [_P(YoloxDesc), _vp, _vp, _vp]),
+    "plyolo_yolov7_workspace": (_sz, [_P(YoloV7Desc)]),
+    "plyolo_yolov7_loss_fwd": (_i, [_P(YoloV7Desc), _vp, _vp, _vp, _vp, _sz, _vp]),
+    "plyolo_yolov7_loss_bwd": (_i, [_P(YoloV7Desc), _vp, _vp, _f, _vp, _vp, _sz, _vp]),
+    "plyolo_yolov7_matched": (_i, [_P(YoloV7Desc), _vp, _vp, _vp, _vp]),
     "plyolo_yolov7_eval_decode": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp]),
     "plyolo_postprocess_workspace": (_sz, [_P(NmsDesc)]),
     "plyolo_postprocess": (_i, [_P(NmsDesc), _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
