@@ -280,7 +280,8 @@ int plyolo_yolov7_eval_decode(const float* raw_level, int B, int h, int w, int n
  * find_3_positive :308-368, bbox_iou(CIoU) :376-410) on the level-major raw head output
  * (level l = dense fp32 NHWC [B, h_l, w_l, na*(5+C)] starting at row lvl_row[l]).
  * labels [B,M,5] rows (cls,cx,cy,w,h) in pixels, zero padded.  losses[4] = loss, box, obj, cls
- * (already weighted: 0.05 / 1 / 0.5*C/80).  loss_bwd: draw (same layout as raw) = gout * dloss/draw.
+ * (already weighted: 0.05 / 1 / 0.5*C/80).  loss_bwd: gout = DEVICE pointer to the 4 upstream gradients of
+ * losses[0..3]; draw (same layout as raw) = sum_i gout[i] * d losses[i] / d raw.
  * Ties among equal costs/IoUs go to the lowest candidate index (the reference's torch.topk leaves
  * them unspecified); candidates are enumerated in the reference's order. */
 typedef struct plyolo_yolov7_desc {
@@ -292,7 +293,7 @@ typedef struct plyolo_yolov7_desc {
 size_t plyolo_yolov7_workspace(const plyolo_yolov7_desc* d);
 int plyolo_yolov7_loss_fwd(const plyolo_yolov7_desc* d, const float* raw, const float* labels, float* losses,
                            void* workspace, size_t ws_bytes, void* stream);
-int plyolo_yolov7_loss_bwd(const plyolo_yolov7_desc* d, const float* raw, const float* labels, float gout, float* draw,
+int plyolo_yolov7_loss_bwd(const plyolo_yolov7_desc* d, const float* raw, const float* labels, const float* gout, float* draw,
                            void* workspace, size_t ws_bytes, void* stream);
 /* diagnostics/tests: counts[B] and entries[B][cand_cap][6] = (level, anchor, gj, gi, gt row, last) */
 int plyolo_yolov7_matched(const plyolo_yolov7_desc* d, const void* workspace, int32_t* counts_dev, int32_t* entries_dev,

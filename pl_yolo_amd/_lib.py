@@ -136,7 +136,7 @@ SIGNATURES = {
     "plyolo_yolox_eval_decode": (_i, [_P(YoloxDesc), _vp, _vp, _vp]),
     "plyolo_yolov7_workspace": (_sz, [_P(YoloV7Desc)]),
     "plyolo_yolov7_loss_fwd": (_i, [_P(YoloV7Desc), _vp, _vp, _vp, _vp, _sz, _vp]),
-    "plyolo_yolov7_loss_bwd": (_i, [_P(YoloV7Desc), _vp, _vp, _f, _vp, _vp, _sz, _vp]),
+    "plyolo_yolov7_loss_bwd": (_i, [_P(YoloV7Desc), _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "plyolo_yolov7_matched": (_i, [_P(YoloV7Desc), _vp, _vp, _vp, _vp]),
     "plyolo_yolov7_eval_decode": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp]),
     "plyolo_postprocess_workspace": (_sz, [_P(NmsDesc)]),

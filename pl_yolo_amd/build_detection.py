@@ -69,7 +69,9 @@ class OneStageD(nn.Module):
             return r.forward_maps(x)
         if not self.training:
             return r.forward_eval(x)           # [B, A, 5+C]: x1,y1,x2,y2,sig(obj),sig(cls) (yolox_loss.py:25-36)
-        out = R.train_step(r, x, labels)       # fp32[8], differentiable
+        out = R.train_step(r, x, labels)       # fp32 loss vector, differentiable
+        if isinstance(self.loss, YOLOv7Loss):  # yolov7_loss.py:150-153 returns {"loss": tensor[1]}
+            return {"loss": out[0:1]}
         return {
             "loss": out[0],
             "loss_iou": out[1],

@@ -388,8 +388,8 @@ DEVINL int level_of_row(const plyolo_yolov7_desc& d, size_t row) {
 
 // obj term: sum_l balance_l * mean BCEwl(obj, tobj)  (:140); GRAD: d/d obj logits
 template <bool GRAD>
-__global__ __launch_bounds__(256) void k_v7_obj(const plyolo_yolov7_desc d, const float* raw, V7Ws ws, size_t total, float gout,
-                                                float* draw) {
+__global__ __launch_bounds__(256) void k_v7_obj(const plyolo_yolov7_desc d, const float* raw, V7Ws ws, size_t total,
+                                                const float* gout4, float* draw) {
   __shared__ float s_red[4];
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   float v = 0.f;
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void k_v7_obj(const plyolo_yolov7_desc d, cons
     const size_t o = row * (size_t)(d.na * (5 + d.C)) + a * (5 + d.C) + 4;
     const float scale = V7_BALANCE[l] / ((float)d.B * d.na * d.lvl_h[l] * d.lvl_w[l]);
     const float x = raw[o], t = ws.tobj[idx];
-    if (GRAD) draw[o] = gout * scale * (sig(x) - t);
+    if (GRAD) draw[o] = (gout4[0] + gout4[2]) * scale * (sig(x) - t);
     else v = bcewl(x, t) * scale;
   }
   if (!GRAD) {
@@ -453,8 +453,8 @@ __global__ __launch_bounds__(256) void k_v7_final(const plyolo_yolov7_desc d, V7
 }
 
 // d loss / d raw for the box and class channels of matched cells (a cell matched twice receives both)
-__global__ __launch_bounds__(256) void k_v7_bwd_pos(const plyolo_yolov7_desc d, const float* raw, const float* labels, V7Ws ws, float gout,
-                                                    float* draw) {
+__global__ __launch_bounds__(256) void k_v7_bwd_pos(const plyolo_yolov7_desc d, const float* raw, const float* labels, V7Ws ws,
+                                                    const float* gout4, float* draw) {
   const int b = blockIdx.x, cap = d.cand_cap, Mn = ws.nmatch[b], ch = 5 + d.C;
   const int* match = ws.match + (size_t)b * cap * 6;
   const float* lab = labels + (size_t)b * d.M * 5;
@@ -472,11 +472,11 @@ __global__ __launch_bounds__(256) void k_v7_bwd_pos(const plyolo_yolov7_desc d, 
       ciou_terms(bx, tb, gr);
       // d(px)/d(tx) = 2 s (1-s);  d(pw)/d(tw) = 2 * pw * (1-s)   [pw = (2s)^2 * anchor]
       const float dp = c < 2 ? 2.0f * sg[c] * (1.0f - sg[c]) : 2.0f * bx[c] * (1.0f - sg[c]);
-      atomicAdd(g + c, gout * 0.05f * (-gr[c] / nl) * dp);
+      atomicAdd(g + c, (gout4[0] + gout4[1]) * 0.05f * (-gr[c] / nl) * dp);
     } else {
       c -= 4;  // class index
       const int tc = (int)lab[m[4] * 5];
-      const float w = gout * (0.5f * d.C / 80.0f) / (nl * d.C);
+      const float w = (gout4[0] + gout4[3]) * (0.5f * d.C / 80.0f) / (nl * d.C);
       atomicAdd(g + 5 + c, w * (sig(p[5 + c]) - (c == tc ? 1.f : 0.f)));
     }
   }
@@ -549,14 +549,14 @@ int plyolo_yolov7_loss_fwd(const plyolo_yolov7_desc* dp, const float* raw, const
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_v7_cand, dim3(d.B), dim3(256), 0, s, d, raw, labels, ws);
     hipLaunchKernelGGL(k_v7_match, dim3(d.B), dim3(256), 0, s, d, raw, labels, ws);
-    hipLaunchKernelGGL(k_v7_obj<false>, dim3(nblk), dim3(256), 0, s, d, raw, ws, total, 0.f, (float*)nullptr);
+    hipLaunchKernelGGL(k_v7_obj<false>, dim3(nblk), dim3(256), 0, s, d, raw, ws, total, (const float*)nullptr, (float*)nullptr);
     hipLaunchKernelGGL(k_v7_pos, dim3(d.B), dim3(256), 0, s, d, raw, labels, ws, nblk);
     hipLaunchKernelGGL(k_v7_final, dim3(1), dim3(256), 0, s, d, ws, nblk, losses);
     return hipGetLastError();
   });
 }
 
-int plyolo_yolov7_loss_bwd(const plyolo_yolov7_desc* dp, const float* raw, const float* labels, float gout, float* draw,
+int plyolo_yolov7_loss_bwd(const plyolo_yolov7_desc* dp, const float* raw, const float* labels, const float* gout, float* draw,
                            void* workspace, size_t ws_bytes, void* stream) {
   const plyolo_yolov7_desc d = *dp;
   if (int rc = check_desc(d)) return rc;

@@ -20,7 +20,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import BF16, F32, ACT, HIER_GROUP, BnFuse, ConvDesc, PackEntry, YoloxDesc, call, ptr
+from ._lib import BF16, F32, ACT, HIER_GROUP, BnFuse, ConvDesc, PackEntry, YoloxDesc, yolov7_desc, call, ptr
 
 BN_EPS_DEFAULT = 1e-3
 
@@ -548,6 +548,18 @@ class V7HeadBuffers:
     def alloc_grad_only(self):
         self.draw = torch.zeros(self.rows * self.nch, dtype=torch.float32, device=self.g.device)
 
+    def alloc_loss(self, max_labels):
+        """Buffers of the training branch (yolov7_loss.py:80-153): labels in, 4 loss scalars out."""
+        dev = self.g.device
+        self.M = max(int(max_labels), 1)
+        self.desc = yolov7_desc(self.B, self.M, self.nc, self.sizes, self.strides, self.anchors)
+        self.labels = torch.zeros(self.B * self.M * 5, dtype=torch.float32, device=dev)
+        self.losses = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.gout = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.ws_bytes = _lib.lib().plyolo_yolov7_workspace(C.byref(self.desc))
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
+        self.draw = torch.empty(self.rows * self.nch, dtype=torch.float32, device=dev)
+
     def set_map_grads(self, grads):
         for (h, w), r0, gm in zip(self.sizes, self.lvl_row, grads):
             n = self.B * h * w
@@ -557,6 +569,24 @@ class V7HeadBuffers:
         self.eval_out = torch.empty(self.B * self.A * self.ch, dtype=torch.float32, device=self.g.device)
         self.eval_shape = (self.B, self.A, self.ch)
         self.anchor_t = torch.tensor(self.anchors, dtype=torch.float32).reshape(-1).to(self.g.device)
+
+
+class YoloV7LossOp:
+    """YOLOv7Loss train branch (yolov7_loss.py:80-368) -> csrc/yolov7_loss.hip."""
+
+    def __init__(self, g, head):
+        self.g, self.head = g, head
+        g.ops.append(self)
+
+    def fwd(self):
+        hd = self.head
+        call("plyolo_yolov7_loss_fwd", C.byref(hd.desc), hd.raw.data_ptr(), hd.labels.data_ptr(), hd.losses.data_ptr(),
+             hd.ws.data_ptr(), hd.ws_bytes, None)
+
+    def bwd(self):
+        hd = self.head
+        call("plyolo_yolov7_loss_bwd", C.byref(hd.desc), hd.raw.data_ptr(), hd.labels.data_ptr(), hd.gout.data_ptr(),
+             hd.draw.data_ptr(), hd.ws.data_ptr(), hd.ws_bytes, None)
 
 
 class YoloV7EvalDecodeOp:

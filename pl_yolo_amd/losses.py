@@ -31,8 +31,8 @@ class YOLOXLoss(nn.Module):
 
 class YOLOv7Loss(nn.Module):
     """YOLOv7 loss plugin (reference models/losses/yolov7/yolov7_loss.py:9-415).  Eval decode
-    (:50-78) runs on the device (csrc/yolox_loss.hip: k_v7_eval_decode); the training branch
-    (find_3_positive / build_targets / CIoU loss, :80-368) is not built yet."""
+    (:50-78) runs on the device (csrc/yolox_loss.hip: k_v7_eval_decode), the training branch
+    (find_3_positive / build_targets / CIoU + obj + cls losses, :80-368) in csrc/yolov7_loss.hip."""
 
     def __init__(self, num_classes, strides, anchors, label_smoothing=0, focal_g=0.0):
         super().__init__()
@@ -48,5 +48,6 @@ class YOLOv7Loss(nn.Module):
 
     def emit(self, g, head_buffers, training):
         if training:
-            raise NotImplementedError("YOLOv7 training loss has no HIP kernel yet")
-        G.YoloV7EvalDecodeOp(g, head_buffers)
+            G.YoloV7LossOp(g, head_buffers)
+        else:
+            G.YoloV7EvalDecodeOp(g, head_buffers)

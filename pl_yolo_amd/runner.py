@@ -139,13 +139,13 @@ class DetectorRunner:
             if anchors is None:
                 raise PlyoloError("anchor-based head needs a loss plugin with anchors (yolov7)")
             head = G.V7HeadBuffers(g, B, nc, model.head.n_anchors, [(f.H, f.W) for f in feats], strides, anchors)
-            if mode == "train":
-                raise NotImplementedError("the YOLOv7 training loss (models/losses/yolov7/yolov7_loss.py:80-368) has no HIP kernel "
-                                          "yet; use labels=None (raw maps, differentiable) or eval mode")
         s.head = head
         model.head.emit(g, feats, head)
         if mode == "train":
-            head.alloc_loss()
+            if model.head.n_anchors == 1:
+                head.alloc_loss()
+            else:
+                head.alloc_loss(M)
             model.loss.emit(g, head, True)
         elif mode == "eval":
             head.alloc_eval()

@@ -54,9 +54,28 @@ def test_v7_fp32_maps_grads_eval_vs_golden():
     with torch.no_grad():
         out = model(x, torch.from_numpy(g["labels"]).to(hu.DEV))
     np.testing.assert_allclose(out.cpu().numpy(), g["eval_out"], rtol=2e-3, atol=5e-3)
+
+
+def test_v7_fp32_training_loss_and_grads_vs_golden():
+    """OneStageD.forward(x, labels) in train mode for the YOLOv7 family: loss and every parameter
+    gradient vs what the reference produced (`out/loss`, `lossgrad/*`)."""
+    g, model = _model("fp32")
     model.train()
-    with pytest.raises(NotImplementedError):
-        model(x, torch.from_numpy(g["labels"]).to(hu.DEV))  # training loss not built yet: fails loudly
+    x = torch.from_numpy(g["x"]).to(hu.DEV)
+    out = model(x, torch.from_numpy(g["labels"]).to(hu.DEV))
+    assert set(out) == {"loss"} and tuple(out["loss"].shape) == (1,)
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    print("yolov7 train loss hip %.6f ref %.6f" % (float(out["loss"]), float(g["out/loss"][0])))
+    assert abs(float(out["loss"]) - float(g["out/loss"][0])) <= 1e-4
+    worst = 0.0
+    for name, p in model.named_parameters():
+        ref = g["lossgrad/" + name]
+        assert p.grad is not None, name
+        err = float(np.abs(p.grad.cpu().numpy() - ref).max()) / max(1e-3, float(np.abs(ref).max()))
+        worst = max(worst, err)
+        assert err <= 2e-3, (name, err)
+    print("yolov7 worst relative loss-gradient error %.3g" % worst)
 
 
 def test_v7_bf16_runs_and_tracks_fp32():
@@ -111,9 +130,10 @@ def test_v7_loss_kernels_vs_reference(case):
     ws = torch.empty(wsb, dtype=torch.uint8, device=hu.DEV)
     losses = torch.zeros(4, device=hu.DEV)
     draw = torch.full_like(raw, 7.0)
+    gout = torch.tensor([1.0, 0.0, 0.0, 0.0], device=hu.DEV)
     for _ in range(2):  # twice: the workspace is reusable
         _lib.call("plyolo_yolov7_loss_fwd", C.byref(d), raw.data_ptr(), labels.data_ptr(), losses.data_ptr(), ws.data_ptr(), wsb, hu.stream())
-        _lib.call("plyolo_yolov7_loss_bwd", C.byref(d), raw.data_ptr(), labels.data_ptr(), 1.0, draw.data_ptr(), ws.data_ptr(), wsb, hu.stream())
+        _lib.call("plyolo_yolov7_loss_bwd", C.byref(d), raw.data_ptr(), labels.data_ptr(), gout.data_ptr(), draw.data_ptr(), ws.data_ptr(), wsb, hu.stream())
     counts = torch.zeros(B, dtype=torch.int32, device=hu.DEV)
     entries = torch.zeros(B, d.cand_cap, 6, dtype=torch.int32, device=hu.DEV)
     _lib.call("plyolo_yolov7_matched", C.byref(d), ws.data_ptr(), counts.data_ptr(), entries.data_ptr(), hu.stream())
