@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 # SURVEY.md section 8d, per image, bf16: 3 x fwd conv FLOPs ; 3 x (sum conv-in + conv-out elems) x 2 B
 ALGO = {"yolox_s": dict(flops=80.07e9, bytes=443.6e6), "yolox_l": dict(flops=465.9e9, bytes=1229e6),
         "yolox_x": dict(flops=3376.9e9 / 4, bytes=7020e6 / 4), "yolox_nano": dict(flops=8.73e9 * (640 / 416) ** 2, bytes=96.2e6 * (640 / 416) ** 2),
-        "yolox_test": dict(flops=1e9, bytes=1e8)}
+        "yolov7": dict(flops=337.4e9, bytes=1266e6), "yolox_test": dict(flops=1e9, bytes=1e8)}
 PEAK_HBM = 8000.0      # GB/s  (MI355X_MICROARCH.md: HBM3E spec)
 PEAK_MFMA = 2500.0     # TFLOP/s dense bf16
 
@@ -136,7 +136,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
 
-    with open(os.path.join(ROOT, "configs", "model", "yolox", args.model + ".yaml")) as f:
+    family = "yolov7" if args.model.startswith("yolov7") else "yolox"
+    with open(os.path.join(ROOT, "configs", "model", family, args.model + ".yaml")) as f:
         cfg = yaml.safe_load(f)
     cfg["_name"] = args.model
     nc = 80

@@ -86,32 +86,6 @@ typedef struct plyolo_conv_desc {
 int plyolo_conv2d_fwd(const plyolo_conv_desc* d, const void* x, const void* wp, const float* bias,
                       void* y, float* stats, void* stream);
 int plyolo_conv2d_stat_rows(const plyolo_conv_desc* d);
-/* Forward conv with the train-mode BatchNorm statistics FINISHED inside the launch
- * (BaseConv = conv -> bn -> act, network_blocks.py:30-37): every workgroup writes its partial
- * row, the last workgroup of each group of 32 rows sums the group, the last group sums the
- * groups (fixed order => bit-reproducible) and produces coef[4C] = (scale, shift, mean,
- * invstd) + the running statistics -- no separate finalize launch.
- *   rows   fp32 [2][plyolo_conv2d_stat_rows(d)][Cout]   (scratch, may be shared between layers)
- *   gpart  fp32 [2][ceil(rows/32)][Cout]                (scratch, shareable)
- *   gcnt   u32  [ceil(Cout/32)][ceil(rows/32)], fcnt u32 [ceil(Cout/32)]: zeroed ONCE by the
- *          caller, self-resetting, shareable between layers that run on one stream.
- * bf16 path only. */
-typedef struct plyolo_bn_fuse {
-  const float* gamma;
-  const float* beta;
-  float* running_mean;
-  float* running_var;
-  int64_t* num_batches_tracked;
-  float* coef;
-  float* rows;
-  float* gpart;
-  unsigned int* gcnt;
-  unsigned int* fcnt;
-  double count;       /* N*OH*OW */
-  float eps, momentum;
-} plyolo_bn_fuse;
-int plyolo_conv2d_fwd_bn(const plyolo_conv_desc* d, const void* x, const void* wp, void* y,
-                         const plyolo_bn_fuse* bn, void* stream);
 /* dx = conv_transpose(dy, w).  wpd: packed dgrad weights.  accumulate!=0: dx += */
 int plyolo_conv2d_dgrad(const plyolo_conv_desc* d, const void* dy, const void* wpd, void* dx,
                         int accumulate, void* stream);
@@ -129,8 +103,10 @@ int plyolo_bias_grad(int dtype, const void* dy, int M, int C, int ld, float* dbi
  * lives in DEVICE memory: n entries of plyolo_pack_entry. */
 typedef struct plyolo_pack_entry {
   const float* w;   /* OIHW fp32 master weights (torch layout), [Cout][Cin][k][k] */
-  void* wp;         /* [tap][Cout_total][Cin_p] fwd pack (bf16 or fp32) */
-  void* wpd;        /* [tap][Cin_p][Cout_p8] dgrad pack, or NULL */
+  void* wp;         /* fwd pack, plyolo_pack_elems() elements: fp32 [tap][Cout_total][Cin_p];
+                       bf16 = MFMA B-fragment order [tap][ceil(Cout_total/32)][ceil(Cin_p/16)][64][8] */
+  void* wpd;        /* dgrad pack or NULL: fp32 [tap][Cin_p][Cout_p8];
+                       bf16 [tap][ceil(Cin_p/32)][ceil(Cout_total/16)][64][8] */
   float* dwp;       /* [nslab][tap][Cout_total][Cin_p] fp32 wgrad slabs (unpack source) */
   float* dw;        /* OIHW fp32 gradient (unpack destination), or NULL */
   const float* b;   /* fp32 bias [Cout] or NULL */
@@ -145,6 +121,9 @@ typedef struct plyolo_pack_entry {
   int nslab;        /* number of wgrad slabs to sum in unpack (>= 1) */
 } plyolo_pack_entry;
 int plyolo_pack_weights(const plyolo_pack_entry* table_dev, int n, int dtype, int max_elems, void* stream);
+/* Element counts of the two packs (the buffers must be zero-initialised ONCE: pad positions are
+ * never written). */
+int plyolo_pack_elems(int dtype, int Cout_total, int Cin_p, int ksize, size_t* wp_elems, size_t* wpd_elems);
 /* dw (OIHW) (+)= permute(dwp) for the whole table. */
 int plyolo_unpack_wgrads(const plyolo_pack_entry* table_dev, int n, int max_elems, int accumulate, void* stream);
 
@@ -172,13 +151,6 @@ int plyolo_bn_act_fwd(int dtype, int M, int C, const void* z, int z_ld, const fl
 int plyolo_bn_bwd_rows(int M);
 int plyolo_bn_act_bwd_reduce(int dtype, int M, int C, const void* dout, int d_ld, const void* z, int z_ld,
                              const float* coef, int act, float* partial, void* stream);
-/* bn_act_bwd_reduce with the finish fused in (same hierarchical last-arriver reduction as
- * plyolo_conv2d_fwd_bn): writes dgamma, dbeta and bcoef.  partial: fp32 [2][rows][C] scratch;
- * gpart fp32 [2][ceil(rows/32)][C]; gcnt u32 [ceil(rows/32)], fcnt u32 [1] zeroed once. */
-int plyolo_bn_act_bwd_reduce_fin(int dtype, int M, int C, const void* dout, int d_ld, const void* z, int z_ld,
-                                 const float* coef, int act, const float* gamma, float* dgamma, float* dbeta,
-                                 float* bcoef, float* partial, float* gpart, unsigned int* gcnt,
-                                 unsigned int* fcnt, void* stream);
 /* dgamma/dbeta (+)=; bcoef[0:C]=A, [C:2C]=B, [2C:3C]=Cc so that dz = A*du + B*z + Cc */
 int plyolo_bn_bwd_finalize(const float* partial, int rows, int C, double count, const float* gamma,
                            const float* coef, float* dgamma, float* dbeta, int accumulate, float* bcoef,

@@ -22,14 +22,6 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("dtype", "N", "H", "W", "Cin", "Cout", "ksize", "stride", "x_ld", "y_ld", "y_f32")]
 
 
-HIER_GROUP = 32  # rows per group of the in-kernel hierarchical reduction
-
-
-class BnFuse(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("gamma", "beta", "running_mean", "running_var", "num_batches_tracked", "coef", "rows", "gpart", "gcnt", "fcnt")] + [
-        ("count", C.c_double), ("eps", C.c_float), ("momentum", C.c_float)]
-
-
 class PackEntry(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("w", "wp", "wpd", "dwp", "dw", "b", "bp", "dbp", "db")] + [
         (n, C.c_int) for n in ("Cout", "Cin", "Cin_p", "ksize", "Cout_total", "Cout_p8", "co_off", "nslab")
@@ -50,6 +42,13 @@ class YoloV7Desc(C.Structure):
         ("lvl_h", C.c_int * 3), ("lvl_w", C.c_int * 3), ("lvl_stride", C.c_int * 3), ("lvl_row", C.c_int * 3),
         ("anchors", C.c_float * 18), ("cand_cap", C.c_int),
     ]
+
+
+def pack_elems(dtype, Cout_total, Cin_p, ksize):
+    """(wp_elems, wpd_elems) of the packed weight buffers of one convolution."""
+    a, b = _sz(0), _sz(0)
+    call("plyolo_pack_elems", dtype, Cout_total, Cin_p, ksize, C.byref(a), C.byref(b))
+    return int(a.value), int(b.value)
 
 
 def yolov7_desc(B, M, num_classes, sizes, strides, anchors):
@@ -95,13 +94,12 @@ SIGNATURES = {
     "plyolo_plan_op_info": (_i, [_vp, _i, C.c_char_p, _i, _P(_d), _P(_d)]),
     "plyolo_conv2d_fwd": (_i, [_P(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
     "plyolo_conv2d_stat_rows": (_i, [_P(ConvDesc)]),
-    "plyolo_conv2d_fwd_bn": (_i, [_P(ConvDesc), _vp, _vp, _vp, _P(BnFuse), _vp]),
-    "plyolo_bn_act_bwd_reduce_fin": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "plyolo_conv2d_dgrad": (_i, [_P(ConvDesc), _vp, _vp, _vp, _i, _vp]),
     "plyolo_conv2d_wgrad": (_i, [_P(ConvDesc), _vp, _vp, _vp, _vp]),
     "plyolo_conv2d_wgrad_slabs": (_i, [_P(ConvDesc)]),
     "plyolo_bias_grad": (_i, [_i, _vp, _i, _i, _i, _vp, _vp]),
     "plyolo_pack_weights": (_i, [_vp, _i, _i, _i, _vp]),
+    "plyolo_pack_elems": (_i, [_i, _i, _i, _i, _P(_sz), _P(_sz)]),
     "plyolo_unpack_wgrads": (_i, [_vp, _i, _i, _i, _vp]),
     "plyolo_bn_finalize": (_i, [_vp, _i, _i, _d, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "plyolo_bn_finalize_workspace": (_sz, [_i]),

@@ -37,7 +37,8 @@ void take_annotation(PlanOp* op) {
 }
 
 int conv_mfma_stat_rows(const plyolo_conv_desc* d);
-int conv_mfma_fwd(const plyolo_conv_desc*, const void*, const void*, const float*, void*, float*, const plyolo_bn_fuse*, void*);
+int conv_mfma_fwd(const plyolo_conv_desc*, const void*, const void*, const float*, void*, float*, void*);
+void conv_mfma_pack_elems(int Cout_total, int Cin_p, int ksize, size_t* wp, size_t* wpd);
 int conv_mfma_dgrad(const plyolo_conv_desc*, const void*, const void*, void*, int, void*);
 int conv_mfma_wgrad(const plyolo_conv_desc*, const void*, const void*, float*, void*);
 int conv_mfma_wgrad_slabs(const plyolo_conv_desc*);
@@ -169,14 +170,20 @@ int plyolo_conv2d_stat_rows(const plyolo_conv_desc* d) {
 }
 int plyolo_conv2d_fwd(const plyolo_conv_desc* d, const void* x, const void* wp, const float* bias, void* y, float* stats, void* stream) {
   if (check_conv(d, "conv2d_fwd", true)) return -1;
-  return d->dtype == PLYOLO_BF16 ? conv_mfma_fwd(d, x, wp, bias, y, stats, nullptr, stream) : conv_ref_fwd(d, x, wp, bias, y, stats, stream);
+  return d->dtype == PLYOLO_BF16 ? conv_mfma_fwd(d, x, wp, bias, y, stats, stream) : conv_ref_fwd(d, x, wp, bias, y, stats, stream);
 }
-int plyolo_conv2d_fwd_bn(const plyolo_conv_desc* d, const void* x, const void* wp, void* y, const plyolo_bn_fuse* bn, void* stream) {
-  if (check_conv(d, "conv2d_fwd_bn", true)) return -1;
-  PLY_CHECK_ARG(d->dtype == PLYOLO_BF16 && !d->y_f32, "conv2d_fwd_bn: bf16 path only");
-  PLY_CHECK_ARG(bn && bn->coef && bn->rows && bn->gpart && bn->gcnt && bn->fcnt && bn->count > 0, "conv2d_fwd_bn: incomplete plyolo_bn_fuse");
-  return conv_mfma_fwd(d, x, wp, nullptr, y, nullptr, bn, stream);
+int plyolo_pack_elems(int dtype, int Cout_total, int Cin_p, int ksize, size_t* wp_elems, size_t* wpd_elems) {
+  PLY_CHECK_ARG(wp_elems && wpd_elems && Cout_total > 0 && Cin_p > 0 && (ksize == 1 || ksize == 3), "pack_elems: bad arguments");
+  if (dtype == PLYOLO_BF16) {
+    conv_mfma_pack_elems(Cout_total, Cin_p, ksize, wp_elems, wpd_elems);
+  } else {
+    const size_t taps = (size_t)ksize * ksize;
+    *wp_elems = taps * Cout_total * Cin_p;
+    *wpd_elems = taps * Cin_p * ((Cout_total + 7) / 8 * 8);
+  }
+  return 0;
 }
+
 int plyolo_conv2d_dgrad(const plyolo_conv_desc* d, const void* dy, const void* wpd, void* dx, int accumulate, void* stream) {
   if (check_conv(d, "conv2d_dgrad", false)) return -1;
   return d->dtype == PLYOLO_BF16 ? conv_mfma_dgrad(d, dy, wpd, dx, accumulate, stream) : conv_ref_dgrad(d, dy, wpd, dx, accumulate, stream);

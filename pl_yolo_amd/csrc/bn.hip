@@ -22,17 +22,6 @@ namespace {
 
 constexpr int FIN_CHUNKS = 32;
 
-struct BwdFin {  // bcoef == NULL: partial rows only (separate bn_bwd_finalize launch)
-  float* gpart;
-  unsigned* gcnt;
-  unsigned* fcnt;
-  const float* gamma;
-  float* dgamma;
-  float* dbeta;
-  float* bcoef;
-  double count;
-};
-
 struct FinWs {
   double* part;        // [FIN_CHUNKS][2][C]
   unsigned* counter;   // [ceil(C/32)]
@@ -158,8 +147,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(int M, int C, const T* 
 // partial[0][row][c] = sum du ; partial[1][row][c] = sum du * zhat ; one partial row per block
 template <typename T>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(int M, int C, const T* __restrict__ dout, int d_ld, const T* __restrict__ z,
-                                                                int z_ld, const float* __restrict__ coef, int act, float* partial, int rows,
-                                                                BwdFin fin) {
+                                                                int z_ld, const float* __restrict__ coef, int act, float* partial, int rows) {
   constexpr int V = Vec<T>::N;
   __shared__ float red[256 * 2 * V];
   const int cvn = C / V;
@@ -201,37 +189,13 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(int M, int C, co
           s1[i] += red[((k * cm.cols + cm.tcol) * 2 + 0) * V + i];
           s2[i] += red[((k * cm.cols + cm.tcol) * 2 + 1) * V + i];
         }
-      if (fin.bcoef != nullptr) {  // handed to another workgroup inside this launch: write-through
 #pragma unroll
-        for (int i = 0; i < V; ++i) {
-          hier_store(partial + (size_t)row * C + cv * V + i, s1[i]);
-          hier_store(partial + ((size_t)rows + row) * C + cv * V + i, s2[i]);
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < V; ++i) {
-          partial[(size_t)row * C + cv * V + i] = s1[i];
-          partial[((size_t)rows + row) * C + cv * V + i] = s2[i];
-        }
+      for (int i = 0; i < V; ++i) {
+        partial[(size_t)row * C + cv * V + i] = s1[i];
+        partial[((size_t)rows + row) * C + cv * V + i] = s2[i];
       }
     }
   }
-  if (fin.bcoef == nullptr) return;
-  // ---- fused finish (deterministic hierarchical last-arriver reduction)
-  __shared__ int s_flag;
-  HierRed h;
-  h.rows = partial; h.gpart = fin.gpart; h.gcnt = fin.gcnt; h.fcnt = fin.fcnt; h.nrows = rows; h.C = C;
-  hier_finish(h, row, 0, 0, C, &s_flag, [&](int c, double s, double ss) {
-    if (fin.dbeta) fin.dbeta[c] = (float)s;
-    if (fin.dgamma) fin.dgamma[c] = (float)ss;
-    const float mean = coef[2 * C + c], invstd = coef[3 * C + c];
-    const float A = (fin.gamma ? fin.gamma[c] : 1.f) * invstd;
-    const float B = (float)(-(double)A * (ss / fin.count) * (double)invstd);
-    const float Cc = (float)(-(double)A * (s / fin.count) - (double)B * (double)mean);
-    fin.bcoef[c] = A;
-    fin.bcoef[C + c] = B;
-    fin.bcoef[2 * C + c] = Cc;
-  });
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* partial, int rows, int C, double count, const float* gamma,
@@ -397,23 +361,7 @@ int plyolo_bn_act_bwd_reduce(int dtype, int M, int C, const void* dout, int d_ld
   plyolo::annotate("bn_act_bwd_reduce", 0.0, (double)M * C * (dtype == PLYOLO_BF16 ? 2.0 : 4.0) * 2.0);
   return submit(stream, [=](hipStream_t s) -> hipError_t {
     DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<T>, dim3(rows), dim3(256), 0, s, M, C, (const T*)dout, d_ld,
-                                         (const T*)z, z_ld, coef, act, partial, rows, BwdFin{});)
-    return hipGetLastError();
-  });
-}
-
-int plyolo_bn_act_bwd_reduce_fin(int dtype, int M, int C, const void* dout, int d_ld, const void* z, int z_ld, const float* coef,
-                                 int act, const float* gamma, float* dgamma, float* dbeta, float* bcoef, float* partial,
-                                 float* gpart, unsigned int* gcnt, unsigned int* fcnt, void* stream) {
-  const int V = dtype == PLYOLO_BF16 ? 8 : 4;
-  PLY_CHECK_ARG(C % V == 0 && z_ld % V == 0 && d_ld % V == 0, "bn_act_bwd_reduce_fin: C/ld must be multiples of %d", V);
-  PLY_CHECK_ARG(bcoef && partial && gpart && gcnt && fcnt, "bn_act_bwd_reduce_fin: scratch pointers required");
-  const int rows = plyolo_bn_bwd_rows(M);
-  BwdFin fin{gpart, gcnt, fcnt, gamma, dgamma, dbeta, bcoef, (double)M};
-  plyolo::annotate("bn_act_bwd_reduce", 0.0, (double)M * C * (dtype == PLYOLO_BF16 ? 2.0 : 4.0) * 2.0);
-  return submit(stream, [=](hipStream_t s) -> hipError_t {
-    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<T>, dim3(rows), dim3(256), 0, s, M, C, (const T*)dout, d_ld,
-                                         (const T*)z, z_ld, coef, act, partial, rows, fin);)
+                                         (const T*)z, z_ld, coef, act, partial, rows);)
     return hipGetLastError();
   });
 }

@@ -104,78 +104,6 @@ template <> struct Vec<float> {
 template <bool PRECISE> DEVINL float actf(float u, int act) { return PRECISE ? act_fwd_precise(u, act) : act_fwd(u, act); }
 
 
-// ---- deterministic in-kernel reduction of per-workgroup partial rows -------------------
-// Every workgroup publishes ONE partial row (two quantities x C channels) of
-// rows[2][nrows][C] with hier_store().  Rows are grouped by 32: the last workgroup of a group
-// to arrive sums the group's rows into gpart[2][ngroups][C]; the last group to finish sums
-// the group rows and calls finish(c, sum0, sum1) for its columns.  Fixed summation order =>
-// bit-reproducible.  Hand-off protocol (cdna_hip_programming.md Guideline 16, sc1 form): every
-// handed-off value is stored write-through (`sc1`, relaxed agent-scope atomic store), each
-// storing wave drains with s_waitcnt vmcnt(0), a workgroup barrier, then ONE lane takes the
-// ticket; readers use sc1 loads.  No release fence: a `buffer_wbl2` would write back the
-// whole XCD L2 (the conv output just stored) once per workgroup -- measured 2x on the step.
-// Counters are zeroed once by the caller and reset themselves.  `cb` = column-block id
-// (counter namespace), columns [c0, c0+ncols).
-constexpr int HIER_GROUP = 32;
-struct HierRed {
-  float* rows;
-  float* gpart;
-  unsigned* gcnt;  // [ncb][ngroups]
-  unsigned* fcnt;  // [ncb]
-  int nrows, C;
-};
-DEVINL void hier_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-DEVINL float hier_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-template <typename F>
-DEVINL void hier_finish(const HierRed& h, int row, int cb, int c0, int ncols, int* s_flag, F&& finish) {
-  const int tid = threadIdx.x;
-  const int ngroups = (h.nrows + HIER_GROUP - 1) / HIER_GROUP;
-  const int group = row / HIER_GROUP;
-  const int g0 = group * HIER_GROUP;
-  const int gn = (h.nrows - g0 < HIER_GROUP) ? h.nrows - g0 : HIER_GROUP;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's row stores have left
-  __syncthreads();
-  if (tid == 0) {
-    const unsigned t = __hip_atomic_fetch_add(h.gcnt + (size_t)cb * ngroups + group, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *s_flag = (t == (unsigned)gn - 1u) ? 1 : 0;
-  }
-  __syncthreads();
-  if (!*s_flag) return;
-  for (int c = tid; c < ncols; c += blockDim.x) {
-    const int col = c0 + c;
-    if (col >= h.C) continue;
-    float s = 0.f, ss = 0.f;
-    for (int k = 0; k < gn; ++k) {
-      s += hier_load(h.rows + (size_t)(g0 + k) * h.C + col);
-      ss += hier_load(h.rows + ((size_t)h.nrows + g0 + k) * h.C + col);
-    }
-    hier_store(h.gpart + (size_t)group * h.C + col, s);
-    hier_store(h.gpart + ((size_t)ngroups + group) * h.C + col, ss);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) {
-    __hip_atomic_store(h.gcnt + (size_t)cb * ngroups + group, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned t = __hip_atomic_fetch_add(h.fcnt + cb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *s_flag = (t == (unsigned)ngroups - 1u) ? 1 : 0;
-  }
-  __syncthreads();
-  if (!*s_flag) return;
-  for (int c = tid; c < ncols; c += blockDim.x) {
-    const int col = c0 + c;
-    if (col >= h.C) continue;
-    double s = 0.0, ss = 0.0;
-    for (int k = 0; k < ngroups; ++k) {
-      s += (double)hier_load(h.gpart + (size_t)k * h.C + col);
-      ss += (double)hier_load(h.gpart + ((size_t)ngroups + k) * h.C + col);
-    }
-    finish(col, s, ss);
-  }
-  if (tid == 0) __hip_atomic_store(h.fcnt + cb, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// ---------------------------------------------------------------- host side
 namespace plyolo {
 
 void set_error(const char* fmt, ...);

@@ -392,6 +392,11 @@ __global__ void nchw_to_nhwc_kernel(int N, int H, int W, int C, const float* in,
 }
 
 // ------------------------------------------------------------ weight packing
+// fp32 (parity path): wp [tap][Cout_total][Cin_p], wpd [tap][Cin_p][Cout_p8].
+// bf16 (MFMA path): both packs are in MFMA B-fragment order (conv_mfma.hip, conv_mfma_pack_elems):
+//   wp  fragment (tap, nb, kb) = 64 lanes x 8 values, lane (r = l&31, h = l>>5), j  <-  W[nb*32+r][kb*16+h*8+j][tap]
+//   wpd fragment (tap, nb, kb)                                                      <-  W[kb*16+h*8+j][nb*32+r][tap]
+// Pad positions are never written (the arenas are zero-initialised once).
 template <typename T>
 __global__ void pack_weights_kernel(const plyolo_pack_entry* table) {
   const plyolo_pack_entry e = table[blockIdx.x];
@@ -399,13 +404,28 @@ __global__ void pack_weights_kernel(const plyolo_pack_entry* table) {
   const int nf = taps * e.Cout * e.Cin_p;
   T* wp = (T*)e.wp;
   T* wpd = (T*)e.wpd;
+  constexpr bool FRAG = sizeof(T) == 2;
+  const int nkb_f = (e.Cin_p + 15) / 16, nnb_f = (e.Cout_total + 31) / 32;
+  const int nkb_d = (e.Cout_total + 15) / 16, nnb_d = (e.Cin_p + 31) / 32;
   for (int idx = blockIdx.y * blockDim.x + threadIdx.x; idx < nf; idx += gridDim.y * blockDim.x) {
     const int ci = idx % e.Cin_p;
     const int co = (idx / e.Cin_p) % e.Cout;
     const int t = idx / (e.Cin_p * e.Cout);
     const float v = ci < e.Cin ? e.w[((size_t)co * e.Cin + ci) * taps + t] : 0.f;
-    ActT<T>::st(wp + ((size_t)t * e.Cout_total + e.co_off + co) * e.Cin_p + ci, v);
-    if (wpd) ActT<T>::st(wpd + ((size_t)t * e.Cin_p + ci) * e.Cout_p8 + e.co_off + co, v);
+    const int cot = e.co_off + co;
+    if (FRAG) {
+      {
+        const int nb = cot >> 5, r = cot & 31, kb = ci >> 4, h = (ci >> 3) & 1, j = ci & 7;
+        ActT<T>::st(wp + (((size_t)t * nnb_f + nb) * nkb_f + kb) * 512 + (h * 32 + r) * 8 + j, v);
+      }
+      if (wpd) {
+        const int nb = ci >> 5, r = ci & 31, kb = cot >> 4, h = (cot >> 3) & 1, j = cot & 7;
+        ActT<T>::st(wpd + (((size_t)t * nnb_d + nb) * nkb_d + kb) * 512 + (h * 32 + r) * 8 + j, v);
+      }
+    } else {
+      ActT<T>::st(wp + ((size_t)t * e.Cout_total + cot) * e.Cin_p + ci, v);
+      if (wpd) ActT<T>::st(wpd + ((size_t)t * e.Cin_p + ci) * e.Cout_p8 + cot, v);
+    }
   }
   if (e.b && blockIdx.y == 0)
     for (int i = threadIdx.x; i < e.Cout; i += blockDim.x) e.bp[e.co_off + i] = e.b[i];

@@ -20,7 +20,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import BF16, F32, ACT, HIER_GROUP, BnFuse, ConvDesc, PackEntry, YoloxDesc, yolov7_desc, call, ptr
+from ._lib import BF16, F32, ACT, ConvDesc, PackEntry, YoloxDesc, yolov7_desc, call, ptr
 
 BN_EPS_DEFAULT = 1e-3
 
@@ -84,7 +84,6 @@ class Graph:
         import os
         # in-launch BatchNorm finish (last-arriver hand-off): measured SLOWER than the separate
         # finalize launches on these short kernels (profiles/README.md), so it is opt-in
-        self.fuse_bn_finish = os.environ.get("PLYOLO_FUSE_BN", "0") == "1"
 
     # ------------------------------------------------------------------ tracing
     def new_act(self, N, H, W, C_, name=""):
@@ -131,16 +130,9 @@ class Graph:
         self.scratch32 = torch.zeros(max(self.scratch_f32, 8), dtype=torch.float32, device=dev)
         cmax = max([c.Cout_total for c in self.convs] + [8])
         self.fin_ws = torch.zeros(_lib.lib().plyolo_bn_finalize_workspace(cmax), dtype=torch.uint8, device=dev)
-        # fused BatchNorm finish (bf16 path): group partial rows + self-resetting arrival counters,
-        # shared by all layers (launches on one stream are sequential)
-        self.fuse_bn = self.dtype == BF16 and self.fuse_bn_finish
-        gmax = max([getattr(o, "max_groups", 1) for o in self.ops] + [64])
-        self.bn_gpart = torch.zeros(2 * gmax * cmax, dtype=torch.float32, device=dev)
-        self.bn_gcnt = torch.zeros((cmax // 32 + 2) * gmax, dtype=torch.int32, device=dev)
-        self.bn_fcnt = torch.zeros(cmax // 32 + 2, dtype=torch.int32, device=dev)
         # weight arenas
         wp_n = sum(_align(c.wp_elems) for c in self.convs)
-        dwp_n = sum(_align(c.wp_elems * c.nslab) for c in self.convs)
+        dwp_n = sum(_align(c.dwp_elems * c.nslab) for c in self.convs)
         wpd_n = sum(_align(c.wpd_elems) for c in self.convs)
         self.wp_arena = torch.zeros(max(wp_n, 8), dtype=self.tdtype, device=dev)
         self.wpd_arena = torch.zeros(max(wpd_n, 8), dtype=self.tdtype, device=dev)
@@ -158,7 +150,7 @@ class Graph:
             c.bp = self.bias_arena.data_ptr() + o3 * 4
             c.dbp = self.dbias_arena.data_ptr() + o3 * 4
             o1 += _align(c.wp_elems)
-            o4 += _align(c.wp_elems * c.nslab)
+            o4 += _align(c.dwp_elems * c.nslab)
             o2 += _align(c.wpd_elems)
             o3 += _align(c.Cout_total)
             for (w, b, co_off) in c.sources:
@@ -242,8 +234,8 @@ class PackedConv:
         self.Cout_total = sum(w.shape[0] for (w, _, _) in sources)
         self.Cout_p8 = (self.Cout_total + 7) // 8 * 8
         taps = ksize * ksize
-        self.wp_elems = taps * self.Cout_total * Cin_p
-        self.wpd_elems = taps * Cin_p * self.Cout_p8
+        self.dwp_elems = taps * self.Cout_total * Cin_p            # wgrad slab (plain [tap][Cout][Cin_p])
+        self.wp_elems, self.wpd_elems = _lib.pack_elems(g.dtype, self.Cout_total, Cin_p, ksize)
         self.need_dgrad = need_dgrad
         self.nslab = 1
         self.wp = self.wpd = self.dwp = self.bp = self.dbp = None
@@ -303,9 +295,6 @@ class ConvUnitOp:
         self.desc = conv_desc(g, x.N, x.H, x.W, self.Cin_p, Cout, k, stride, self.Cin_p, Cout)
         self.pc.set_slabs(self.desc)
         g.scratch_elems = max(g.scratch_elems, self.z.rows * Cout)
-        # upper bound of the per-workgroup partial rows (8x16 output tiles / 64-pixel bwd rows)
-        tiles = x.N * ((self.OH + 7) // 8) * ((self.OW + 15) // 16)
-        self.max_groups = (max(tiles, self.z.rows // 64 + 1, 1024) + HIER_GROUP - 1) // HIER_GROUP + 1
         g.ops.append(self)
 
     def _alloc_small(self):
@@ -330,27 +319,17 @@ class ConvUnitOp:
         zt = self.z.tensor
         train_stats = g.training and bn is not None
         coef = None
-        if train_stats and g.fuse_bn:
-            f = BnFuse()
-            f.gamma, f.beta = ptr(bn.weight), ptr(bn.bias)
-            f.running_mean, f.running_var, f.num_batches_tracked = ptr(bn.running_mean), ptr(bn.running_var), ptr(bn.num_batches_tracked)
-            f.coef, f.rows, f.gpart = self.coef.data_ptr(), self.stats.data_ptr(), g.bn_gpart.data_ptr()
-            f.gcnt, f.fcnt = g.bn_gcnt.data_ptr(), g.bn_fcnt.data_ptr()
-            f.count, f.eps, f.momentum = float(self.out.M), float(bn.eps), float(bn.momentum)
-            call("plyolo_conv2d_fwd_bn", C.byref(self.desc), g.aptr(self.x), self.pc.wp, zt.data_ptr(), C.byref(f), None)
+        call("plyolo_conv2d_fwd", C.byref(self.desc), g.aptr(self.x), self.pc.wp, None, zt.data_ptr(),
+             self.stats.data_ptr() if train_stats else None, None)
+        if bn is not None:
             coef = self.coef.data_ptr()
-        else:
-            call("plyolo_conv2d_fwd", C.byref(self.desc), g.aptr(self.x), self.pc.wp, None, zt.data_ptr(),
-                 self.stats.data_ptr() if train_stats else None, None)
-            if bn is not None:
-                coef = self.coef.data_ptr()
-                if g.training:
-                    call("plyolo_bn_finalize", self.stats.data_ptr(), self.stat_rows, self.Cout, float(self.out.M),
-                         ptr(bn.weight), ptr(bn.bias), float(bn.eps), float(bn.momentum), ptr(bn.running_mean),
-                         ptr(bn.running_var), ptr(bn.num_batches_tracked), coef, g.fin_ws.data_ptr(), g.fin_ws.numel(), None)
-                else:
-                    call("plyolo_bn_eval_coef", self.Cout, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
-                         ptr(bn.running_var), float(bn.eps), coef, None)
+            if g.training:
+                call("plyolo_bn_finalize", self.stats.data_ptr(), self.stat_rows, self.Cout, float(self.out.M),
+                     ptr(bn.weight), ptr(bn.bias), float(bn.eps), float(bn.momentum), ptr(bn.running_mean),
+                     ptr(bn.running_var), ptr(bn.num_batches_tracked), coef, g.fin_ws.data_ptr(), g.fin_ws.numel(), None)
+            else:
+                call("plyolo_bn_eval_coef", self.Cout, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
+                     ptr(bn.running_var), float(bn.eps), coef, None)
         call("plyolo_bn_act_fwd", g.dtype, self.out.M, self.Cout, zt.data_ptr(), self.Cout, coef, self.act,
              g.aptr(self.res) if self.res is not None else None, self.res.ld if self.res is not None else 0,
              g.aptr(self.out), self.out.ld, None)
@@ -366,16 +345,11 @@ class ConvUnitOp:
         if self.res is not None:
             acc = g.grad_mode(self.res)
             call("plyolo_copy_add", g.dtype, M, Cout, dout, self.out.ld, g.gptr(self.res), self.res.ld, acc, None)
-        if g.fuse_bn:
-            call("plyolo_bn_act_bwd_reduce_fin", g.dtype, M, Cout, dout, self.out.ld, zt, Cout, self.coef.data_ptr(), self.act,
-                 ptr(bn.weight), g.grad_ptr_of(bn.weight), g.grad_ptr_of(bn.bias), self.bcoef.data_ptr(),
-                 self.bpartial.data_ptr(), g.bn_gpart.data_ptr(), g.bn_gcnt.data_ptr(), g.bn_fcnt.data_ptr(), None)
-        else:
-            call("plyolo_bn_act_bwd_reduce", g.dtype, M, Cout, dout, self.out.ld, zt, Cout, self.coef.data_ptr(), self.act,
-                 self.bpartial.data_ptr(), None)
-            call("plyolo_bn_bwd_finalize", self.bpartial.data_ptr(), self.brows, Cout, float(M), ptr(bn.weight),
-                 self.coef.data_ptr(), g.grad_ptr_of(bn.weight), g.grad_ptr_of(bn.bias), 0, self.bcoef.data_ptr(),
-                 g.fin_ws.data_ptr(), g.fin_ws.numel(), None)
+        call("plyolo_bn_act_bwd_reduce", g.dtype, M, Cout, dout, self.out.ld, zt, Cout, self.coef.data_ptr(), self.act,
+             self.bpartial.data_ptr(), None)
+        call("plyolo_bn_bwd_finalize", self.bpartial.data_ptr(), self.brows, Cout, float(M), ptr(bn.weight),
+             self.coef.data_ptr(), g.grad_ptr_of(bn.weight), g.grad_ptr_of(bn.bias), 0, self.bcoef.data_ptr(),
+             g.fin_ws.data_ptr(), g.fin_ws.numel(), None)
         dz = g.scratch.data_ptr()
         call("plyolo_bn_act_bwd_dz", g.dtype, M, Cout, dout, self.out.ld, zt, Cout, self.coef.data_ptr(),
              self.bcoef.data_ptr(), self.act, dz, Cout, None)

@@ -45,8 +45,9 @@ class Packed:
         self.Cout_p8 = (Cout + 7) // 8 * 8
         taps = k * k
         dev = w.device
-        self.wp = torch.zeros(taps * Cout * self.Cin_p, dtype=tdtype(dt), device=dev)
-        self.wpd = torch.zeros(taps * self.Cin_p * self.Cout_p8, dtype=tdtype(dt), device=dev)
+        n_wp, n_wpd = _lib.pack_elems(dt, Cout, self.Cin_p, k)
+        self.wp = torch.zeros(n_wp, dtype=tdtype(dt), device=dev)
+        self.wpd = torch.zeros(n_wpd, dtype=tdtype(dt), device=dev)
         self.nslab = nslab  # room for the wgrad slabs; set_slabs(desc) before unpack()
         self.dwp = torch.zeros(nslab * taps * Cout * self.Cin_p, dtype=torch.float32, device=dev)
         self.dw = torch.zeros_like(self.w)

@@ -33,6 +33,12 @@ SHAPES = [
     (2, 32, 32, 32, 8, 3, 2),       # Cout 8: a single 16-byte output vector per pixel
     (2, 16, 16, 16, 8, 1, 1),
     (1, 160, 160, 32, 8, 3, 2),
+    (16, 80, 80, 64, 128, 3, 1),    # >= 384 tiles of 16x16: the 256-pixel tile (8 fragments per wave)
+    (4, 160, 160, 32, 64, 3, 1),    # 16x16 tile, BN 64 (2x2 waves)
+    (8, 160, 160, 16, 32, 3, 1),    # 16x16 tile, BN 32 (4 waves along pixels)
+    (16, 80, 80, 256, 128, 1, 1),   # pointwise, 16x16 tile, 4 chunks
+    (6, 72, 88, 48, 80, 3, 1),      # 16x16 tile with ragged edges, Cin tail chunk (48 = 32 + 16), Cout 80
+    (2, 160, 160, 64, 64, 3, 2),    # stride 2 dgrad parity classes on 16x16 tiles
 ]
 
 
@@ -199,48 +205,3 @@ def test_head_pred_backward_bf16(cout):
     e3 = hu.relerr(pk.db, gb)
     print("head_pred_bwd", cout, "dgrad %.3g wgrad %.3g bias %.3g" % (e1, e2, e3))
     assert e1 <= 2.0 ** -6 and e2 <= 1e-4 and e3 <= 1e-4
-
-
-@pytest.mark.parametrize("shape", [(2, 16, 16, 16, 32, 3, 1), (2, 40, 40, 64, 256, 3, 1), (3, 18, 22, 16, 32, 3, 2), (2, 20, 20, 512, 256, 1, 1)],
-                         ids=str)
-def test_conv_fwd_fused_bn_finish(shape):
-    """plyolo_conv2d_fwd_bn: statistics finished by the last-arriving workgroup (coef, running
-    stats, counter) == F.batch_norm statistics of the conv output; slots/counters self-clean."""
-    from pl_yolo_amd._lib import BnFuse
-    N, H, W, Cin, Cout, k, s = shape
-    torch.manual_seed(sum(shape) + 5)
-    x = hu.rnd_bf16(torch.randn(N, Cin, H, W, device=hu.DEV))
-    w = hu.rnd_bf16(torch.randn(Cout, Cin, k, k, device=hu.DEV) / (Cin * k * k) ** 0.5)
-    ref = _ref_conv(x, w, s)
-    OH, OW = ref.shape[2:]
-    xm, pk = hu.to_nhwc(x, BF16, Cin), hu.Packed(w, BF16)
-    y = torch.empty(N * OH * OW, Cout, dtype=torch.bfloat16, device=hu.DEV)
-    gamma, beta = torch.rand(Cout, device=hu.DEV) + 0.5, torch.rand(Cout, device=hu.DEV) - 0.5
-    rm, rv = torch.zeros(Cout, device=hu.DEV), torch.ones(Cout, device=hu.DEV)
-    nbt = torch.zeros(1, dtype=torch.int64, device=hu.DEV)
-    coef = torch.zeros(4 * Cout, device=hu.DEV)
-    d = hu.conv_desc(BF16, N, H, W, Cin, Cout, k, s, Cin, Cout)
-    nrows = hu._lib.lib().plyolo_conv2d_stat_rows(C.byref(d))
-    ngr = (nrows + 31) // 32
-    rows_t = torch.zeros(2 * nrows * Cout, device=hu.DEV)
-    gpart = torch.zeros(2 * ngr * Cout, device=hu.DEV)
-    gcnt = torch.zeros((Cout // 32 + 2) * ngr, dtype=torch.int32, device=hu.DEV)
-    fcnt = torch.zeros(Cout // 32 + 2, dtype=torch.int32, device=hu.DEV)
-    f = BnFuse()
-    f.gamma, f.beta, f.running_mean, f.running_var, f.num_batches_tracked = gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(), nbt.data_ptr()
-    f.coef, f.rows, f.gpart, f.gcnt, f.fcnt = coef.data_ptr(), rows_t.data_ptr(), gpart.data_ptr(), gcnt.data_ptr(), fcnt.data_ptr()
-    f.count, f.eps, f.momentum = float(N * OH * OW), 1e-3, 0.03
-    for rep in range(2):
-        call("plyolo_conv2d_fwd_bn", C.byref(d), xm.data_ptr(), pk.wp.data_ptr(), y.data_ptr(), C.byref(f), hu.stream())
-    torch.cuda.synchronize()
-    assert hu.relerr(hu.from_nhwc(y, N, OH, OW, Cout), ref) <= 2.0 ** -7
-    mean, var = ref.mean((0, 2, 3)), ref.var((0, 2, 3), unbiased=False)
-    invstd = 1 / torch.sqrt(var + 1e-3)
-    assert hu.relerr(coef[2 * Cout:3 * Cout], mean) < 2e-4 and hu.relerr(coef[3 * Cout:], invstd) < 2e-4
-    assert hu.relerr(coef[:Cout], gamma * invstd) < 2e-4
-    assert float((coef[Cout:2 * Cout] - (beta - mean * gamma * invstd)).abs().max()) < 2e-3
-    assert int(nbt) == 2 and int(gcnt.abs().sum()) == 0 and int(fcnt.abs().sum()) == 0
-    n = N * OH * OW
-    rm_ref = 0.03 * mean * (1 + 0.97)
-    rv_ref = 0.97 * (0.97 * 1 + 0.03 * var * n / (n - 1)) + 0.03 * var * n / (n - 1)
-    assert hu.relerr(rm, rm_ref) < 5e-4 and hu.relerr(rv, rv_ref) < 5e-4
