@@ -37,6 +37,8 @@ struct ConvP {
   int so, oy_off, ox_off;
   int si, iy_off, ix_off;
   int ITH, ITW;
+  int rowp;  // LDS pitch of one halo-tile image row (bytes): a multiple of 256 when si == 1, so that the two
+             // image rows a 32-pixel A fragment spans land on disjoint banks (conflict-free ds_read_b128)
   int ntaps;
   int tiles_y, tiles_x, nmb;
   int accumulate;
@@ -47,6 +49,7 @@ struct ConvP {
   // whose s_waitcnt vmcnt(0) would also drain the in-flight weight prefetch every tap
   unsigned long long taps_lo;
   unsigned int taps_hi;
+  int ablate;  // diagnostics (PLYOLO_ABLATE): 1 skip epilogue, 4 reload no halo after chunk 0, 8 skip MFMA, 16 skip weight loads, 32 skip LDS fragment reads
 };
 
 DEVINL unsigned tap_code(const ConvP& p, int t) {
@@ -72,7 +75,7 @@ DEVINL u32x4 add_bf16x8(u32x4 a, u32x4 b) {
 //     fragment order, so a wave's B fragment is ONE coalesced 1-KiB global load (L2/L1 resident),
 //     prefetched one tap ahead in registers.  No per-tap barrier: waves only meet when the halo
 //     tile is replaced, so MFMA, LDS reads and the loads of the co-resident workgroup overlap.
-template <int BN, int CK, int TH, bool OUT_F32>
+template <int BN, int CK, int TH, bool OUT_F32, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvP p) {
   constexpr int BM = TH * TW;
   constexpr int WN = BN / 32, WM = 4 / WN, MT = BM / (32 * WM);
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvP p) {
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int m = (wm * MT + mt) * 32 + r;
-    arow[mt] = (((m >> 4) * p.si) * p.ITW + (m & 15) * p.si) * ROWB + h * 16;
+    arow[mt] = ((m >> 4) * p.si) * p.rowp + ((m & 15) * p.si) * ROWB + h * 16;
   }
 
   f32x16 acc[MT];
@@ -135,12 +138,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvP p) {
     }
   };
 
+  constexpr int abl = ABL;  // compile-time diagnostics switch (see ConvP::ablate)
   load_b(0, bcur);
   int phase = 0;
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     const int c0 = chunk * CK;
     __syncthreads();  // every wave is done reading the previous chunk's halo tile
-    {
+    if (!(abl & 4) || chunk == 0) {
       // halo tile: issue a whole batch of 16-byte loads before the first LDS write so that
       // HV loads per thread are in flight at once (a load->wait->write loop serialises them)
       constexpr int HV = 6;
@@ -166,36 +170,50 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvP p) {
           const int idx = base + tid + v * 256;
           if (idx < nvec) {
             const int pix = idx / CV, cv = idx - pix * CV;
-            *(u32x4*)(smem + pix * ROWB + cv * 16) = hv[v];
+            const int iy = pix / p.ITW, ix = pix - iy * p.ITW;
+            *(u32x4*)(smem + iy * p.rowp + ix * ROWB + cv * 16) = hv[v];
           }
         }
       }
     }
     __syncthreads();  // halo tile visible
     for (int t = 0; t < p.ntaps; ++t, ++phase) {
-      if (phase + 1 < total) load_b(phase + 1, bnext);
+      if (phase + 1 < total && !(abl & 16)) load_b(phase + 1, bnext);
       const unsigned tc = tap_code(p, t);
-      const int toff = ((int)(tc & 3u) * p.ITW + (int)((tc >> 2) & 3u)) * ROWB;
+      const int toff = (int)(tc & 3u) * p.rowp + (int)((tc >> 2) & 3u) * ROWB;
 #pragma unroll
       for (int kk = 0; kk < KS; ++kk) {
         bf16x8 a[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) a[mt] = *(const bf16x8*)(smem + arow[mt] + toff + kk * 32);
         const bf16x8 b = *(const bf16x8*)&bcur[kk];
 #pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[mt] = (abl & 32) ? b : *(const bf16x8*)(smem + arow[mt] + toff + kk * 32);
+        if (!(abl & 8))
+#pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b, acc[mt], 0, 0, 0);
+        else
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][0] += (float)a[mt][0];
       }
 #pragma unroll
       for (int kk = 0; kk < KS; ++kk) bcur[kk] = bnext[kk];
     }
   }
   __syncthreads();  // all LDS operand reads retired; LDS is reused for the epilogue
+  if (abl & 1) {  // keep every accumulator live, skip the epilogue
+    float t = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t += acc[mt][i];
+    if (t == 12345.f) ((float*)p.y)[0] = t;
+    return;
+  }
 
   // ---- epilogue ---------------------------------------------------------------
   constexpr int SROW = OUT_F32 ? (BN + 4) * 4 : (BN * 2 + 16);  // staging row pitch (bytes)
   float* red = (float*)(smem + BM * SROW);                       // [WM][2][BN]
 
-  if (p.stats != nullptr) {
+  if (p.stats != nullptr && !(abl & 64)) {
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -214,6 +232,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvP p) {
       red[(wm * 2 + 1) * BN + wn * 32 + r] = s2;
     }
   }
+  if (!(abl & 256))
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -227,7 +246,15 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvP p) {
     }
   __syncthreads();
 
-  if (p.stats != nullptr && tid < BN) {
+  if (abl & 256) {
+    float t = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t += acc[mt][i];
+    if (t == 12345.f) ((float*)p.y)[0] = t;
+  }
+  if (p.stats != nullptr && tid < BN && !(abl & 64)) {
     float s = 0.f, ss = 0.f;
 #pragma unroll
     for (int w = 0; w < WM; ++w) {
@@ -241,6 +268,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvP p) {
     }
   }
 
+  if (abl & 128) return;
   if (OUT_F32) {
     float* y = (float*)p.y;
     for (int idx = tid; idx < BM * BN; idx += 256) {
@@ -273,14 +301,36 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvP p) {
 }
 
 template <int BN, int CK, int TH, bool OUT_F32>
-hipError_t launch_inst(const ConvP& p, hipStream_t s) {
+hipError_t launch_inst(ConvP p, hipStream_t s) {
   constexpr int BM = TH * TW, WN = BN / 32, WM = 4 / WN;
   constexpr int ROWB = CK * 2 + 16;
   constexpr int SROW = OUT_F32 ? (BN + 4) * 4 : (BN * 2 + 16);
-  size_t lds_main = (size_t)p.ITH * p.ITW * ROWB;
+  p.rowp = p.ITW * ROWB;
+  if (p.si == 1) p.rowp = (p.rowp + 255) & ~255;
+  size_t lds_main = (size_t)p.ITH * p.rowp;
   size_t lds_epi = (size_t)BM * SROW + WM * 2 * BN * 4;
   size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
   auto kern = conv_mfma_kernel<BN, CK, TH, OUT_F32>;
+  if (BN == 128 && CK == 64 && TH == 16 && !OUT_F32 && p.ablate) {  // diagnostic instantiations of the main shape only
+    switch (p.ablate) {
+      case 1: kern = conv_mfma_kernel<128, 64, 16, false, 1>; break;
+      case 8: kern = conv_mfma_kernel<128, 64, 16, false, 8>; break;
+      case 9: kern = conv_mfma_kernel<128, 64, 16, false, 9>; break;
+      case 41: kern = conv_mfma_kernel<128, 64, 16, false, 41>; break;
+      case 57: kern = conv_mfma_kernel<128, 64, 16, false, 57>; break;
+      case 61: kern = conv_mfma_kernel<128, 64, 16, false, 61>; break;
+      case 33: kern = conv_mfma_kernel<128, 64, 16, false, 33>; break;
+      case 5: kern = conv_mfma_kernel<128, 64, 16, false, 5>; break;
+      case 16: kern = conv_mfma_kernel<128, 64, 16, false, 16>; break;
+      case 37: kern = conv_mfma_kernel<128, 64, 16, false, 37>; break;
+      case 64: kern = conv_mfma_kernel<128, 64, 16, false, 64>; break;
+      case 128: kern = conv_mfma_kernel<128, 64, 16, false, 128>; break;
+      case 192: kern = conv_mfma_kernel<128, 64, 16, false, 192>; break;
+      case 256: kern = conv_mfma_kernel<128, 64, 16, false, 256>; break;
+      case 448: kern = conv_mfma_kernel<128, 64, 16, false, 448>; break;
+      default: break;
+    }
+  }
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -338,6 +388,7 @@ void set_taps(ConvP& p) {
 // choose the tiles, then derive the grid; ext = halo extent beyond (T-1)*si (per axis)
 void finish(ConvP& p, int ext_y, int ext_x, bool out_f32, int* BN, int* CK, int* TH) {
   set_taps(p);
+  if (const char* e = getenv("PLYOLO_ABLATE")) p.ablate = atoi(e);
   pick_tiles(p, ext_y, out_f32, BN, CK, TH);
   p.ITH = (*TH - 1) * p.si + ext_y;
   p.ITW = (TW - 1) * p.si + ext_x;
