@@ -81,11 +81,11 @@ typedef struct plyolo_conv_desc {
 
 /* y[n,oh,ow,co] = sum x[n,oh*s+kh-p,ow*s+kw-p,ci] * w[co,ci,kh,kw] (+ bias[co]).
  * wp: packed fwd weights.  bias: fp32[Cout] or NULL.
- * stats: NULL, or fp32 [2][plyolo_conv2d_stat_rows(d)][Cout] receiving per-block
- * partial sums of y and y^2 (train-mode BatchNorm statistics, fused epilogue). */
+ * stats: NULL, or the fp64 stat slots [PLYOLO_STAT_SLOTS][2][Cout] (see the BatchNorm section;
+ * zeroed by the caller) that receive the sums of y and y^2 (train-mode BatchNorm statistics,
+ * fused epilogue). */
 int plyolo_conv2d_fwd(const plyolo_conv_desc* d, const void* x, const void* wp, const float* bias,
-                      void* y, float* stats, void* stream);
-int plyolo_conv2d_stat_rows(const plyolo_conv_desc* d);
+                      void* y, double* stats, void* stream);
 /* dx = conv_transpose(dy, w).  wpd: packed dgrad weights.  accumulate!=0: dx += */
 int plyolo_conv2d_dgrad(const plyolo_conv_desc* d, const void* dy, const void* wpd, void* dx,
                         int accumulate, void* stream);
@@ -129,34 +129,45 @@ int plyolo_unpack_wgrads(const plyolo_pack_entry* table_dev, int n, int max_elem
 
 /* ------------------------------------------------- BatchNorm + activation
  * Replaces nn.BatchNorm2d(eps=1e-3, momentum=0.03) + SiLU of BaseConv
- * (models/layers/normalization.py:8, network_blocks.py:30-37) fwd and bwd. */
-/* Reduce conv-epilogue partials -> mean / biased var -> coef[0:C]=scale,
- * coef[C:2C]=shift, coef[2C:3C]=mean, coef[3C:4C]=invstd; update running stats
- * (unbiased var) and num_batches_tracked (int64) when non-NULL. */
-int plyolo_bn_finalize(const float* stats, int rows, int C, double count, const float* gamma,
-                       const float* beta, float eps, float momentum, float* running_mean,
-                       float* running_var, int64_t* num_batches_tracked, float* coef,
-                       void* workspace, size_t ws_bytes, void* stream);
-/* workspace: chunk partials + arrival counters; must be ZEROED once by the caller (the
- * counters reset themselves after every launch) and may be shared by all layers that
- * run on one stream. */
-size_t plyolo_bn_finalize_workspace(int C);
+ * (models/layers/normalization.py:8, network_blocks.py:30-37) fwd and bwd.
+ *
+ * Per-channel batch statistics travel in STAT SLOTS: fp64 [PLYOLO_STAT_SLOTS][2][C]
+ * accumulators (sum, sum of squares) that the producing kernel adds to with agent-scope fp64
+ * atomics (one add per workgroup and channel; fp64 makes the order of the adds irrelevant to
+ * the fp32 result).  The CALLER zeroes the slots before the producing launch.  The consuming
+ * kernel sums the slots itself, so there is no separate finalize launch on the hot path. */
+#define PLYOLO_STAT_SLOTS 8
+typedef struct plyolo_bn_stats {
+  const double* slots;        /* [PLYOLO_STAT_SLOTS][2][C] filled by plyolo_conv2d_fwd */
+  double count;               /* N*OH*OW */
+  const float* gamma;         /* may be NULL (1) */
+  const float* beta;          /* may be NULL (0) */
+  float eps, momentum;
+  float* running_mean;        /* updated in place when non-NULL (unbiased var, like torch) */
+  float* running_var;
+  int64_t* num_batches_tracked;
+} plyolo_bn_stats;
+/* Standalone reduction of the slots -> coef[0:C]=scale, [C:2C]=shift, [2C:3C]=mean, [3C:4C]=invstd
+ * (+ running statistics).  Not needed when plyolo_bn_act_fwd is given `st`. */
+int plyolo_bn_finalize(const plyolo_bn_stats* st, int C, float* coef, void* stream);
 /* eval mode: coef from running statistics */
 int plyolo_bn_eval_coef(int C, const float* gamma, const float* beta, const float* running_mean,
                         const float* running_var, float eps, float* coef, void* stream);
-/* out = act(z*scale+shift) (+ res).  z [M][C] pitch z_ld; out pitch o_ld; res pitch r_ld or NULL */
-int plyolo_bn_act_fwd(int dtype, int M, int C, const void* z, int z_ld, const float* coef, int act,
-                      const void* res, int r_ld, void* out, int o_ld, void* stream);
-/* partial[2][rows][C]: sum du, sum du*zhat  with du = dout * act'(u) */
-int plyolo_bn_bwd_rows(int M);
+/* out = act(z*scale+shift) (+ res).  z [M][C] pitch z_ld; out pitch o_ld; res pitch r_ld or NULL.
+ * st == NULL: coef is an INPUT.  st != NULL (train mode): every workgroup derives scale/shift from
+ * the stat slots, and coef (the 4C values above, needed by the backward kernels) plus the running
+ * statistics are WRITTEN by this launch. */
+int plyolo_bn_act_fwd(int dtype, int M, int C, const void* z, int z_ld, float* coef, int act,
+                      const void* res, int r_ld, void* out, int o_ld, const plyolo_bn_stats* st, void* stream);
+/* bslots (fp64 [PLYOLO_STAT_SLOTS][2][C], zeroed by the caller) += sum du, sum du*zhat
+ * with du = dout * act'(u) */
 int plyolo_bn_act_bwd_reduce(int dtype, int M, int C, const void* dout, int d_ld, const void* z, int z_ld,
-                             const float* coef, int act, float* partial, void* stream);
-/* dgamma/dbeta (+)=; bcoef[0:C]=A, [C:2C]=B, [2C:3C]=Cc so that dz = A*du + B*z + Cc */
-int plyolo_bn_bwd_finalize(const float* partial, int rows, int C, double count, const float* gamma,
-                           const float* coef, float* dgamma, float* dbeta, int accumulate, float* bcoef,
-                           void* workspace, size_t ws_bytes, void* stream); /* workspace: as bn_finalize */
+                             const float* coef, int act, double* bslots, void* stream);
+/* dz = A*du + B*z + Cc with A,B,Cc derived from bslots inside the launch; also writes
+ * dgamma / dbeta (fp32 [C], may be NULL; accumulate != 0: +=). */
 int plyolo_bn_act_bwd_dz(int dtype, int M, int C, const void* dout, int d_ld, const void* z, int z_ld,
-                         const float* coef, const float* bcoef, int act, void* dz, int dz_ld, void* stream);
+                         const float* coef, const double* bslots, const float* gamma, float* dgamma,
+                         float* dbeta, int accumulate, int act, void* dz, int dz_ld, void* stream);
 
 /* -------------------------------------------------- data movement kernels */
 /* Focus space-to-depth (network_blocks.py:50-65): NCHW fp32 image ->

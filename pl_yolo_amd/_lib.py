@@ -22,6 +22,15 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("dtype", "N", "H", "W", "Cin", "Cout", "ksize", "stride", "x_ld", "y_ld", "y_f32")]
 
 
+STAT_SLOTS = 8  # PLYOLO_STAT_SLOTS
+
+
+class BnStats(C.Structure):
+    _fields_ = [("slots", C.c_void_p), ("count", C.c_double), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("eps", C.c_float), ("momentum", C.c_float), ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
+                ("num_batches_tracked", C.c_void_p)]
+
+
 class PackEntry(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("w", "wp", "wpd", "dwp", "dw", "b", "bp", "dbp", "db")] + [
         (n, C.c_int) for n in ("Cout", "Cin", "Cin_p", "ksize", "Cout_total", "Cout_p8", "co_off", "nslab")
@@ -93,7 +102,6 @@ SIGNATURES = {
     "plyolo_plan_profile": (_i, [_vp, _vp, _vp, _i]),
     "plyolo_plan_op_info": (_i, [_vp, _i, C.c_char_p, _i, _P(_d), _P(_d)]),
     "plyolo_conv2d_fwd": (_i, [_P(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
-    "plyolo_conv2d_stat_rows": (_i, [_P(ConvDesc)]),
     "plyolo_conv2d_dgrad": (_i, [_P(ConvDesc), _vp, _vp, _vp, _i, _vp]),
     "plyolo_conv2d_wgrad": (_i, [_P(ConvDesc), _vp, _vp, _vp, _vp]),
     "plyolo_conv2d_wgrad_slabs": (_i, [_P(ConvDesc)]),
@@ -101,14 +109,11 @@ SIGNATURES = {
     "plyolo_pack_weights": (_i, [_vp, _i, _i, _i, _vp]),
     "plyolo_pack_elems": (_i, [_i, _i, _i, _i, _P(_sz), _P(_sz)]),
     "plyolo_unpack_wgrads": (_i, [_vp, _i, _i, _i, _vp]),
-    "plyolo_bn_finalize": (_i, [_vp, _i, _i, _d, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "plyolo_bn_finalize_workspace": (_sz, [_i]),
+    "plyolo_bn_finalize": (_i, [_P(BnStats), _i, _vp, _vp]),
     "plyolo_bn_eval_coef": (_i, [_i, _vp, _vp, _vp, _vp, _f, _vp, _vp]),
-    "plyolo_bn_act_fwd": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp]),
-    "plyolo_bn_bwd_rows": (_i, [_i]),
+    "plyolo_bn_act_fwd": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _P(BnStats), _vp]),
     "plyolo_bn_act_bwd_reduce": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp]),
-    "plyolo_bn_bwd_finalize": (_i, [_vp, _i, _i, _d, _vp, _vp, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
-    "plyolo_bn_act_bwd_dz": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp]),
+    "plyolo_bn_act_bwd_dz": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp]),
     "plyolo_focus_s2d": (_i, [_i, _vp, _i, _i, _i, _vp, _i, _vp]),
     "plyolo_copy_add": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _i, _vp]),
     "plyolo_upsample2x_fwd": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),

@@ -36,14 +36,12 @@ void take_annotation(PlanOp* op) {
   g_ann_flops = g_ann_bytes = 0.0;
 }
 
-int conv_mfma_stat_rows(const plyolo_conv_desc* d);
-int conv_mfma_fwd(const plyolo_conv_desc*, const void*, const void*, const float*, void*, float*, void*);
+int conv_mfma_fwd(const plyolo_conv_desc*, const void*, const void*, const float*, void*, double*, void*);
 void conv_mfma_pack_elems(int Cout_total, int Cin_p, int ksize, size_t* wp, size_t* wpd);
 int conv_mfma_dgrad(const plyolo_conv_desc*, const void*, const void*, void*, int, void*);
 int conv_mfma_wgrad(const plyolo_conv_desc*, const void*, const void*, float*, void*);
 int conv_mfma_wgrad_slabs(const plyolo_conv_desc*);
-int conv_ref_stat_rows(const plyolo_conv_desc* d);
-int conv_ref_fwd(const plyolo_conv_desc*, const void*, const void*, const float*, void*, float*, void*);
+int conv_ref_fwd(const plyolo_conv_desc*, const void*, const void*, const float*, void*, double*, void*);
 int conv_ref_dgrad(const plyolo_conv_desc*, const void*, const void*, void*, int, void*);
 int conv_ref_wgrad(const plyolo_conv_desc*, const void*, const void*, float*, void*);
 
@@ -164,11 +162,7 @@ int plyolo_plan_graph_launch(plyolo_plan* p, void* stream) {
   return 0;
 }
 
-int plyolo_conv2d_stat_rows(const plyolo_conv_desc* d) {
-  if (check_conv(d, "conv2d_stat_rows", true)) return -1;
-  return d->dtype == PLYOLO_BF16 ? conv_mfma_stat_rows(d) : conv_ref_stat_rows(d);
-}
-int plyolo_conv2d_fwd(const plyolo_conv_desc* d, const void* x, const void* wp, const float* bias, void* y, float* stats, void* stream) {
+int plyolo_conv2d_fwd(const plyolo_conv_desc* d, const void* x, const void* wp, const float* bias, void* y, double* stats, void* stream) {
   if (check_conv(d, "conv2d_fwd", true)) return -1;
   return d->dtype == PLYOLO_BF16 ? conv_mfma_fwd(d, x, wp, bias, y, stats, stream) : conv_ref_fwd(d, x, wp, bias, y, stats, stream);
 }

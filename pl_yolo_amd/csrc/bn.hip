@@ -9,85 +9,68 @@
 // the pixel rows, so the per-channel coefficients live in registers, consecutive
 // lanes touch consecutive 16-byte vectors of a pixel row (full 128-byte lines), and
 // there is no integer division in the loop.
-//   bn_finalize      conv-epilogue partials -> mean/var -> (scale, shift, mean, invstd),
-//                    running statistics; chunked over many workgroups, the last one to
-//                    arrive finishes (agent-scope release/acquire, counter self-resets)
-//   bn_act_fwd       out = act(z*scale+shift) (+ residual)      strided output = concat
-//   bn_act_bwd_reduce  per-channel  sum du, sum du*zhat  (du = dout*act'(u)) partials
-//   bn_bwd_finalize  dgamma/dbeta + the three coefficients of  dz = A*du + B*z + Cc
-//   bn_act_bwd_dz    dz
+//
+// Batch statistics arrive in fp64 STAT SLOTS (include/plyolo.h): the producer (conv epilogue or
+// bn_act_bwd_reduce) adds one partial per workgroup and channel with agent-scope fp64 atomics;
+// the consumer's workgroups each sum the 8 slots in their prologue (a few KB from L2) and derive
+// the per-channel coefficients themselves -- no finalize launch between producer and consumer.
+//   bn_act_fwd         out = act(z*scale+shift) (+ residual); strided output = concat;
+//                      workgroup 0 also publishes coef (for the backward) + running statistics
+//   bn_act_bwd_reduce  per-channel  sum du, sum du*zhat  (du = dout*act'(u))  -> slots
+//   bn_act_bwd_dz      dz = A*du + B*z + Cc ; workgroup 0 publishes dgamma / dbeta
 #include "common.h"
 
 namespace {
 
-constexpr int FIN_CHUNKS = 32;
+constexpr int NSLOT = PLYOLO_STAT_SLOTS;
+constexpr int BN_MAXC = 2048;  // channels per launch (LDS: 3 floats per channel)
 
-struct FinWs {
-  double* part;        // [FIN_CHUNKS][2][C]
-  unsigned* counter;   // [ceil(C/32)]
-};
+DEVINL void slot_add(double* p, double v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* stats, int rows, int C, double count, const float* gamma,
-                                                          const float* beta, float eps, float momentum, float* rmean, float* rvar,
-                                                          int64_t* nbt, float* coef, FinWs ws, int nchunk) {
-  // 32 channels x 8 row-slices per block; blockIdx.y = row chunk
-  __shared__ double red[2][8][32];
-  __shared__ int s_last;
-  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
-  const int per = (rows + nchunk - 1) / nchunk;
-  const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
-  double s = 0.0, ss = 0.0;
-  if (c < C)
-    for (int r = r0 + sl; r < r1; r += 8) {
-      s += stats[(size_t)r * C + c];
-      ss += stats[((size_t)rows + r) * C + c];
-    }
-  red[0][sl][cl] = s;
-  red[1][sl][cl] = ss;
-  __syncthreads();
-  if (sl == 0 && c < C) {
-    for (int k = 1; k < 8; ++k) { s += red[0][k][cl]; ss += red[1][k][cl]; }
-    ws.part[((size_t)blockIdx.y * 2 + 0) * C + c] = s;
-    ws.part[((size_t)blockIdx.y * 2 + 1) * C + c] = ss;
+// sums of the stat slots for channel c
+DEVINL void slot_sums(const double* slots, int C, int c, double* s, double* ss) {
+  double a = 0.0, b = 0.0;
+#pragma unroll
+  for (int r = 0; r < NSLOT; ++r) {
+    a += slots[((size_t)r * 2 + 0) * C + c];
+    b += slots[((size_t)r * 2 + 1) * C + c];
   }
-  // publish this chunk, then take a ticket; the last arriver reduces all chunks
-  __threadfence();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // keep the drain (ROCm 7.2 may drop the fence's own wait)
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned t = atomicAdd(&ws.counter[blockIdx.x], 1u);
-    s_last = (t == (unsigned)nchunk - 1u) ? 1 : 0;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();
-  if (sl == 0 && c < C) {
-    s = 0.0; ss = 0.0;
-    for (int k = 0; k < nchunk; ++k) {
-      s += ws.part[((size_t)k * 2 + 0) * C + c];
-      ss += ws.part[((size_t)k * 2 + 1) * C + c];
-    }
-    const double mean = s / count;
-    double var = ss / count - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-    const float scale = g * invstd;
+  *s = a;
+  *ss = b;
+}
+
+// (scale, shift, mean, invstd) of channel c from the slot sums; optionally the running statistics
+DEVINL void bn_coef(const plyolo_bn_stats& st, int C, int c, bool publish, float* coef, float* scale_o, float* shift_o) {
+  double s, ss;
+  slot_sums(st.slots, C, c, &s, &ss);
+  const double mean = s / st.count;
+  double var = ss / st.count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)st.eps));
+  const float g = st.gamma ? st.gamma[c] : 1.f, b = st.beta ? st.beta[c] : 0.f;
+  const float scale = g * invstd, shift = b - (float)mean * scale;
+  *scale_o = scale;
+  *shift_o = shift;
+  if (publish) {
     coef[c] = scale;
-    coef[C + c] = b - (float)mean * scale;
+    coef[C + c] = shift;
     coef[2 * C + c] = (float)mean;
     coef[3 * C + c] = invstd;
-    if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
-    if (rvar) {
-      const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-      rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+    const float mom = st.momentum;
+    if (st.running_mean) st.running_mean[c] = (1.f - mom) * st.running_mean[c] + mom * (float)mean;
+    if (st.running_var) {
+      const double unb = st.count > 1.0 ? var * st.count / (st.count - 1.0) : var;
+      st.running_var[c] = (1.f - mom) * st.running_var[c] + mom * (float)unb;
     }
+    if (c == 0 && st.num_batches_tracked) *st.num_batches_tracked += 1;
   }
-  if (threadIdx.x == 0) {
-    ws.counter[blockIdx.x] = 0u;  // ready for the next launch
-    if (nbt && blockIdx.x == 0) *nbt += 1;
-  }
+}
+
+__global__ void bn_finalize_kernel(plyolo_bn_stats st, int C, float* coef) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float sc, sh;
+  bn_coef(st, C, c, true, coef, &sc, &sh);
 }
 
 __global__ void bn_eval_coef_kernel(int C, const float* gamma, const float* beta, const float* rmean, const float* rvar,
@@ -113,10 +96,16 @@ struct ColMap {
   }
 };
 
-template <typename T>
-__global__ __launch_bounds__(256) void bn_act_fwd_kernel(int M, int C, const T* __restrict__ z, int z_ld, const float* __restrict__ coef,
-                                                         int act, const T* __restrict__ res, int r_ld, T* __restrict__ out, int o_ld) {
+template <typename T, bool FUSED>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(int M, int C, const T* __restrict__ z, int z_ld, float* coef, int act,
+                                                         const T* __restrict__ res, int r_ld, T* __restrict__ out, int o_ld,
+                                                         plyolo_bn_stats st) {
   constexpr int V = Vec<T>::N;
+  __shared__ float s_co[FUSED ? 2 * BN_MAXC : 2];
+  if (FUSED) {
+    for (int c = threadIdx.x; c < C; c += 256) bn_coef(st, C, c, blockIdx.x == 0, coef, &s_co[c], &s_co[C + c]);
+    __syncthreads();
+  }
   const int cvn = C / V;
   const ColMap cm(cvn);
   if (cm.trow >= cm.rpb) return;
@@ -126,8 +115,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(int M, int C, const T* 
     float sc[V], sh[V];
 #pragma unroll
     for (int i = 0; i < V; ++i) {
-      sc[i] = coef ? coef[c + i] : 1.f;
-      sh[i] = coef ? coef[C + c + i] : 0.f;
+      if (FUSED) { sc[i] = s_co[c + i]; sh[i] = s_co[C + c + i]; }
+      else { sc[i] = coef ? coef[c + i] : 1.f; sh[i] = coef ? coef[C + c + i] : 0.f; }
     }
 #pragma unroll 2
     for (int m = blockIdx.x * cm.rpb + cm.trow; m < M; m += step) {
@@ -144,16 +133,16 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(int M, int C, const T* 
   }
 }
 
-// partial[0][row][c] = sum du ; partial[1][row][c] = sum du * zhat ; one partial row per block
+// bslots[slot][0][c] += sum du ; bslots[slot][1][c] += sum du * zhat ; one add per block and channel
 template <typename T>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(int M, int C, const T* __restrict__ dout, int d_ld, const T* __restrict__ z,
-                                                                int z_ld, const float* __restrict__ coef, int act, float* partial, int rows) {
+                                                                int z_ld, const float* __restrict__ coef, int act, double* bslots) {
   constexpr int V = Vec<T>::N;
   __shared__ float red[256 * 2 * V];
   const int cvn = C / V;
   const ColMap cm(cvn);
   const int step = gridDim.x * cm.rpb;
-  const int row = blockIdx.x;
+  double* slot = bslots + (size_t)(blockIdx.x % NSLOT) * 2 * C;
   for (int cv0 = 0; cv0 < cvn; cv0 += cm.cols) {
     const int cv = cv0 + cm.tcol;
     float s1[V], s2[V];
@@ -191,72 +180,36 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(int M, int C, co
         }
 #pragma unroll
       for (int i = 0; i < V; ++i) {
-        partial[(size_t)row * C + cv * V + i] = s1[i];
-        partial[((size_t)rows + row) * C + cv * V + i] = s2[i];
+        slot_add(slot + cv * V + i, (double)s1[i]);
+        slot_add(slot + C + cv * V + i, (double)s2[i]);
       }
     }
   }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* partial, int rows, int C, double count, const float* gamma,
-                                                              const float* coef, float* dgamma, float* dbeta, int accumulate, float* bcoef,
-                                                              FinWs ws, int nchunk) {
-  // same chunked last-arriver reduction as bn_finalize_kernel
-  __shared__ double red[2][8][32];
-  __shared__ int s_last;
-  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
-  const int per = (rows + nchunk - 1) / nchunk;
-  const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
-  double s = 0.0, ss = 0.0;
-  if (c < C)
-    for (int r = r0 + sl; r < r1; r += 8) {
-      s += partial[(size_t)r * C + c];
-      ss += partial[((size_t)rows + r) * C + c];
-    }
-  red[0][sl][cl] = s;
-  red[1][sl][cl] = ss;
-  __syncthreads();
-  if (sl == 0 && c < C) {
-    for (int k = 1; k < 8; ++k) { s += red[0][k][cl]; ss += red[1][k][cl]; }
-    ws.part[((size_t)blockIdx.y * 2 + 0) * C + c] = s;
-    ws.part[((size_t)blockIdx.y * 2 + 1) * C + c] = ss;
-  }
-  __threadfence();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned t = atomicAdd(&ws.counter[blockIdx.x], 1u);
-    s_last = (t == (unsigned)nchunk - 1u) ? 1 : 0;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();
-  if (sl == 0 && c < C) {
-    s = 0.0; ss = 0.0;
-    for (int k = 0; k < nchunk; ++k) {
-      s += ws.part[((size_t)k * 2 + 0) * C + c];
-      ss += ws.part[((size_t)k * 2 + 1) * C + c];
-    }
-    const float db = (float)s, dg = (float)ss;
-    if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + db;
-    if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + dg;
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_bwd_dz_kernel(int M, int C, const T* __restrict__ dout, int d_ld, const T* __restrict__ z,
+                                                            int z_ld, const float* __restrict__ coef, const double* __restrict__ bslots,
+                                                            double count, const float* gamma, float* dgamma, float* dbeta,
+                                                            int accumulate, int act, T* __restrict__ dz, int dz_ld) {
+  constexpr int V = Vec<T>::N;
+  __shared__ float s_b[3 * BN_MAXC];
+  // dz = A*du + B*z + Cc with A = gamma*invstd, B = -A*invstd*mean(du*zhat), Cc = -A*mean(du) - B*mean
+  for (int c = threadIdx.x; c < C; c += 256) {
+    double s, ss;
+    slot_sums(bslots, C, c, &s, &ss);
     const float mean = coef[2 * C + c], invstd = coef[3 * C + c];
     const float A = (gamma ? gamma[c] : 1.f) * invstd;
     const float B = (float)(-(double)A * (ss / count) * (double)invstd);
-    const float Cc = (float)(-(double)A * (s / count) - (double)B * (double)mean);
-    bcoef[c] = A;
-    bcoef[C + c] = B;
-    bcoef[2 * C + c] = Cc;
+    s_b[c] = A;
+    s_b[C + c] = B;
+    s_b[2 * C + c] = (float)(-(double)A * (s / count) - (double)B * (double)mean);
+    if (blockIdx.x == 0) {
+      if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s;
+      if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)ss;
+    }
   }
-  if (threadIdx.x == 0) ws.counter[blockIdx.x] = 0u;
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void bn_act_bwd_dz_kernel(int M, int C, const T* __restrict__ dout, int d_ld, const T* __restrict__ z,
-                                                            int z_ld, const float* __restrict__ coef, const float* __restrict__ bcoef,
-                                                            int act, T* __restrict__ dz, int dz_ld) {
-  constexpr int V = Vec<T>::N;
+  __syncthreads();
   const int cvn = C / V;
   const ColMap cm(cvn);
   if (cm.trow >= cm.rpb) return;
@@ -267,7 +220,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_dz_kernel(int M, int C, const 
 #pragma unroll
     for (int i = 0; i < V; ++i) {
       sc[i] = coef[c + i]; sh[i] = coef[C + c + i];
-      A[i] = bcoef[c + i]; B[i] = bcoef[C + c + i]; Cc[i] = bcoef[2 * C + c + i];
+      A[i] = s_b[c + i]; B[i] = s_b[C + c + i]; Cc[i] = s_b[2 * C + c + i];
     }
 #pragma unroll 2
     for (int m = blockIdx.x * cm.rpb + cm.trow; m < M; m += step) {
@@ -285,10 +238,11 @@ __global__ __launch_bounds__(256) void bn_act_bwd_dz_kernel(int M, int C, const 
   }
 }
 
+// 256 CUs x 4 workgroups; every workgroup re-reads the stat slots, so keep the grid bounded
 inline int stream_grid(int M, int cvn) {
   const int cols = cvn < 256 ? cvn : 256, rpb = 256 / cols;
   int g = (M + rpb - 1) / rpb;
-  if (g > 2048) g = 2048;  // 256 CUs x 8 workgroups, grid-stride the rest
+  if (g > 1024) g = 1024;
   return g < 1 ? 1 : g;
 }
 
@@ -302,25 +256,12 @@ using plyolo::submit;
 
 extern "C" {
 
-// layout: arrival counters FIRST (fixed offset: the workspace is shared by layers of different C),
-// chunk partials after them
-constexpr size_t FIN_COUNTER_BYTES = 1024;  // up to 256 column blocks = 8192 channels
-size_t plyolo_bn_finalize_workspace(int C) { return FIN_COUNTER_BYTES + (size_t)FIN_CHUNKS * 2 * C * sizeof(double); }
-
-int plyolo_bn_finalize(const float* stats, int rows, int C, double count, const float* gamma, const float* beta, float eps,
-                       float momentum, float* running_mean, float* running_var, int64_t* nbt, float* coef, void* workspace,
-                       size_t ws_bytes, void* stream) {
-  PLY_CHECK_ARG(workspace != nullptr && ws_bytes >= plyolo_bn_finalize_workspace(C), "bn_finalize: workspace too small");
-  FinWs ws;
-  ws.counter = (unsigned*)workspace;
-  ws.part = (double*)((unsigned char*)workspace + FIN_COUNTER_BYTES);
-  int nchunk = rows / 32;
-  if (nchunk < 1) nchunk = 1;
-  if (nchunk > FIN_CHUNKS) nchunk = FIN_CHUNKS;
-  plyolo::annotate("bn_finalize", 0.0, 8.0 * rows * C);
+int plyolo_bn_finalize(const plyolo_bn_stats* stp, int C, float* coef, void* stream) {
+  PLY_CHECK_ARG(stp && stp->slots && stp->count > 0 && coef, "bn_finalize: incomplete plyolo_bn_stats");
+  const plyolo_bn_stats st = *stp;
+  plyolo::annotate("bn_finalize", 0.0, 16.0 * NSLOT * C);
   return submit(stream, [=](hipStream_t s) -> hipError_t {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32), nchunk), dim3(256), 0, s, stats, rows, C, count, gamma, beta, eps, momentum,
-                       running_mean, running_var, nbt, coef, ws, nchunk);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, st, C, coef);
     return hipGetLastError();
   });
 }
@@ -333,65 +274,56 @@ int plyolo_bn_eval_coef(int C, const float* gamma, const float* beta, const floa
   });
 }
 
-int plyolo_bn_act_fwd(int dtype, int M, int C, const void* z, int z_ld, const float* coef, int act, const void* res, int r_ld,
-                      void* out, int o_ld, void* stream) {
+int plyolo_bn_act_fwd(int dtype, int M, int C, const void* z, int z_ld, float* coef, int act, const void* res, int r_ld,
+                      void* out, int o_ld, const plyolo_bn_stats* stp, void* stream) {
   const int V = dtype == PLYOLO_BF16 ? 8 : 4;
   PLY_CHECK_ARG(C % V == 0 && z_ld % V == 0 && o_ld % V == 0 && (!res || r_ld % V == 0), "bn_act_fwd: C/ld must be multiples of %d", V);
+  PLY_CHECK_ARG(!stp || (stp->slots && stp->count > 0 && coef && C <= BN_MAXC), "bn_act_fwd: incomplete plyolo_bn_stats (or C > %d)", BN_MAXC);
   const int grid = stream_grid(M, C / V);
+  plyolo_bn_stats st{};
+  if (stp) st = *stp;
+  const bool fused = stp != nullptr;
   plyolo::annotate("bn_act_fwd", 0.0, (double)M * C * (dtype == PLYOLO_BF16 ? 2.0 : 4.0) * (res ? 3.0 : 2.0));
   return submit(stream, [=](hipStream_t s) -> hipError_t {
-    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_fwd_kernel<T>, dim3(grid), dim3(256), 0, s, M, C, (const T*)z, z_ld, coef, act,
-                                         (const T*)res, r_ld, (T*)out, o_ld);)
+    DISPATCH_T(dtype, {
+      if (fused)
+        hipLaunchKernelGGL((bn_act_fwd_kernel<T, true>), dim3(grid), dim3(256), 0, s, M, C, (const T*)z, z_ld, coef, act, (const T*)res,
+                           r_ld, (T*)out, o_ld, st);
+      else
+        hipLaunchKernelGGL((bn_act_fwd_kernel<T, false>), dim3(grid), dim3(256), 0, s, M, C, (const T*)z, z_ld, coef, act, (const T*)res,
+                           r_ld, (T*)out, o_ld, st);
+    })
     return hipGetLastError();
   });
-}
-
-int plyolo_bn_bwd_rows(int M) {
-  int r = M / 64;
-  if (r < 1) r = 1;
-  if (r > 1024) r = 1024;
-  return r;
 }
 
 int plyolo_bn_act_bwd_reduce(int dtype, int M, int C, const void* dout, int d_ld, const void* z, int z_ld, const float* coef,
-                             int act, float* partial, void* stream) {
+                             int act, double* bslots, void* stream) {
   const int V = dtype == PLYOLO_BF16 ? 8 : 4;
   PLY_CHECK_ARG(C % V == 0 && z_ld % V == 0 && d_ld % V == 0, "bn_act_bwd_reduce: C/ld must be multiples of %d", V);
-  const int rows = plyolo_bn_bwd_rows(M);
+  int rows = M / 64;
+  if (rows < 1) rows = 1;
+  if (rows > 1024) rows = 1024;
   plyolo::annotate("bn_act_bwd_reduce", 0.0, (double)M * C * (dtype == PLYOLO_BF16 ? 2.0 : 4.0) * 2.0);
   return submit(stream, [=](hipStream_t s) -> hipError_t {
     DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<T>, dim3(rows), dim3(256), 0, s, M, C, (const T*)dout, d_ld,
-                                         (const T*)z, z_ld, coef, act, partial, rows);)
-    return hipGetLastError();
-  });
-}
-
-int plyolo_bn_bwd_finalize(const float* partial, int rows, int C, double count, const float* gamma, const float* coef,
-                           float* dgamma, float* dbeta, int accumulate, float* bcoef, void* workspace, size_t ws_bytes, void* stream) {
-  PLY_CHECK_ARG(workspace != nullptr && ws_bytes >= plyolo_bn_finalize_workspace(C), "bn_bwd_finalize: workspace too small");
-  FinWs ws;
-  ws.counter = (unsigned*)workspace;
-  ws.part = (double*)((unsigned char*)workspace + FIN_COUNTER_BYTES);
-  int nchunk = rows / 32;
-  if (nchunk < 1) nchunk = 1;
-  if (nchunk > FIN_CHUNKS) nchunk = FIN_CHUNKS;
-  plyolo::annotate("bn_bwd_finalize", 0.0, 8.0 * rows * C);
-  return submit(stream, [=](hipStream_t s) -> hipError_t {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32), nchunk), dim3(256), 0, s, partial, rows, C, count, gamma, coef, dgamma,
-                       dbeta, accumulate, bcoef, ws, nchunk);
+                                         (const T*)z, z_ld, coef, act, bslots);)
     return hipGetLastError();
   });
 }
 
 int plyolo_bn_act_bwd_dz(int dtype, int M, int C, const void* dout, int d_ld, const void* z, int z_ld, const float* coef,
-                         const float* bcoef, int act, void* dz, int dz_ld, void* stream) {
+                         const double* bslots, const float* gamma, float* dgamma, float* dbeta, int accumulate, int act, void* dz,
+                         int dz_ld, void* stream) {
   const int V = dtype == PLYOLO_BF16 ? 8 : 4;
   PLY_CHECK_ARG(C % V == 0 && z_ld % V == 0 && d_ld % V == 0 && dz_ld % V == 0, "bn_act_bwd_dz: C/ld must be multiples of %d", V);
+  PLY_CHECK_ARG(C <= BN_MAXC && bslots && coef, "bn_act_bwd_dz: C > %d or missing slots/coef", BN_MAXC);
   const int grid = stream_grid(M, C / V);
+  const double count = (double)M;
   plyolo::annotate("bn_act_bwd_dz", 0.0, (double)M * C * (dtype == PLYOLO_BF16 ? 2.0 : 4.0) * 3.0);
   return submit(stream, [=](hipStream_t s) -> hipError_t {
     DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_bwd_dz_kernel<T>, dim3(grid), dim3(256), 0, s, M, C, (const T*)dout, d_ld, (const T*)z,
-                                         z_ld, coef, bcoef, act, (T*)dz, dz_ld);)
+                                         z_ld, coef, bslots, count, gamma, dgamma, dbeta, accumulate, act, (T*)dz, dz_ld);)
     return hipGetLastError();
   });
 }

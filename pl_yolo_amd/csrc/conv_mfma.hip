@@ -30,7 +30,7 @@ struct ConvP {
   const bf16_t* w;   // fragment-native packed weights (see frag_index)
   void* y;
   const float* bias;
-  float* stats;
+  double* stats;  // fp64 stat slots [PLYOLO_STAT_SLOTS][2][Cout] or NULL
   int N, H, W, Cin, Cout, x_ld, y_ld;
   int OHt, OWt;  // extent of the output position grid handled by this launch
   int OHf, OWf;  // full output tensor spatial dims
@@ -262,9 +262,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvP p) {
       ss += red[(w * 2 + 1) * BN + tid];
     }
     const int co = cout0 + tid;
-    if (co < p.Cout) {
-      p.stats[(size_t)tile * p.Cout + co] = s;
-      p.stats[((size_t)p.nmb + tile) * p.Cout + co] = ss;
+    if (co < p.Cout) {  // one fp64 add per workgroup and channel (agent scope); the order cannot change the fp32 result
+      double* slot = p.stats + (size_t)(tile % PLYOLO_STAT_SLOTS) * 2 * p.Cout;
+      __hip_atomic_fetch_add(slot + co, (double)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(slot + p.Cout + co, (double)ss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 
@@ -437,16 +438,8 @@ void conv_mfma_pack_elems(int Cout_total, int Cin_p, int ksize, size_t* wp, size
   *wpd = taps * ((Cin_p + 31) / 32) * ((Cout_total + 15) / 16) * 512;
 }
 
-// number of per-block stat rows a forward launch writes
-int conv_mfma_stat_rows(const plyolo_conv_desc* d) {
-  ConvP p{};
-  int BN, CK, TH;
-  setup_fwd(d, p, &BN, &CK, &TH);
-  return p.nmb;
-}
-
 int conv_mfma_fwd(const plyolo_conv_desc* d, const void* x, const void* wp, const float* bias, void* y,
-                  float* stats, void* stream) {
+                  double* stats, void* stream) {
   ConvP p{};
   p.x = (const bf16_t*)x;
   p.w = (const bf16_t*)wp;

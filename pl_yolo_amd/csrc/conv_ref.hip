@@ -102,8 +102,8 @@ __global__ void k_conv_ref_wgrad(const float* x, const float* dy, float* dwp, in
   atomicAdd(dwp + idx, (float)acc);
 }
 
-// per-channel sum / sum of squares partials of y [M][C] (pitch ld): stats[2][rows][C]
-__global__ void channel_stats_f32(const float* y, size_t M, int C, int ld, float* stats, int rows) {
+// per-channel sum / sum of squares of y [M][C] (pitch ld), added to the fp64 stat slots (block b -> slot b % NSLOTS)
+__global__ void channel_stats_f32(const float* y, size_t M, int C, int ld, double* stats, int rows) {
   const int row = blockIdx.x;
   const size_t chunk = (M + rows - 1) / rows;
   const size_t m0 = (size_t)row * chunk, m1 = m0 + chunk < M ? m0 + chunk : M;
@@ -114,8 +114,9 @@ __global__ void channel_stats_f32(const float* y, size_t M, int C, int ld, float
       s += v;
       ss += v * v;
     }
-    stats[(size_t)row * C + c] = (float)s;
-    stats[((size_t)rows + row) * C + c] = (float)ss;
+    double* slot = stats + (size_t)(row % PLYOLO_STAT_SLOTS) * 2 * C;
+    __hip_atomic_fetch_add(slot + c, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(slot + C + c, ss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -124,7 +125,6 @@ __global__ void channel_stats_f32(const float* y, size_t M, int C, int ld, float
 namespace plyolo {
 
 constexpr int REF_STAT_ROWS = 64;
-int conv_ref_stat_rows(const plyolo_conv_desc*) { return REF_STAT_ROWS; }
 
 static RefP make(const plyolo_conv_desc* d) {
   RefP p{};
@@ -137,7 +137,7 @@ static RefP make(const plyolo_conv_desc* d) {
   return p;
 }
 
-int conv_ref_fwd(const plyolo_conv_desc* d, const void* x, const void* wp, const float* bias, void* y, float* stats,
+int conv_ref_fwd(const plyolo_conv_desc* d, const void* x, const void* wp, const float* bias, void* y, double* stats,
                  void* stream) {
   RefP p = make(d);
   p.x = (const float*)x; p.w = (const float*)wp; p.y = (float*)y; p.bias = bias;

@@ -20,7 +20,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import BF16, F32, ACT, ConvDesc, PackEntry, YoloxDesc, yolov7_desc, call, ptr
+from ._lib import BF16, F32, ACT, STAT_SLOTS, BnStats, ConvDesc, PackEntry, YoloxDesc, yolov7_desc, call, ptr
 
 BN_EPS_DEFAULT = 1e-3
 
@@ -129,7 +129,15 @@ class Graph:
         self.scratch = torch.empty(max(self.scratch_elems, 8), dtype=self.tdtype, device=dev)
         self.scratch32 = torch.zeros(max(self.scratch_f32, 8), dtype=torch.float32, device=dev)
         cmax = max([c.Cout_total for c in self.convs] + [8])
-        self.fin_ws = torch.zeros(_lib.lib().plyolo_bn_finalize_workspace(cmax), dtype=torch.uint8, device=dev)
+        # fp64 stat slots of every BatchNorm (forward: sum z, sum z^2; backward: sum du, sum du*zhat);
+        # one memset per plan zeroes a whole arena (zero_fwd_stats / zero_bwd_stats)
+        off = 0
+        for op in self.ops:
+            if isinstance(op, ConvUnitOp) and op.bn is not None:
+                op.slot_off = off
+                off += STAT_SLOTS * 2 * op.Cout
+        self.stat_arena = torch.zeros(max(off, 8), dtype=torch.float64, device=dev)
+        self.bstat_arena = torch.zeros(max(off, 8), dtype=torch.float64, device=dev)
         # weight arenas
         wp_n = sum(_align(c.wp_elems) for c in self.convs)
         dwp_n = sum(_align(c.dwp_elems * c.nslab) for c in self.convs)
@@ -165,6 +173,13 @@ class Graph:
                 entries.append((e, w, b))
                 self.max_pack_elems = max(self.max_pack_elems, c.ksize * c.ksize * w.shape[0] * c.Cin_p)
         self.pack_entries = entries
+
+    def zero_fwd_stats(self):
+        if self.training:
+            call("plyolo_memset_async", self.stat_arena.data_ptr(), 0, self.stat_arena.numel() * 8, None)
+
+    def zero_bwd_stats(self):
+        call("plyolo_memset_async", self.bstat_arena.data_ptr(), 0, self.bstat_arena.numel() * 8, None)
 
     def build_pack_table(self, grad_ptr_of):
         """Device copy of the PackEntry table; `grad_ptr_of(param)` -> device address of
@@ -302,37 +317,31 @@ class ConvUnitOp:
         if hasattr(self, "coef"):
             return
         self.desc.x_ld = self.x.ld
-        rows = _lib.lib().plyolo_conv2d_stat_rows(C.byref(self.desc))
-        if rows <= 0:
-            _lib.check(-1, "plyolo_conv2d_stat_rows")
-        self.stat_rows = rows
-        dev = g.device
-        self.stats = torch.empty(2 * rows * self.Cout, dtype=torch.float32, device=dev)
-        self.coef = torch.empty(4 * self.Cout, dtype=torch.float32, device=dev)
-        self.bcoef = torch.empty(3 * self.Cout, dtype=torch.float32, device=dev)
-        self.brows = _lib.lib().plyolo_bn_bwd_rows(self.out.M)
-        self.bpartial = torch.empty(2 * self.brows * self.Cout, dtype=torch.float32, device=dev)
+        self.coef = torch.empty(4 * self.Cout, dtype=torch.float32, device=g.device)
 
     def fwd(self):
         g, bn = self.g, self.bn
         self._alloc_small()
         zt = self.z.tensor
         train_stats = g.training and bn is not None
-        coef = None
-        call("plyolo_conv2d_fwd", C.byref(self.desc), g.aptr(self.x), self.pc.wp, None, zt.data_ptr(),
-             self.stats.data_ptr() if train_stats else None, None)
+        slots = g.stat_arena.data_ptr() + self.slot_off * 8 if train_stats else None
+        call("plyolo_conv2d_fwd", C.byref(self.desc), g.aptr(self.x), self.pc.wp, None, zt.data_ptr(), slots, None)
+        coef, st = None, None
         if bn is not None:
             coef = self.coef.data_ptr()
-            if g.training:
-                call("plyolo_bn_finalize", self.stats.data_ptr(), self.stat_rows, self.Cout, float(self.out.M),
-                     ptr(bn.weight), ptr(bn.bias), float(bn.eps), float(bn.momentum), ptr(bn.running_mean),
-                     ptr(bn.running_var), ptr(bn.num_batches_tracked), coef, g.fin_ws.data_ptr(), g.fin_ws.numel(), None)
+            if g.training:   # scale/shift derived from the stat slots inside bn_act_fwd (no finalize launch)
+                st = BnStats()
+                st.slots, st.count = slots, float(self.out.M)
+                st.gamma, st.beta = ptr(bn.weight), ptr(bn.bias)
+                st.eps, st.momentum = float(bn.eps), float(bn.momentum)
+                st.running_mean, st.running_var = ptr(bn.running_mean), ptr(bn.running_var)
+                st.num_batches_tracked = ptr(bn.num_batches_tracked)
             else:
                 call("plyolo_bn_eval_coef", self.Cout, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
                      ptr(bn.running_var), float(bn.eps), coef, None)
         call("plyolo_bn_act_fwd", g.dtype, self.out.M, self.Cout, zt.data_ptr(), self.Cout, coef, self.act,
              g.aptr(self.res) if self.res is not None else None, self.res.ld if self.res is not None else 0,
-             g.aptr(self.out), self.out.ld, None)
+             g.aptr(self.out), self.out.ld, C.byref(st) if st is not None else None, None)
 
     def bwd(self):
         g, bn = self.g, self.bn
@@ -345,14 +354,11 @@ class ConvUnitOp:
         if self.res is not None:
             acc = g.grad_mode(self.res)
             call("plyolo_copy_add", g.dtype, M, Cout, dout, self.out.ld, g.gptr(self.res), self.res.ld, acc, None)
-        call("plyolo_bn_act_bwd_reduce", g.dtype, M, Cout, dout, self.out.ld, zt, Cout, self.coef.data_ptr(), self.act,
-             self.bpartial.data_ptr(), None)
-        call("plyolo_bn_bwd_finalize", self.bpartial.data_ptr(), self.brows, Cout, float(M), ptr(bn.weight),
-             self.coef.data_ptr(), g.grad_ptr_of(bn.weight), g.grad_ptr_of(bn.bias), 0, self.bcoef.data_ptr(),
-             g.fin_ws.data_ptr(), g.fin_ws.numel(), None)
+        bslots = g.bstat_arena.data_ptr() + self.slot_off * 8
+        call("plyolo_bn_act_bwd_reduce", g.dtype, M, Cout, dout, self.out.ld, zt, Cout, self.coef.data_ptr(), self.act, bslots, None)
         dz = g.scratch.data_ptr()
-        call("plyolo_bn_act_bwd_dz", g.dtype, M, Cout, dout, self.out.ld, zt, Cout, self.coef.data_ptr(),
-             self.bcoef.data_ptr(), self.act, dz, Cout, None)
+        call("plyolo_bn_act_bwd_dz", g.dtype, M, Cout, dout, self.out.ld, zt, Cout, self.coef.data_ptr(), bslots, ptr(bn.weight),
+             g.grad_ptr_of(bn.weight), g.grad_ptr_of(bn.bias), 0, self.act, dz, Cout, None)
         call("plyolo_conv2d_wgrad", C.byref(self.desc), g.aptr(self.x), dz, self.pc.dwp, None)
         if self.need_dgrad:
             acc = g.grad_mode(self.x)

@@ -158,6 +158,7 @@ class DetectorRunner:
         s.fwd = G.Plan()
         with s.fwd:
             call("plyolo_pack_weights", g.pack_table.data_ptr(), g.n_pack, g.dtype, g.max_pack_elems, None)
+            g.zero_fwd_stats()
             for op in g.ops:
                 op.fwd()
         s.bwd = None
@@ -167,6 +168,7 @@ class DetectorRunner:
             with s.bwd:
                 if g.dtype != BF16:  # the fp32 parity wgrad accumulates with atomics; the MFMA path overwrites its slabs
                     call("plyolo_memset_async", g.dwp_arena.data_ptr(), 0, g.dwp_arena.numel() * 4, None)
+                g.zero_bwd_stats()
                 for op in reversed(g.ops):
                     op.bwd()
                 call("plyolo_unpack_wgrads", g.pack_table.data_ptr(), g.n_pack, g.max_pack_elems, 0, None)

@@ -63,9 +63,7 @@ def test_conv_fwd_stats(dt, shape):
     pk = hu.Packed(w, dt)
     y = torch.full((N * OH * OW, y_ld), 3.0, dtype=hu.tdtype(dt), device=hu.DEV)
     d = hu.conv_desc(dt, N, H, W, Cin, Cout, k, s, x_ld, y_ld)
-    rows = hu._lib.lib().plyolo_conv2d_stat_rows(C.byref(d))
-    assert rows > 0
-    stats = torch.full((2, rows, Cout), float("nan"), device=hu.DEV)
+    stats = torch.zeros(hu._lib.STAT_SLOTS, 2, Cout, dtype=torch.float64, device=hu.DEV)   # fp64 stat slots
     call("plyolo_conv2d_fwd", C.byref(d), xm.data_ptr(), pk.wp.data_ptr(), None, y.data_ptr(), stats.data_ptr(), hu.stream())
     torch.cuda.synchronize()
     got = hu.from_nhwc(y, N, OH, OW, Cout)
@@ -75,11 +73,10 @@ def test_conv_fwd_stats(dt, shape):
     assert err <= tol
     assert torch.all(y[:, Cout:].float() == 3.0), "pad columns of the output pitch were overwritten"
     # fused BatchNorm statistics (computed from the fp32 accumulators)
-    s1 = stats[0].double().sum(0)
-    s2 = stats[1].double().sum(0)
+    s1 = stats[:, 0].sum(0)
+    s2 = stats[:, 1].sum(0)
     r1 = ref.double().sum((0, 2, 3))
     r2 = (ref.double() ** 2).sum((0, 2, 3))
-    assert not torch.isnan(stats).any()
     assert float((s1 - r1).abs().max()) <= 2e-4 * float(ref.abs().sum((0, 2, 3)).max())
     assert float((s2 - r2).abs().max()) <= 2e-4 * float(r2.max())
 

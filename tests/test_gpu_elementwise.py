@@ -45,24 +45,33 @@ def test_bn_act_fwd_bwd(dt, act):
     M = N * H * W
     zm = hu.to_nhwc(z.detach(), dt, Cc)
     resm = hu.to_nhwc(res, dt, Cc + 8)
-    # statistics partials as the conv epilogue would produce them (3 row blocks)
-    zz = zm.float()
-    rows = 200  # > 64 rows per chunk -> several chunk workgroups + last-arriver reduction
-    stats = torch.zeros(2, rows, Cc, device=hu.DEV)
-    for r, chunk in enumerate(torch.chunk(zz, rows, 0)):
-        stats[0, r] = chunk.sum(0)
-        stats[1, r] = (chunk * chunk).sum(0)
+    # statistics as the conv epilogue leaves them: partial sums spread over the fp64 stat slots
+    zz = zm.double()
+    S = hu._lib.STAT_SLOTS
+    stats = torch.zeros(S, 2, Cc, dtype=torch.float64, device=hu.DEV)
+    for r, chunk in enumerate(torch.chunk(zz, 3 * S, 0)):
+        stats[r % S, 0] += chunk.sum(0)
+        stats[r % S, 1] += (chunk * chunk).sum(0)
     coef = torch.zeros(4 * Cc, device=hu.DEV)
+    coef2 = torch.zeros(4 * Cc, device=hu.DEV)
     nbt = torch.zeros(1, dtype=torch.int64, device=hu.DEV)
-    wsb = hu._lib.lib().plyolo_bn_finalize_workspace(Cc)
-    fws = torch.zeros(wsb, dtype=torch.uint8, device=hu.DEV)
-    for _ in range(2):  # second launch checks the self-resetting arrival counters
-        rm.zero_(); rv.fill_(1.0); nbt.zero_()
-        call("plyolo_bn_finalize", stats.data_ptr(), rows, Cc, float(M), gamma.data_ptr(), beta.data_ptr(), 1e-3, 0.03,
-             rm.data_ptr(), rv.data_ptr(), nbt.data_ptr(), coef.data_ptr(), fws.data_ptr(), wsb, hu.stream())
+    st = hu._lib.BnStats()
+    st.slots, st.count, st.gamma, st.beta = stats.data_ptr(), float(M), gamma.data_ptr(), beta.data_ptr()
+    st.eps, st.momentum = 1e-3, 0.03
+    # standalone finalize (no running statistics) ...
+    call("plyolo_bn_finalize", C.byref(st), Cc, coef2.data_ptr(), hu.stream())
+    # ... and the fused form: bn_act_fwd derives scale/shift itself and publishes coef + running statistics
+    st.running_mean, st.running_var, st.num_batches_tracked = rm.data_ptr(), rv.data_ptr(), nbt.data_ptr()
     out = torch.full((M, Cc + 16), 2.0, dtype=hu.tdtype(dt), device=hu.DEV)
     call("plyolo_bn_act_fwd", dt, M, Cc, zm.data_ptr(), Cc, coef.data_ptr(), hu._lib.ACT[act], resm.data_ptr(), Cc + 8,
-         out.data_ptr(), Cc + 16, hu.stream())
+         out.data_ptr(), Cc + 16, C.byref(st), hu.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(coef, coef2)
+    out_b = torch.full((M, Cc + 16), 2.0, dtype=hu.tdtype(dt), device=hu.DEV)   # coef as an input gives the same bytes
+    call("plyolo_bn_act_fwd", dt, M, Cc, zm.data_ptr(), Cc, coef.data_ptr(), hu._lib.ACT[act], resm.data_ptr(), Cc + 8,
+         out_b.data_ptr(), Cc + 16, None, hu.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(out, out_b)
     torch.cuda.synchronize()
     assert int(nbt) == 1
     assert hu.relerr(rm, rm_ref) < 1e-5 and hu.relerr(rv, rv_ref) < 1e-5
@@ -72,16 +81,12 @@ def test_bn_act_fwd_bwd(dt, act):
     assert torch.all(out[:, Cc:].float() == 2.0)
     # backward
     dm = hu.to_nhwc(dout, dt, Cc + 8)
-    brows = hu._lib.lib().plyolo_bn_bwd_rows(M)
-    part = torch.zeros(2 * brows * Cc, device=hu.DEV)
-    bcoef = torch.zeros(3 * Cc, device=hu.DEV)
+    bslots = torch.zeros(hu._lib.STAT_SLOTS, 2, Cc, dtype=torch.float64, device=hu.DEV)
     dg, db = torch.zeros(Cc, device=hu.DEV), torch.zeros(Cc, device=hu.DEV)
     dz = torch.zeros(M, Cc, dtype=hu.tdtype(dt), device=hu.DEV)
-    call("plyolo_bn_act_bwd_reduce", dt, M, Cc, dm.data_ptr(), Cc + 8, zm.data_ptr(), Cc, coef.data_ptr(), hu._lib.ACT[act], part.data_ptr(), hu.stream())
-    call("plyolo_bn_bwd_finalize", part.data_ptr(), brows, Cc, float(M), gamma.data_ptr(), coef.data_ptr(), dg.data_ptr(), db.data_ptr(), 0,
-         bcoef.data_ptr(), fws.data_ptr(), wsb, hu.stream())
-    call("plyolo_bn_act_bwd_dz", dt, M, Cc, dm.data_ptr(), Cc + 8, zm.data_ptr(), Cc, coef.data_ptr(), bcoef.data_ptr(), hu._lib.ACT[act],
-         dz.data_ptr(), Cc, hu.stream())
+    call("plyolo_bn_act_bwd_reduce", dt, M, Cc, dm.data_ptr(), Cc + 8, zm.data_ptr(), Cc, coef.data_ptr(), hu._lib.ACT[act], bslots.data_ptr(), hu.stream())
+    call("plyolo_bn_act_bwd_dz", dt, M, Cc, dm.data_ptr(), Cc + 8, zm.data_ptr(), Cc, coef.data_ptr(), bslots.data_ptr(), gamma.data_ptr(),
+         dg.data_ptr(), db.data_ptr(), 0, hu._lib.ACT[act], dz.data_ptr(), Cc, hu.stream())
     torch.cuda.synchronize()
     e1, e2, e3 = hu.relerr(hu.from_nhwc(dz, N, H, W, Cc), gz), hu.relerr(dg, gg), hu.relerr(db, gb)
     print("bn_act_bwd", act, "dz %.3g dgamma %.3g dbeta %.3g" % (e1, e2, e3))
@@ -218,26 +223,3 @@ def test_sgd_ema():
     torch.cuda.synchronize()
     assert hu.relerr(p, ref_p.data) < 1e-6
     assert hu.relerr(ema, ema_ref) < 1e-6
-
-
-def test_bn_finalize_shared_workspace_across_layers():
-    """One finalize workspace serves layers of different widths back to back (as the launch
-    plans do): the arrival counters must not alias another layer's chunk partials."""
-    torch.manual_seed(8)
-    wsb = hu._lib.lib().plyolo_bn_finalize_workspace(256)
-    fws = torch.zeros(wsb, dtype=torch.uint8, device=hu.DEV)
-    for rep in range(2):
-        for Cc in (256, 64, 32, 8, 128, 32):
-            rows, M = 2000, 2000 * 128
-            stats = torch.rand(2, rows, Cc, device=hu.DEV) * 100
-            stats[1] += 200 * 128
-            g, b = torch.rand(Cc, device=hu.DEV) + 0.5, torch.rand(Cc, device=hu.DEV)
-            coef = torch.zeros(4 * Cc, device=hu.DEV)
-            call("plyolo_bn_finalize", stats.data_ptr(), rows, Cc, float(M), g.data_ptr(), b.data_ptr(), 1e-3, 0.03,
-                 None, None, None, coef.data_ptr(), fws.data_ptr(), wsb, hu.stream())
-            torch.cuda.synchronize()
-            mean = stats[0].double().sum(0) / M
-            var = stats[1].double().sum(0) / M - mean * mean
-            want = (1 / torch.sqrt(var + 1e-3)).float()
-            assert hu.relerr(coef[3 * Cc:], want) < 1e-5, (rep, Cc)
-            assert hu.relerr(coef[2 * Cc:3 * Cc], mean.float()) < 1e-5, (rep, Cc)

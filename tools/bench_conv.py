@@ -56,8 +56,7 @@ for env in ENVS:
     d = hu.conv_desc(BF16, N, H, W, Cin, Cout, k, s, Cin, Cout)
     pk = hu.Packed(w, BF16, nslab=hu._lib.lib().plyolo_conv2d_wgrad_slabs(C.byref(d)))
     pk.set_slabs(d)
-    rows = hu._lib.lib().plyolo_conv2d_stat_rows(C.byref(d))
-    stats = torch.empty(2 * rows * Cout, device="cuda")
+    stats = torch.zeros(hu._lib.STAT_SLOTS * 2 * Cout, dtype=torch.float64, device="cuda")
     st = hu.stream()
     gf = 2.0 * N * OH * OW * Cout * Cin * k * k / 1e9
     res = []
