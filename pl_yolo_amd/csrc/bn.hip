@@ -178,12 +178,22 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(int M, int C, co
           s1[i] += red[((k * cm.cols + cm.tcol) * 2 + 0) * V + i];
           s2[i] += red[((k * cm.cols + cm.tcol) * 2 + 1) * V + i];
         }
-#pragma unroll
-      for (int i = 0; i < V; ++i) {
-        slot_add(slot + cv * V + i, (double)s1[i]);
-        slot_add(slot + C + cv * V + i, (double)s2[i]);
-      }
     }
+    __syncthreads();
+    // transpose through LDS so that consecutive lanes add to consecutive channels (coalesced atomics)
+    float* tot = red;  // [2][cols*V]
+    const int nch = cm.cols * V;
+    if (cm.trow == 0 && cv < cvn) {
+#pragma unroll
+      for (int i = 0; i < V; ++i) { tot[cm.tcol * V + i] = s1[i]; tot[nch + cm.tcol * V + i] = s2[i]; }
+    }
+    __syncthreads();
+    const int cbase = cv0 * V, cend = C - cbase < nch ? C - cbase : nch;
+    for (int j = threadIdx.x; j < 2 * cend; j += 256) {
+      const int which = j >= cend, cc = j - which * cend;
+      slot_add(slot + (size_t)which * C + cbase + cc, (double)tot[which * nch + cc]);
+    }
+    __syncthreads();
   }
 }
 
