@@ -259,10 +259,10 @@ static WgPlan plan_wgrad(const plyolo_conv_desc* d) {
   p.nci = (p.Cin + w.CI_T - 1) / w.CI_T;
   const int nco = (p.Cout + w.CO_T - 1) / w.CO_T;
   // spatial split: a few workgroups per CU; every split writes a private fp32 slab (S*WK*|dW|
-  // bytes stored once and read once by the unpack pass), capped at ~32 MB and 256 slabs per layer
+  // bytes stored once and read once by the unpack pass), capped at ~32 MB and 1024 slabs per layer
   const double dw_bytes = 4.0 * d->ksize * d->ksize * (double)d->Cout * d->Cin;
   int S = 768 / (nco * p.nci * w.WK);
-  if (S * w.WK > 256) S = 256 / w.WK;
+  if (S * w.WK > 1024) S = 1024 / w.WK;
   const int s_budget = (int)(32.0e6 / (dw_bytes * w.WK));
   if (S > s_budget) S = s_budget;
   if (S < 1) S = 1;

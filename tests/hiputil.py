@@ -38,7 +38,7 @@ def rnd_bf16(x):
 class Packed:
     """Pack one conv weight (+bias) through plyolo_pack_weights."""
 
-    def __init__(self, w, dt, bias=None, cin_p=None, nslab=256):
+    def __init__(self, w, dt, bias=None, cin_p=None, nslab=1):
         Cout, Cin, k, _ = w.shape
         self.w = w.contiguous()
         self.Cin_p = cin_p or Cin
@@ -48,8 +48,9 @@ class Packed:
         n_wp, n_wpd = _lib.pack_elems(dt, Cout, self.Cin_p, k)
         self.wp = torch.zeros(n_wp, dtype=tdtype(dt), device=dev)
         self.wpd = torch.zeros(n_wpd, dtype=tdtype(dt), device=dev)
-        self.nslab = nslab  # room for the wgrad slabs; set_slabs(desc) before unpack()
-        self.dwp = torch.zeros(nslab * taps * Cout * self.Cin_p, dtype=torch.float32, device=dev)
+        self.nslab = nslab  # set_slabs(desc) sizes the wgrad slab buffer for a concrete launch
+        self.slab_elems = taps * Cout * self.Cin_p
+        self.dwp = torch.zeros(nslab * self.slab_elems, dtype=torch.float32, device=dev)
         self.dw = torch.zeros_like(self.w)
         self.bias = bias.contiguous() if bias is not None else None
         self.bp = torch.zeros(max(Cout, 8), dtype=torch.float32, device=dev)
@@ -69,7 +70,11 @@ class Packed:
 
     def set_slabs(self, desc):
         n = _lib.lib().plyolo_conv2d_wgrad_slabs(C.byref(desc))
-        assert 0 < n <= self.nslab, n
+        assert n > 0, n
+        if n > self.nslab:
+            self.nslab = n
+            self.dwp = torch.zeros(n * self.slab_elems, dtype=torch.float32, device=self.w.device)
+            self.entry.dwp = self.dwp.data_ptr()
         self.entry.nslab = n
         arr = (PackEntry * 1)(self.entry)
         self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.w.device)

@@ -54,7 +54,7 @@ for env in ENVS:
     dy = torch.randn(N * OH * OW, Cout, device="cuda").to(torch.bfloat16)
     dx = torch.empty(N * H * W, Cin, dtype=torch.bfloat16, device="cuda")
     d = hu.conv_desc(BF16, N, H, W, Cin, Cout, k, s, Cin, Cout)
-    pk = hu.Packed(w, BF16, nslab=hu._lib.lib().plyolo_conv2d_wgrad_slabs(C.byref(d)))
+    pk = hu.Packed(w, BF16)
     pk.set_slabs(d)
     stats = torch.zeros(hu._lib.STAT_SLOTS * 2 * Cout, dtype=torch.float64, device="cuda")
     st = hu.stream()
