@@ -55,6 +55,18 @@ plyolo_plan* plyolo_plan_create(void);
 void plyolo_plan_destroy(plyolo_plan*);
 int plyolo_plan_begin(plyolo_plan*);           /* start recording on this thread */
 int plyolo_plan_end(plyolo_plan*);             /* stop recording */
+/* Lanes: launches recorded after plyolo_plan_lane(p, l) belong to lane l (default 0).  Launches of
+ * one lane stay ordered; different lanes run concurrently under plyolo_plan_run (each lane is issued on
+ * its own stream, forked from / joined into the caller's stream).  hipGraph replays are captured on
+ * one stream in recorded order.  Order
+ * across lanes is expressed with events: ev = plyolo_plan_record(p, lane) marks "everything recorded
+ * so far on `lane`"; plyolo_plan_wait(p, lane2, ev) makes the later launches of lane2 wait for it.
+ * plyolo_plan_run replays eagerly on real streams with the same fork / events / join;
+ * plyolo_plan_profile times the launches one by one on a single stream in recorded order, which must
+ * therefore be a valid serial order (record before wait). */
+int plyolo_plan_lane(plyolo_plan* p, int lane);
+int plyolo_plan_record(plyolo_plan* p, int lane);          /* returns the event id (>= 0) or < 0 */
+int plyolo_plan_wait(plyolo_plan* p, int lane, int ev);
 int plyolo_plan_size(const plyolo_plan*);      /* number of recorded launches */
 int plyolo_plan_run(plyolo_plan*, void* stream); /* replay eagerly */
 int plyolo_plan_graph_instantiate(plyolo_plan*, void* stream); /* capture into a hipGraphExec */

@@ -96,6 +96,9 @@ SIGNATURES = {
     "plyolo_plan_begin": (_i, [_vp]),
     "plyolo_plan_end": (_i, [_vp]),
     "plyolo_plan_size": (_i, [_vp]),
+    "plyolo_plan_lane": (_i, [_vp, _i]),
+    "plyolo_plan_record": (_i, [_vp, _i]),
+    "plyolo_plan_wait": (_i, [_vp, _i, _i]),
     "plyolo_plan_run": (_i, [_vp, _vp]),
     "plyolo_plan_graph_instantiate": (_i, [_vp, _vp]),
     "plyolo_plan_graph_launch": (_i, [_vp, _vp]),

@@ -60,6 +60,23 @@ static int check_conv(const plyolo_conv_desc* d, const char* who, bool fwd) {
   return 0;
 }
 
+__global__ void fill_bytes_kernel(unsigned char* p, unsigned value, size_t bytes) {
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+  if (i >= bytes) return;
+  if (i + 16 <= bytes && (((size_t)p + i) & 15) == 0) {
+    const unsigned w = value * 0x01010101u;
+    *(u32x4*)(p + i) = u32x4{w, w, w, w};
+  } else {
+    for (size_t k = i; k < bytes && k < i + 16; ++k) p[k] = (unsigned char)value;
+  }
+}
+hipError_t fill_async(void* p, int value, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return hipSuccess;
+  const size_t nthr = (bytes + 15) / 16;
+  hipLaunchKernelGGL(fill_bytes_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, (unsigned char*)p, (unsigned)(value & 0xff), bytes);
+  return hipGetLastError();
+}
+
 }  // namespace plyolo
 
 using namespace plyolo;
@@ -76,6 +93,8 @@ void plyolo_plan_destroy(plyolo_plan* p) {
   if (!q) return;
   if (q->exec) (void)hipGraphExecDestroy(q->exec);
   if (q->graph) (void)hipGraphDestroy(q->graph);
+  for (auto e : q->events) (void)hipEventDestroy(e);
+  for (auto st : q->side) (void)hipStreamDestroy(st);
   if (g_rec == q) g_rec = nullptr;
   delete q;
 }
@@ -90,17 +109,93 @@ int plyolo_plan_end(plyolo_plan* p) {
   g_rec = nullptr;
   return 0;
 }
+// ---- lanes: independent launch sequences that a hipGraph replay may run concurrently ----------
+int plyolo_plan_lane(plyolo_plan* p, int lane) {
+  PLY_CHECK_ARG(g_rec == (Plan*)p && p != nullptr, "plan_lane: this plan is not recording");
+  PLY_CHECK_ARG(lane >= 0 && lane < 16, "plan_lane: lane must be 0..15");
+  Plan* q = (Plan*)p;
+  q->cur_lane = lane;
+  if (lane + 1 > q->nlanes) q->nlanes = lane + 1;
+  return 0;
+}
+int plyolo_plan_record(plyolo_plan* p, int lane) {
+  PLY_CHECK_ARG(g_rec == (Plan*)p && p != nullptr, "plan_record: this plan is not recording");
+  Plan* q = (Plan*)p;
+  PLY_CHECK_ARG(lane >= 0 && lane < q->nlanes, "plan_record: unknown lane %d", lane);
+  PlanOp op;
+  op.kind = 1; op.lane = lane; op.ev = q->nevents++;
+  op.label = "record";
+  q->ops.emplace_back(std::move(op));
+  return q->nevents - 1;
+}
+int plyolo_plan_wait(plyolo_plan* p, int lane, int ev) {
+  PLY_CHECK_ARG(g_rec == (Plan*)p && p != nullptr, "plan_wait: this plan is not recording");
+  Plan* q = (Plan*)p;
+  PLY_CHECK_ARG(lane >= 0 && lane < 16 && ev >= 0 && ev < q->nevents, "plan_wait: bad lane/event");
+  if (lane + 1 > q->nlanes) q->nlanes = lane + 1;
+  PlanOp op;
+  op.kind = 2; op.lane = lane; op.ev = ev;
+  op.label = "wait";
+  q->ops.emplace_back(std::move(op));
+  return 0;
+}
+
 int plyolo_plan_size(const plyolo_plan* p) { return p ? (int)((const Plan*)p)->ops.size() : 0; }
+// Issue every recorded launch: lane l on its own stream (forked from / joined into `s`), events as
+// recorded.  Used both under stream capture (hipGraph) and for eager multi-stream replay.
+static hipError_t issue_lanes(Plan* q, hipStream_t s, bool lanes, size_t* failed) {
+  if (!lanes || q->nlanes <= 1) {  // single stream, recorded order (a valid serialisation of the lanes)
+    hipError_t le = hipSuccess;
+    for (size_t i = 0; i < q->ops.size() && le == hipSuccess; ++i) {
+      if (q->ops[i].kind != 0) continue;
+      le = q->ops[i].fn(s);
+      if (le != hipSuccess && failed) *failed = i;
+    }
+    return le;
+  }
+  while ((int)q->side.size() < q->nlanes - 1) {
+    hipStream_t st;
+    hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (e != hipSuccess) return e;
+    q->side.push_back(st);
+  }
+  const size_t need_ev = (size_t)q->nevents + 2 * (size_t)q->nlanes;
+  while (q->events.size() < need_ev) {
+    hipEvent_t ev;
+    hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e != hipSuccess) return e;
+    q->events.push_back(ev);
+  }
+  auto lane_stream = [&](int l) { return l == 0 ? s : q->side[(size_t)l - 1]; };
+  hipEvent_t* fork_ev = q->events.data() + q->nevents;  // [nlanes] fork, [nlanes] join
+  hipError_t le = hipSuccess;
+  if (q->nlanes > 1) {
+    le = hipEventRecord(fork_ev[0], s);
+    for (int l = 1; l < q->nlanes && le == hipSuccess; ++l) le = hipStreamWaitEvent(lane_stream(l), fork_ev[0], 0);
+  }
+  for (size_t i = 0; i < q->ops.size() && le == hipSuccess; ++i) {
+    const PlanOp& op = q->ops[i];
+    if (op.kind == 0) le = op.fn(lane_stream(op.lane));
+    else if (op.kind == 1) le = hipEventRecord(q->events[(size_t)op.ev], lane_stream(op.lane));
+    else le = hipStreamWaitEvent(lane_stream(op.lane), q->events[(size_t)op.ev], 0);
+    if (le != hipSuccess && failed) *failed = i;
+  }
+  for (int l = 1; l < q->nlanes && le == hipSuccess; ++l) {
+    le = hipEventRecord(fork_ev[q->nlanes + l], lane_stream(l));
+    if (le == hipSuccess) le = hipStreamWaitEvent(s, fork_ev[q->nlanes + l], 0);
+  }
+  return le;
+}
+
 int plyolo_plan_run(plyolo_plan* p, void* stream) {
   PLY_CHECK_ARG(p != nullptr, "plan_run: null plan");
   PLY_CHECK_ARG(g_rec == nullptr, "plan_run: cannot replay while recording");
   Plan* q = (Plan*)p;
-  for (size_t i = 0; i < q->ops.size(); ++i) {
-    hipError_t e = q->ops[i].fn((hipStream_t)stream);
-    if (e != hipSuccess) {
-      set_error("plan_run: launch %zu (%s) failed: %s", i, q->ops[i].label.c_str(), hipGetErrorString(e));
-      return -2;
-    }
+  size_t failed = 0;
+  const hipError_t e = issue_lanes(q, (hipStream_t)stream, true, &failed);
+  if (e != hipSuccess) {
+    set_error("plan_run: launch %zu (%s) failed: %s", failed, failed < q->ops.size() ? q->ops[failed].label.c_str() : "?", hipGetErrorString(e));
+    return -2;
   }
   return 0;
 }
@@ -112,8 +207,9 @@ int plyolo_plan_graph_instantiate(plyolo_plan* p, void* stream) {
   if (q->graph) { (void)hipGraphDestroy(q->graph); q->graph = nullptr; }
   hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
   if (e != hipSuccess) { set_error("hipStreamBeginCapture: %s", hipGetErrorString(e)); return -2; }
-  hipError_t le = hipSuccess;
-  for (size_t i = 0; i < q->ops.size() && le == hipSuccess; ++i) le = q->ops[i].fn(s);
+  // captured single-lane: re-launching a multi-branch graph with event edges gave wrong results on
+  // ROCm 7.2 (second launch), and the eager multi-stream replay is the faster path anyway
+  const hipError_t le = issue_lanes(q, s, false, nullptr);
   e = hipStreamEndCapture(s, &q->graph);
   if (le != hipSuccess || e != hipSuccess) {
     set_error("graph capture failed: %s / %s", hipGetErrorString(le), hipGetErrorString(e));
@@ -135,7 +231,7 @@ int plyolo_plan_profile(plyolo_plan* p, void* stream, float* ms_out, int n) {
     if (hipEventCreate(&e) != hipSuccess) { set_error("plan_profile: hipEventCreate failed"); return -2; }
   hipError_t err = hipEventRecord(ev[0], s);
   for (size_t i = 0; i < q->ops.size() && err == hipSuccess; ++i) {
-    err = q->ops[i].fn(s);
+    if (q->ops[i].kind == 0) err = q->ops[i].fn(s);
     if (err == hipSuccess) err = hipEventRecord(ev[i + 1], s);
   }
   if (err == hipSuccess) err = hipStreamSynchronize(s);

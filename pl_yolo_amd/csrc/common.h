@@ -109,13 +109,20 @@ namespace plyolo {
 void set_error(const char* fmt, ...);
 
 struct PlanOp {
-  std::function<hipError_t(hipStream_t)> fn;
+  std::function<hipError_t(hipStream_t)> fn;  // empty for the ordering markers below
   std::string label;   // kernel family / template instance, for the plan profiler
   double flops = 0.0;  // algorithmic FLOPs of this launch (0 = not a contraction)
   double bytes = 0.0;  // algorithmic HBM bytes of this launch
+  int lane = 0;        // launches of one lane are ordered; lanes run concurrently inside a hipGraph
+  int kind = 0;        // 0 launch, 1 record event `ev` on `lane`, 2 make `lane` wait for event `ev`
+  int ev = -1;
 };
 struct Plan {
   std::vector<PlanOp> ops;
+  int cur_lane = 0;    // lane of the launches being recorded
+  int nlanes = 1, nevents = 0;
+  std::vector<hipStream_t> side;   // capture streams of lanes 1.. (created on first instantiate)
+  std::vector<hipEvent_t> events;  // fork/join + recorded events
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
 };
@@ -130,6 +137,7 @@ template <typename F> int submit(void* stream, F&& fn) {
   if (p) {
     PlanOp op;
     op.fn = std::forward<F>(fn);
+    op.lane = p->cur_lane;
     take_annotation(&op);
     p->ops.emplace_back(std::move(op));
     return 0;
@@ -144,6 +152,11 @@ template <typename F> int submit(void* stream, F&& fn) {
 }
 
 inline hipError_t launch_status() { return hipGetLastError(); }
+
+// Byte fill as an ordinary kernel launch.  (hipMemsetAsync nodes inside a captured hipGraph were
+// observed to misbehave on re-launch for small sizes on ROCm 7.2; a kernel node is always safe.)
+__global__ void fill_bytes_kernel(unsigned char* p, unsigned value, size_t bytes);
+hipError_t fill_async(void* p, int value, size_t bytes, hipStream_t s);
 
 }  // namespace plyolo
 

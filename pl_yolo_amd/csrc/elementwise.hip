@@ -694,7 +694,7 @@ int plyolo_f32_to_act(int dtype, int M, int C, const float* in, void* out, int o
 
 int plyolo_memset_async(void* p, int value, size_t bytes, void* stream) {
   plyolo::annotate("memset", 0.0, (double)bytes);
-  return submit(stream, [=](hipStream_t s) -> hipError_t { return hipMemsetAsync(p, value, bytes, s); });
+  return submit(stream, [=](hipStream_t s) -> hipError_t { return plyolo::fill_async(p, value, bytes, s); });
 }
 
 int plyolo_nhwc_to_nchw_f32(int dtype, int N, int H, int W, int C, const void* in, int i_ld, float* out, void* stream) {
@@ -738,7 +738,7 @@ int plyolo_unpack_wgrads(const plyolo_pack_entry* table_dev, int n, int max_elem
 int plyolo_bias_grad(int dtype, const void* dy, int M, int C, int ld, float* dbias, void* stream) {
   plyolo::annotate("bias_grad", 0.0, (double)M * C * 2.0);
   return submit(stream, [=](hipStream_t s) -> hipError_t {
-    hipError_t e = hipMemsetAsync(dbias, 0, (size_t)C * 4, s);
+    hipError_t e = plyolo::fill_async(dbias, 0, (size_t)C * 4, s);
     if (e != hipSuccess) return e;
     int nb = M / 64;
     if (nb < 1) nb = 1;

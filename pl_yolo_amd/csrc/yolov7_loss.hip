@@ -545,7 +545,7 @@ int plyolo_yolov7_loss_fwd(const plyolo_yolov7_desc* dp, const float* raw, const
   const int nblk = (int)((total + 255) / 256);
   plyolo::annotate("yolov7_loss_fwd", 0.0, (double)total * (5 + d.C) * 4.0);
   return submit(stream, [=](hipStream_t s) -> hipError_t {
-    hipError_t e = hipMemsetAsync((unsigned char*)workspace + zo, 0, zb, s);
+    hipError_t e = plyolo::fill_async((unsigned char*)workspace + zo, 0, zb, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_v7_cand, dim3(d.B), dim3(256), 0, s, d, raw, labels, ws);
     hipLaunchKernelGGL(k_v7_match, dim3(d.B), dim3(256), 0, s, d, raw, labels, ws);
@@ -568,7 +568,7 @@ int plyolo_yolov7_loss_bwd(const plyolo_yolov7_desc* dp, const float* raw, const
   const size_t dbytes = rows * (size_t)d.na * (5 + d.C) * 4;
   plyolo::annotate("yolov7_loss_bwd", 0.0, (double)dbytes);
   return submit(stream, [=](hipStream_t s) -> hipError_t {
-    hipError_t e = hipMemsetAsync(draw, 0, dbytes, s);
+    hipError_t e = plyolo::fill_async(draw, 0, dbytes, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_v7_obj<true>, dim3(nblk), dim3(256), 0, s, d, raw, ws, total, gout, draw);
     hipLaunchKernelGGL(k_v7_bwd_pos, dim3(d.B), dim3(256), 0, s, d, raw, labels, ws, gout, draw);

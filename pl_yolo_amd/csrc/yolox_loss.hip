@@ -572,7 +572,7 @@ int plyolo_yolox_loss_fwd(const plyolo_yolox_desc* dp, const float* raw, const f
   const int nblk = (int)((BA + 255) / 256);
   plyolo::annotate("yolox_loss_fwd", 0.0, (double)BA * (5 + d.C) * 4.0 * 2.0);
   return submit(stream, [=](hipStream_t s) -> hipError_t {
-    hipError_t e = hipMemsetAsync(ws.cnt, 0, BA * 4, s);
+    hipError_t e = plyolo::fill_async(ws.cnt, 0, BA * 4, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_prep, dim3(cdiv(d.A, 256), d.B), dim3(256), 0, s, d, raw, labels, ws);
     hipLaunchKernelGGL(k_topk, dim3(d.M, d.B), dim3(256), 0, s, d, raw, labels, ws);

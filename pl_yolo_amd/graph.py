@@ -16,6 +16,7 @@ Memory model (HBM, everything resident for the whole run):
     accumulate" is resolved at lowering time (no zero-fill passes).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -81,9 +82,9 @@ class Graph:
         self.scratch_f32 = 0    # shared fp32 scratch (maxpool backward)
         self.image_act = None
         self.post_unpack = []   # ops with work that must follow unpack_wgrads
-        import os
-        # in-launch BatchNorm finish (last-arriver hand-off): measured SLOWER than the separate
-        # finalize launches on these short kernels (profiles/README.md), so it is opt-in
+        self.plan = None        # the Plan being recorded (ops use it for lanes / events)
+        # weight gradients on their own lane (PLYOLO_LANES=0 keeps every launch on lane 0)
+        self.use_lanes = os.environ.get("PLYOLO_LANES", "1") != "0"
 
     # ------------------------------------------------------------------ tracing
     def new_act(self, N, H, W, C_, name=""):
@@ -126,7 +127,9 @@ class Graph:
         dev = self.device
         for st in self.storages:
             st.tensor = torch.empty(st.rows * st.ld, dtype=self.tdtype, device=dev)
-        self.scratch = torch.empty(max(self.scratch_elems, 8), dtype=self.tdtype, device=dev)
+        # dz scratch: DZ_BUFS rotating buffers so that the weight-gradient lane can lag the main lane
+        self.scratch = [torch.empty(max(self.scratch_elems, 8), dtype=self.tdtype, device=dev) for _ in range(DZ_BUFS)]
+        self.dz_turn, self.dz_event = 0, [None] * DZ_BUFS
         self.scratch32 = torch.zeros(max(self.scratch_f32, 8), dtype=torch.float32, device=dev)
         cmax = max([c.Cout_total for c in self.convs] + [8])
         # fp64 stat slots of every BatchNorm (forward: sum z, sum z^2; backward: sum du, sum du*zhat);
@@ -173,6 +176,12 @@ class Graph:
                 entries.append((e, w, b))
                 self.max_pack_elems = max(self.max_pack_elems, c.ksize * c.ksize * w.shape[0] * c.Cin_p)
         self.pack_entries = entries
+
+    def join_lanes(self):
+        """Everything recorded on the weight-gradient lane so far happens before what lane 0 records next."""
+        if self.use_lanes:
+            self.plan.wait(0, self.plan.record(1))
+            self.dz_event = [None] * DZ_BUFS
 
     def zero_fwd_stats(self):
         if self.training:
@@ -238,6 +247,9 @@ class Graph:
         for i in range(a.c_off, a.c_off + a.C):
             st.ginit[i] = True
         return acc
+
+
+DZ_BUFS = 4
 
 
 class PackedConv:
@@ -356,10 +368,26 @@ class ConvUnitOp:
             call("plyolo_copy_add", g.dtype, M, Cout, dout, self.out.ld, g.gptr(self.res), self.res.ld, acc, None)
         bslots = g.bstat_arena.data_ptr() + self.slot_off * 8
         call("plyolo_bn_act_bwd_reduce", g.dtype, M, Cout, dout, self.out.ld, zt, Cout, self.coef.data_ptr(), self.act, bslots, None)
-        dz = g.scratch.data_ptr()
+        plan, lanes = g.plan, g.use_lanes
+        k = g.dz_turn
+        g.dz_turn = (k + 1) % DZ_BUFS
+        if lanes and g.dz_event[k] is not None:
+            plan.wait(0, g.dz_event[k])          # the wgrad that last read this buffer has finished
+            g.dz_event[k] = None
+        dz = g.scratch[k].data_ptr()
         call("plyolo_bn_act_bwd_dz", g.dtype, M, Cout, dout, self.out.ld, zt, Cout, self.coef.data_ptr(), bslots, ptr(bn.weight),
              g.grad_ptr_of(bn.weight), g.grad_ptr_of(bn.bias), 0, self.act, dz, Cout, None)
-        call("plyolo_conv2d_wgrad", C.byref(self.desc), g.aptr(self.x), dz, self.pc.dwp, None)
+        if lanes:
+            # the weight gradient only feeds the optimizer: it runs on lane 1, concurrently with the data-gradient
+            # chain of the layers upstream
+            ev = plan.record(0)
+            plan.lane(1)
+            plan.wait(1, ev)
+            call("plyolo_conv2d_wgrad", C.byref(self.desc), g.aptr(self.x), dz, self.pc.dwp, None)
+            g.dz_event[k] = plan.record(1)
+            plan.lane(0)
+        else:
+            call("plyolo_conv2d_wgrad", C.byref(self.desc), g.aptr(self.x), dz, self.pc.dwp, None)
         if self.need_dgrad:
             acc = g.grad_mode(self.x)
             call("plyolo_conv2d_dgrad", C.byref(self.desc), dz, self.pc.wpd, g.gptr(self.x), acc, None)
@@ -761,6 +789,19 @@ class Plan:
     def size(self):
         return _lib.lib().plyolo_plan_size(self.h)
 
+    # lanes (concurrent launch sequences inside a hipGraph replay), see include/plyolo.h
+    def lane(self, l):
+        call("plyolo_plan_lane", self.h, l)
+
+    def record(self, lane):
+        ev = _lib.lib().plyolo_plan_record(self.h, lane)
+        if ev < 0:
+            _lib.check(ev, "plyolo_plan_record")
+        return ev
+
+    def wait(self, lane, ev):
+        call("plyolo_plan_wait", self.h, lane, ev)
+
     def run(self, stream, use_graph=False):
         if use_graph:
             if not self.graph_ready:
@@ -781,7 +822,8 @@ class Plan:
         fl, by = C.c_double(), C.c_double()
         for i in range(n):
             call("plyolo_plan_op_info", self.h, i, buf, 96, C.byref(fl), C.byref(by))
-            out.append((buf.value.decode(), float(ms[i]), fl.value, by.value))
+            if buf.value not in (b"record", b"wait"):   # ordering markers, not launches
+                out.append((buf.value.decode(), float(ms[i]), fl.value, by.value))
         return out
 
     def __del__(self):

@@ -157,6 +157,7 @@ class DetectorRunner:
         # ---- record the forward plan
         s.fwd = G.Plan()
         with s.fwd:
+            g.plan = s.fwd
             call("plyolo_pack_weights", g.pack_table.data_ptr(), g.n_pack, g.dtype, g.max_pack_elems, None)
             g.zero_fwd_stats()
             for op in g.ops:
@@ -166,11 +167,13 @@ class DetectorRunner:
         if mode in ("train", "maps_grad"):
             s.bwd = G.Plan()
             with s.bwd:
+                g.plan = s.bwd
                 if g.dtype != BF16:  # the fp32 parity wgrad accumulates with atomics; the MFMA path overwrites its slabs
                     call("plyolo_memset_async", g.dwp_arena.data_ptr(), 0, g.dwp_arena.numel() * 4, None)
                 g.zero_bwd_stats()
                 for op in reversed(g.ops):
                     op.bwd()
+                g.join_lanes()
                 call("plyolo_unpack_wgrads", g.pack_table.data_ptr(), g.n_pack, g.max_pack_elems, 0, None)
                 for op in g.post_unpack:
                     op.post_unpack()

@@ -148,7 +148,7 @@ def test_hipgraph_replay_matches_eager():
     labels = torch.from_numpy(g["labels"]).to(hu.DEV)
     sd0 = copy.deepcopy(model.state_dict())
     res = []
-    for use_graph in (False, True, True):
+    for use_graph in (False, True, True, False, True):   # eager multi-stream replay and hipGraph replays, interleaved
         model.load_state_dict(sd0)
         model.runner().use_graph = use_graph
         model.zero_grad(set_to_none=True)
@@ -158,7 +158,8 @@ def test_hipgraph_replay_matches_eager():
         res.append((float(out["loss"]), torch.cat([p.grad.flatten() for p in model.parameters() if p.grad is not None]).clone()))
     for r in res[1:]:
         assert abs(r[0] - res[0][0]) <= 1e-5 * abs(res[0][0])
-        assert hu.cossim(r[1], res[0][1]) > 0.99999
+        # same launches, same order per lane: equal up to the fp32 atomics of the six bias-gradient reductions
+        assert float((r[1] - res[0][1]).abs().max()) <= 1e-5 * float(res[0][1].abs().max())
 
 
 def test_module_contract():
