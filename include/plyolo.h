@@ -136,7 +136,10 @@ int plyolo_pack_weights(const plyolo_pack_entry* table_dev, int n, int dtype, in
 /* Element counts of the two packs (the buffers must be zero-initialised ONCE: pad positions are
  * never written). */
 int plyolo_pack_elems(int dtype, int Cout_total, int Cin_p, int ksize, size_t* wp_elems, size_t* wpd_elems);
-/* dw (OIHW) (+)= permute(dwp) for the whole table. */
+/* dwp slab 0 += slabs 1..nslab-1 in a fixed order (elems = floats per slab, multiple of 4): the
+ * host may run this right after a wgrad launch and then unpack with nslab = 1. */
+int plyolo_reduce_slabs(float* dwp, int nslab, size_t elems, void* stream);
+/* dw (OIHW) (+)= permute(sum of the nslab slabs of dwp) for the whole table. */
 int plyolo_unpack_wgrads(const plyolo_pack_entry* table_dev, int n, int max_elems, int accumulate, void* stream);
 
 /* ------------------------------------------------- BatchNorm + activation

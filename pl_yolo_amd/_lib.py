@@ -110,6 +110,7 @@ SIGNATURES = {
     "plyolo_conv2d_wgrad_slabs": (_i, [_P(ConvDesc)]),
     "plyolo_bias_grad": (_i, [_i, _vp, _i, _i, _i, _vp, _vp]),
     "plyolo_pack_weights": (_i, [_vp, _i, _i, _i, _vp]),
+    "plyolo_reduce_slabs": (_i, [_vp, _i, _sz, _vp]),
     "plyolo_pack_elems": (_i, [_i, _i, _i, _i, _P(_sz), _P(_sz)]),
     "plyolo_unpack_wgrads": (_i, [_vp, _i, _i, _i, _vp]),
     "plyolo_bn_finalize": (_i, [_P(BnStats), _i, _vp, _vp]),

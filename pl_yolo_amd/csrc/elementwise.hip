@@ -431,6 +431,25 @@ __global__ void pack_weights_kernel(const plyolo_pack_entry* table) {
     for (int i = threadIdx.x; i < e.Cout; i += blockDim.x) e.bp[e.co_off + i] = e.b[i];
 }
 
+// slab 0 += slabs 1..n-1 (fixed order).  Runs right after a wgrad launch (on the weight-gradient lane), so
+// that the final unpack only permutes one slab per convolution.
+__global__ void reduce_slabs_kernel(float* dwp, int nslab, size_t elems) {
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < elems; i += (size_t)gridDim.x * blockDim.x * 4) {
+    if (i + 4 <= elems) {
+      f32x4 a = *(const f32x4*)(dwp + i);
+#pragma unroll 4
+      for (int sl = 1; sl < nslab; ++sl) a += *(const f32x4*)(dwp + (size_t)sl * elems + i);
+      *(f32x4*)(dwp + i) = a;
+    } else {
+      for (size_t k = i; k < elems; ++k) {
+        float a = dwp[k];
+        for (int sl = 1; sl < nslab; ++sl) a += dwp[(size_t)sl * elems + k];
+        dwp[k] = a;
+      }
+    }
+  }
+}
+
 __global__ void unpack_wgrads_kernel(const plyolo_pack_entry* table, int accumulate) {
   const plyolo_pack_entry e = table[blockIdx.x];
   if (!e.dw) return;
@@ -720,6 +739,16 @@ int plyolo_pack_weights(const plyolo_pack_entry* table_dev, int n, int dtype, in
   if (gy > 64) gy = 64;
   return submit(stream, [=](hipStream_t s) -> hipError_t {
     DISPATCH_T(dtype, hipLaunchKernelGGL(pack_weights_kernel<T>, dim3(n, gy), dim3(256), 0, s, table_dev);)
+    return hipGetLastError();
+  });
+}
+
+int plyolo_reduce_slabs(float* dwp, int nslab, size_t elems, void* stream) {
+  PLY_CHECK_ARG(dwp && nslab >= 1 && elems % 4 == 0, "reduce_slabs: slab length must be a multiple of 4 floats");
+  if (nslab == 1) return 0;
+  plyolo::annotate("reduce_slabs", 0.0, 4.0 * (double)elems * nslab);
+  return submit(stream, [=](hipStream_t s) -> hipError_t {
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid_for(elems / 4)), dim3(256), 0, s, dwp, nslab, elems);
     return hipGetLastError();
   });
 }

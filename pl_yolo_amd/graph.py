@@ -172,7 +172,8 @@ class Graph:
                 e.b = b.data_ptr() if b is not None else None
                 e.bp, e.dbp, e.db = c.bp, c.dbp, None
                 e.Cout, e.Cin, e.Cin_p, e.ksize = w.shape[0], w.shape[1], c.Cin_p, c.ksize
-                e.Cout_total, e.Cout_p8, e.co_off, e.nslab = c.Cout_total, c.Cout_p8, co_off, c.nslab
+                # every wgrad call site sums its slabs right away (PackedConv.reduce_slabs): unpack reads one slab
+                e.Cout_total, e.Cout_p8, e.co_off, e.nslab = c.Cout_total, c.Cout_p8, co_off, 1
                 entries.append((e, w, b))
                 self.max_pack_elems = max(self.max_pack_elems, c.ksize * c.ksize * w.shape[0] * c.Cin_p)
         self.pack_entries = entries
@@ -267,6 +268,13 @@ class PackedConv:
         self.nslab = 1
         self.wp = self.wpd = self.dwp = self.bp = self.dbp = None
         g.convs.append(self)
+
+    def reduce_slabs(self):
+        """Sum the private wgrad slabs into slab 0 right behind the wgrad launch (same lane), so the
+        final unpack only permutes one slab per convolution."""
+        if self.nslab > 1:
+            call("plyolo_reduce_slabs", self.dwp, self.nslab, self.dwp_elems, None)
+        self.reduced = True
 
     def set_slabs(self, desc):
         """Number of private wgrad slabs the backward launch of `desc` writes."""
@@ -384,10 +392,12 @@ class ConvUnitOp:
             plan.lane(1)
             plan.wait(1, ev)
             call("plyolo_conv2d_wgrad", C.byref(self.desc), g.aptr(self.x), dz, self.pc.dwp, None)
+            self.pc.reduce_slabs()
             g.dz_event[k] = plan.record(1)
             plan.lane(0)
         else:
             call("plyolo_conv2d_wgrad", C.byref(self.desc), g.aptr(self.x), dz, self.pc.dwp, None)
+            self.pc.reduce_slabs()
         if self.need_dgrad:
             acc = g.grad_mode(self.x)
             call("plyolo_conv2d_dgrad", C.byref(self.desc), dz, self.pc.wpd, g.gptr(self.x), acc, None)
@@ -521,6 +531,7 @@ class ImplicitHeadOp:
         self.keep = d
         call("plyolo_bias_grad", g.dtype, self.du.data_ptr(), rows, self.Cout, self.du_ld, self.pc.dbp, None)
         call("plyolo_conv2d_wgrad", C.byref(d), g.aptr(self.x), self.du.data_ptr(), self.pc.dwp, None)
+        self.pc.reduce_slabs()
         acc = g.grad_mode(self.x)
         call("plyolo_conv2d_dgrad", C.byref(d), self.du.data_ptr(), self.pc.wpd, g.gptr(self.x), acc, None)
 
@@ -659,7 +670,9 @@ class HeadPredOp:
         call("plyolo_bias_grad", g.dtype, dro, M, 5, ld_ro, self.pc_ro.dbp, None)
         call("plyolo_bias_grad", g.dtype, dcl, M, self.nc, ld_cl, self.pc_cls.dbp, None)
         call("plyolo_conv2d_wgrad", C.byref(d_ro), g.aptr(self.reg_feat), dro, self.pc_ro.dwp, None)
+        self.pc_ro.reduce_slabs()
         call("plyolo_conv2d_wgrad", C.byref(d_cl), g.aptr(self.cls_feat), dcl, self.pc_cls.dwp, None)
+        self.pc_cls.reduce_slabs()
         acc = g.grad_mode(self.reg_feat)
         call("plyolo_conv2d_dgrad", C.byref(d_ro), dro, self.pc_ro.wpd, g.gptr(self.reg_feat), acc, None)
         acc = g.grad_mode(self.cls_feat)
