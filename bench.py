@@ -116,7 +116,7 @@ def main():
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
     ap.add_argument("--graph", action="store_true", help="replay the plans as hipGraphs (single lane) instead of the eager multi-stream replay")
-    ap.add_argument("--no-graph", action="store_true", help="(default) eager multi-stream replay")
+    ap.add_argument("--no-graph", action="store_true", help="replay every plan eagerly (default: single-lane plans as hipGraphs, multi-lane plans eagerly)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-out", default=None, help="write the per-launch plan profile (JSON) here")
     args = ap.parse_args()
@@ -147,7 +147,7 @@ def main():
     model.compute_dtype = "bf16"
     model = model.to(dev).train()
     runner = model.runner()
-    runner.use_graph = bool(args.graph)
+    runner.use_graph = True if args.graph else (False if args.no_graph else "auto")
     if world > 1:
         from pl_yolo_amd import ddp
         ddp.attach(model)

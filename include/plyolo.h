@@ -67,6 +67,7 @@ int plyolo_plan_end(plyolo_plan*);             /* stop recording */
 int plyolo_plan_lane(plyolo_plan* p, int lane);
 int plyolo_plan_record(plyolo_plan* p, int lane);          /* returns the event id (>= 0) or < 0 */
 int plyolo_plan_wait(plyolo_plan* p, int lane, int ev);
+int plyolo_plan_lanes(const plyolo_plan* p);                /* number of lanes the plan uses (>= 1) */
 int plyolo_plan_size(const plyolo_plan*);      /* number of recorded launches */
 int plyolo_plan_run(plyolo_plan*, void* stream); /* replay eagerly */
 int plyolo_plan_graph_instantiate(plyolo_plan*, void* stream); /* capture into a hipGraphExec */

@@ -96,6 +96,7 @@ SIGNATURES = {
     "plyolo_plan_begin": (_i, [_vp]),
     "plyolo_plan_end": (_i, [_vp]),
     "plyolo_plan_size": (_i, [_vp]),
+    "plyolo_plan_lanes": (_i, [_vp]),
     "plyolo_plan_lane": (_i, [_vp, _i]),
     "plyolo_plan_record": (_i, [_vp, _i]),
     "plyolo_plan_wait": (_i, [_vp, _i, _i]),

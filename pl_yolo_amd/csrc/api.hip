@@ -140,6 +140,7 @@ int plyolo_plan_wait(plyolo_plan* p, int lane, int ev) {
   return 0;
 }
 
+int plyolo_plan_lanes(const plyolo_plan* p) { return p ? ((const Plan*)p)->nlanes : 0; }
 int plyolo_plan_size(const plyolo_plan* p) { return p ? (int)((const Plan*)p)->ops.size() : 0; }
 // Issue every recorded launch: lane l on its own stream (forked from / joined into `s`), events as
 // recorded.  Used both under stream capture (hipGraph) and for eager multi-stream replay.

@@ -83,8 +83,31 @@ class Graph:
         self.image_act = None
         self.post_unpack = []   # ops with work that must follow unpack_wgrads
         self.plan = None        # the Plan being recorded (ops use it for lanes / events)
+        self.cur_lane, self.cur_region = 0, None
+        self.dz_state, self.dz_event = {}, {}
         # weight gradients on their own lane (PLYOLO_LANES=0 keeps every launch on lane 0)
         self.use_lanes = os.environ.get("PLYOLO_LANES", "1") != "0"
+
+    # ------------------------------------------------------------------ lanes
+    def add_op(self, op):
+        op.lane, op.region = self.cur_lane, self.cur_region
+        if self.cur_region is not None:
+            self.cur_region.ops.append(op)
+        self.ops.append(op)
+
+    def fork(self):
+        """Open a fork/join region: ops emitted inside `with region.branch(lane):` blocks run on that lane
+        (concurrently with the other branches under the eager multi-stream replay).  Branches must be
+        independent of each other; everything before / after the region happens before / after all of it.
+        Regions do not nest and only open from lane 0; otherwise (or with PLYOLO_LANES=0) the ops stay inline."""
+        return _Region(self, self.use_lanes and self.cur_region is None and self.cur_lane == 0)
+
+    def dz_buffer(self, lane):
+        """Next rotating dz scratch buffer of `lane`: (device pointer, slot key)."""
+        st = self.dz_state.setdefault(lane, [0])
+        k = st[0]
+        st[0] = (k + 1) % DZ_BUFS
+        return self.scratch[lane][k].data_ptr(), (lane, k)
 
     # ------------------------------------------------------------------ tracing
     def new_act(self, N, H, W, C_, name=""):
@@ -128,8 +151,9 @@ class Graph:
         for st in self.storages:
             st.tensor = torch.empty(st.rows * st.ld, dtype=self.tdtype, device=dev)
         # dz scratch: DZ_BUFS rotating buffers so that the weight-gradient lane can lag the main lane
-        self.scratch = [torch.empty(max(self.scratch_elems, 8), dtype=self.tdtype, device=dev) for _ in range(DZ_BUFS)]
-        self.dz_turn, self.dz_event = 0, [None] * DZ_BUFS
+        main_lanes = sorted({op.lane for op in self.ops})
+        self.scratch = {l: [torch.empty(max(self.scratch_elems, 8), dtype=self.tdtype, device=dev) for _ in range(DZ_BUFS)]
+                        for l in main_lanes}
         self.scratch32 = torch.zeros(max(self.scratch_f32, 8), dtype=torch.float32, device=dev)
         cmax = max([c.Cout_total for c in self.convs] + [8])
         # fp64 stat slots of every BatchNorm (forward: sum z, sum z^2; backward: sum du, sum du*zhat);
@@ -181,8 +205,8 @@ class Graph:
     def join_lanes(self):
         """Everything recorded on the weight-gradient lane so far happens before what lane 0 records next."""
         if self.use_lanes:
-            self.plan.wait(0, self.plan.record(1))
-            self.dz_event = [None] * DZ_BUFS
+            self.plan.wait(0, self.plan.record(WGRAD_LANE))
+            self.dz_event = {}
 
     def zero_fwd_stats(self):
         if self.training:
@@ -251,6 +275,68 @@ class Graph:
 
 
 DZ_BUFS = 4
+WGRAD_LANE = 1      # weight gradients (+ their slab reductions); branch lanes are 2, 3, ...
+
+
+class _Region:
+    """Fork/join region of the launch plans (Graph.fork)."""
+
+    def __init__(self, g, active):
+        self.g, self.active, self.ops, self.lanes = g, active, [], set()
+
+    def __enter__(self):
+        if self.active:
+            self.g.cur_region = self
+        return self
+
+    def __exit__(self, *exc):
+        if self.active:
+            self.g.cur_region = None
+        return False
+
+    def branch(self, lane):
+        return _Branch(self, lane)
+
+
+class _Branch:
+    def __init__(self, region, lane):
+        self.region, self.lane = region, lane
+
+    def __enter__(self):
+        if self.region.active:
+            self.region.g.cur_lane = self.lane
+            if self.lane != 0:
+                self.region.lanes.add(self.lane)
+        return self
+
+    def __exit__(self, *exc):
+        self.region.g.cur_lane = 0
+        return False
+
+
+def record_ops(g, plan, ops, method):
+    """Record `op.<method>()` for every op in `ops` (forward order, or reversed for the backward plan)
+    with the fork / join events of the regions they belong to."""
+    started, remaining = {}, {}
+    for op in ops:
+        r = op.region
+        lane = op.lane if r is not None else 0
+        if r is not None:
+            if id(r) not in started:
+                started[id(r)] = (plan.record(0), set())
+                remaining[id(r)] = len(r.ops)
+            ev, waited = started[id(r)]
+            if lane != 0 and lane not in waited:
+                plan.wait(lane, ev)
+                waited.add(lane)
+        plan.lane(lane)
+        getattr(op, method)()
+        if r is not None:
+            remaining[id(r)] -= 1
+            if remaining[id(r)] == 0:       # join: lane 0 continues after every branch lane
+                for l in sorted(r.lanes):
+                    plan.wait(0, plan.record(l))
+    plan.lane(0)
 
 
 class PackedConv:
@@ -330,7 +416,7 @@ class ConvUnitOp:
         self.desc = conv_desc(g, x.N, x.H, x.W, self.Cin_p, Cout, k, stride, self.Cin_p, Cout)
         self.pc.set_slabs(self.desc)
         g.scratch_elems = max(g.scratch_elems, self.z.rows * Cout)
-        g.ops.append(self)
+        g.add_op(self)
 
     def _alloc_small(self):
         g = self.g
@@ -376,25 +462,22 @@ class ConvUnitOp:
             call("plyolo_copy_add", g.dtype, M, Cout, dout, self.out.ld, g.gptr(self.res), self.res.ld, acc, None)
         bslots = g.bstat_arena.data_ptr() + self.slot_off * 8
         call("plyolo_bn_act_bwd_reduce", g.dtype, M, Cout, dout, self.out.ld, zt, Cout, self.coef.data_ptr(), self.act, bslots, None)
-        plan, lanes = g.plan, g.use_lanes
-        k = g.dz_turn
-        g.dz_turn = (k + 1) % DZ_BUFS
-        if lanes and g.dz_event[k] is not None:
-            plan.wait(0, g.dz_event[k])          # the wgrad that last read this buffer has finished
-            g.dz_event[k] = None
-        dz = g.scratch[k].data_ptr()
+        plan, lanes, me = g.plan, g.use_lanes, self.lane
+        dz, key = g.dz_buffer(me)
+        if lanes and g.dz_event.get(key) is not None:
+            plan.wait(me, g.dz_event.pop(key))   # the wgrad that last read this buffer has finished
         call("plyolo_bn_act_bwd_dz", g.dtype, M, Cout, dout, self.out.ld, zt, Cout, self.coef.data_ptr(), bslots, ptr(bn.weight),
              g.grad_ptr_of(bn.weight), g.grad_ptr_of(bn.bias), 0, self.act, dz, Cout, None)
         if lanes:
-            # the weight gradient only feeds the optimizer: it runs on lane 1, concurrently with the data-gradient
-            # chain of the layers upstream
-            ev = plan.record(0)
-            plan.lane(1)
-            plan.wait(1, ev)
+            # the weight gradient only feeds the optimizer: it runs on its own lane, concurrently with the
+            # data-gradient chain of the layers upstream
+            ev = plan.record(me)
+            plan.lane(WGRAD_LANE)
+            plan.wait(WGRAD_LANE, ev)
             call("plyolo_conv2d_wgrad", C.byref(self.desc), g.aptr(self.x), dz, self.pc.dwp, None)
             self.pc.reduce_slabs()
-            g.dz_event[k] = plan.record(1)
-            plan.lane(0)
+            g.dz_event[key] = plan.record(WGRAD_LANE)
+            plan.lane(me)
         else:
             call("plyolo_conv2d_wgrad", C.byref(self.desc), g.aptr(self.x), dz, self.pc.dwp, None)
             self.pc.reduce_slabs()
@@ -407,7 +490,7 @@ class UpsampleOp:
     def __init__(self, g, x):
         self.g, self.x = g, x
         self.out = g.new_act(x.N, 2 * x.H, 2 * x.W, x.C, "up")
-        g.ops.append(self)
+        g.add_op(self)
 
     def fwd(self):
         g, x = self.g, self.x
@@ -430,7 +513,7 @@ class SppPoolsOp:
         self.g, self.x, self.ks = g, x, tuple(ks)
         self.outs = [g.new_act(x.N, x.H, x.W, x.C, "pool%d" % k) for k in ks]
         g.scratch_f32 = max(g.scratch_f32, x.M * x.C)
-        g.ops.append(self)
+        g.add_op(self)
 
     def fwd(self):
         g, x = self.g, self.x
@@ -469,7 +552,7 @@ class MaxPool2x2Op:
     def __init__(self, g, x):
         self.g, self.x = g, x
         self.out = g.new_act(x.N, x.H // 2, x.W // 2, x.C, "mp2")
-        g.ops.append(self)
+        g.add_op(self)
 
     def fwd(self):
         g, x = self.g, self.x
@@ -500,7 +583,7 @@ class ImplicitHeadOp:
         self.du_ld = (self.Cout + 7) // 8 * 8
         if g.dtype == BF16:
             self.pc.set_slabs(conv_desc(g, N, H, W, self.Cin, self.Cout, 1, 1, self.Cin, self.du_ld, 0))
-        g.ops.append(self)
+        g.add_op(self)
         g.post_unpack.append(self)
 
     def _rows(self):
@@ -595,7 +678,7 @@ class YoloV7LossOp:
 
     def __init__(self, g, head):
         self.g, self.head = g, head
-        g.ops.append(self)
+        g.add_op(self)
 
     def fwd(self):
         hd = self.head
@@ -611,7 +694,7 @@ class YoloV7LossOp:
 class YoloV7EvalDecodeOp:
     def __init__(self, g, head):
         self.g, self.head = g, head
-        g.ops.append(self)
+        g.add_op(self)
 
     def fwd(self):
         hd = self.head
@@ -642,7 +725,7 @@ class HeadPredOp:
         if g.dtype == BF16:
             self.pc_ro.set_slabs(conv_desc(g, N, H, W, Cin, 5, 1, 1, Cin, 16, 0))
             self.pc_cls.set_slabs(conv_desc(g, N, H, W, Cin, self.nc, 1, 1, Cin, head.cls_ld, 0))
-        g.ops.append(self)
+        g.add_op(self)
 
     def fwd(self):
         g, hd = self.g, self.head
@@ -757,7 +840,7 @@ class HeadBuffers:
 class YoloxLossOp:
     def __init__(self, g, head):
         self.g, self.head = g, head
-        g.ops.append(self)
+        g.add_op(self)
 
     def fwd(self):
         hd = self.head
@@ -774,7 +857,7 @@ class YoloxLossOp:
 class YoloxEvalDecodeOp:
     def __init__(self, g, head):
         self.g, self.head = g, head
-        g.ops.append(self)
+        g.add_op(self)
 
     def fwd(self):
         hd = self.head
@@ -801,6 +884,9 @@ class Plan:
 
     def size(self):
         return _lib.lib().plyolo_plan_size(self.h)
+
+    def lanes(self):
+        return _lib.lib().plyolo_plan_lanes(self.h)
 
     # lanes (concurrent launch sequences inside a hipGraph replay), see include/plyolo.h
     def lane(self, l):

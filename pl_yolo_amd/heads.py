@@ -45,14 +45,18 @@ class DecoupledHead(HipModule):
     def emit(self, g, inputs, head_buffers):
         """Writes the raw predictions of every level into `head_buffers.raw`
         (channel order reg(4), obj(1), cls(C) -- decoupled_head.py:93)."""
-        for k, x in enumerate(inputs):
-            x = self.stems[k].emit(g, x)
-            cls_feat, reg_feat = x, x
-            for m in self.cls_convs[k]:
-                cls_feat = m.emit(g, cls_feat)
-            for m in self.reg_convs[k]:
-                reg_feat = m.emit(g, reg_feat)
-            G.HeadPredOp(g, head_buffers, k, cls_feat, reg_feat, self.cls_preds[k], self.reg_preds[k], self.obj_preds[k])
+        # the levels are independent from the stem conv to the prediction convs (and back, in the backward
+        # plan): level 0 stays on the main lane, the smaller levels run beside it on lanes 2, 3, ...
+        with g.fork() as region:
+            for k, x in enumerate(inputs):
+                with region.branch(0 if k == 0 else 1 + k):
+                    x = self.stems[k].emit(g, x)
+                    cls_feat, reg_feat = x, x
+                    for m in self.cls_convs[k]:
+                        cls_feat = m.emit(g, cls_feat)
+                    for m in self.reg_convs[k]:
+                        reg_feat = m.emit(g, reg_feat)
+                    G.HeadPredOp(g, head_buffers, k, cls_feat, reg_feat, self.cls_preds[k], self.reg_preds[k], self.obj_preds[k])
         return head_buffers
 
 

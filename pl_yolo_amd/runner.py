@@ -33,7 +33,10 @@ class DetectorRunner:
         self.dtype = BF16 if dtype in ("bf16", BF16) else F32
         self.sessions = {}
         self.flat = None
-        self.use_graph = os.environ.get("PLYOLO_GRAPH", "0") == "1"
+        # PLYOLO_GRAPH: "1" every plan as a hipGraph, "0" every plan eagerly, "auto" (default) single-lane
+        # plans as hipGraphs (smallest launch gaps) and multi-lane plans eagerly on their streams
+        mode = os.environ.get("PLYOLO_GRAPH", "auto")
+        self.use_graph = {"1": True, "0": False}.get(mode, "auto")
         self._side = None  # hipGraph capture/replay needs a non-default stream
         self.ddp = None  # set by pl_yolo_amd.ddp.attach()
 
@@ -160,8 +163,7 @@ class DetectorRunner:
             g.plan = s.fwd
             call("plyolo_pack_weights", g.pack_table.data_ptr(), g.n_pack, g.dtype, g.max_pack_elems, None)
             g.zero_fwd_stats()
-            for op in g.ops:
-                op.fwd()
+            G.record_ops(g, s.fwd, g.ops, "fwd")
         s.bwd = None
         s.used_params = []
         if mode in ("train", "maps_grad"):
@@ -171,8 +173,7 @@ class DetectorRunner:
                 if g.dtype != BF16:  # the fp32 parity wgrad accumulates with atomics; the MFMA path overwrites its slabs
                     call("plyolo_memset_async", g.dwp_arena.data_ptr(), 0, g.dwp_arena.numel() * 4, None)
                 g.zero_bwd_stats()
-                for op in reversed(g.ops):
-                    op.bwd()
+                G.record_ops(g, s.bwd, list(reversed(g.ops)), "bwd")
                 g.join_lanes()
                 call("plyolo_unpack_wgrads", g.pack_table.data_ptr(), g.n_pack, g.max_pack_elems, 0, None)
                 for op in g.post_unpack:
@@ -208,7 +209,8 @@ class DetectorRunner:
         stream.  Eager replays go straight onto that stream; hipGraph replays use a
         private stream (capture is not allowed on the legacy default stream) fenced with
         events on both sides."""
-        if not self.use_graph:
+        use_graph = self.use_graph if self.use_graph != "auto" else plan.lanes() <= 1
+        if not use_graph:
             plan.run(self._stream(), False)
             return
         cur = torch.cuda.current_stream()
