@@ -202,17 +202,34 @@ def main():
         nrep = len(prof)
         table = sorted(((k, v[0] / nrep, v[1] / nrep, v[2] / nrep, v[3] / nrep) for k, v in agg.items()), key=lambda r: -r[2])
         total_ms = sum(r[2] for r in table)
-        dom = table[0]
-        label, cnt, ms_tot, fl_tot, by_tot = dom
+        # dominant kernel = the kernel FAMILY (all template instances of one __global__ function) with the
+        # largest share of the step; roofline figures are per launch, averaged over the family's launches
+        fam = {}
+        for (label, cnt, ms_tot, fl_tot, by_tot) in table:
+            f = fam.setdefault(label.split("<")[0], [0.0, 0.0, 0.0, 0.0])
+            f[0] += cnt; f[1] += ms_tot; f[2] += fl_tot; f[3] += by_tot
+        label, (cnt, ms_tot, fl_tot, by_tot) = max(fam.items(), key=lambda kv: kv[1][1])
         avg_ms = ms_tot / cnt
         tf = fl_tot / cnt / (avg_ms * 1e-3) / 1e12
         gbs = by_tot / cnt / (avg_ms * 1e-3) / 1e9
         mfma_bound = (fl_tot / PEAK_MFMA / 1e12) >= (by_tot / PEAK_HBM / 1e9)
+        traffic = None
+        try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, tools/rocpd_pmc.py)
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as f:
+                pm = json.load(f)
+            key = {"conv_mfma_fwd": "conv_mfma", "conv_mfma_dgrad": "conv_mfma", "conv_mfma_dgrad_s2": "conv_mfma"}.get(label, label)
+            if args.model == "yolox_s" and args.size == 640 and args.batch == 32 and key in pm:
+                traffic = {"bytes_per_launch": (pm[key]["read_MB_per_launch"] + pm[key]["write_MB_per_launch"]) * 1e6,
+                           "algorithmic_bytes_per_launch": by_tot / cnt,
+                           "source": "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, family %s)" % key}
+        except OSError:
+            pass
         roof = {"kernel": label, "launches_per_step": cnt, "avg_ms": avg_ms, "share_of_step": ms_tot / total_ms,
                 "bound": "mfma" if mfma_bound else "hbm",
                 "achieved": tf if mfma_bound else gbs, "peak": PEAK_MFMA if mfma_bound else PEAK_HBM,
                 "unit": "TFLOP/s" if mfma_bound else "GB/s",
-                "frac": (tf / PEAK_MFMA) if mfma_bound else (gbs / PEAK_HBM), "traffic": None}
+                "frac": (tf / PEAK_MFMA) if mfma_bound else (gbs / PEAK_HBM), "traffic": traffic,
+                "achieved_tflops": tf, "achieved_gbs": gbs}
         a = ALGO.get(args.model, ALGO["yolox_s"])
         scale = (args.size / 640.0) ** 2 if args.model != "yolox_nano" else (args.size / 640.0) ** 2
         t_roof = max(a["flops"] * scale * args.batch / (PEAK_MFMA * 1e12), a["bytes"] * scale * args.batch / (PEAK_HBM * 1e9))
@@ -226,12 +243,15 @@ def main():
                 json.dump({"columns": ["kernel", "launches", "total_ms", "algo_flops", "algo_bytes"], "rows": table,
                            "sum_ms": total_ms, "ops_columns": ["plan", "kernel", "ms", "algo_flops", "algo_bytes"], "ops": ops}, f, indent=1)
         result = {
-            "metric": "images/sec fwd+bwd YOLOX-s 640x640 bs32", "value": value, "unit": "images/sec",
+            "metric": ("images/sec fwd+bwd YOLOX-s 640x640 bs32" if (args.model, args.size, args.batch) == ("yolox_s", 640, 32)
+                       else "images/sec fwd+bwd %s %dx%d bs%d" % (args.model, args.size, args.size, args.batch)),
+            "value": value, "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "%s %dx%d, batch %d per GPU, 30 GT/img, fwd + SimOTA/loss + bwd%s" % (
                 args.model, args.size, args.size, args.batch, " + RCCL grad all-reduce" if world > 1 else ""),
-                "global_batch": world * args.batch, "parallelism": "dp%d" % world, "hipgraph": not args.no_graph,
+                "global_batch": world * args.batch, "parallelism": "dp%d" % world,
+                "replay": "hipgraph" if args.graph else "eager multi-stream (weight-gradient + head-level lanes)",
                 "loss": loss},
             "roofline": roof,
         }

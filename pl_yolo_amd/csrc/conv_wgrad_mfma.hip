@@ -261,7 +261,9 @@ static WgPlan plan_wgrad(const plyolo_conv_desc* d) {
   // spatial split: a few workgroups per CU; every split writes a private fp32 slab (S*WK*|dW|
   // bytes stored once and read once by the unpack pass), capped at ~32 MB and 1024 slabs per layer
   const double dw_bytes = 4.0 * d->ksize * d->ksize * (double)d->Cout * d->Cin;
-  int S = 768 / (nco * p.nci * w.WK);
+  int target = 768;  // workgroups per launch (3 per CU)
+  if (const char* e = getenv("PLYOLO_WG_TARGET")) { const int v = atoi(e); if (v >= 64) target = v; }
+  int S = target / (nco * p.nci * w.WK);
   if (S * w.WK > 1024) S = 1024 / w.WK;
   const int s_budget = (int)(32.0e6 / (dw_bytes * w.WK));
   if (S > s_budget) S = s_budget;
