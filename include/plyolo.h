@@ -162,28 +162,58 @@ typedef struct plyolo_bn_stats {
   float* running_mean;        /* updated in place when non-NULL (unbiased var, like torch) */
   float* running_var;
   int64_t* num_batches_tracked;
+  /* Two BatchNorm modules normalising one merged convolution (CSP conv1 || conv2, same input):
+   * channels [split, C) take their affine parameters / running statistics from the second set,
+   * indexed from 0.  split == 0: unused. */
+  int split;
+  const float* gamma2;
+  const float* beta2;
+  float* running_mean2;
+  float* running_var2;
+  int64_t* num_batches_tracked2;
 } plyolo_bn_stats;
+/* Second destination (or source) of a channel-split activation matrix: columns [split, C) live at
+ * p2 (pitch ld2), indexed from 0.  NULL or split == 0: one matrix. */
+typedef struct plyolo_split {
+  int split;
+  void* p2;
+  int ld2;
+} plyolo_split;
 /* Standalone reduction of the slots -> coef[0:C]=scale, [C:2C]=shift, [2C:3C]=mean, [3C:4C]=invstd
  * (+ running statistics).  Not needed when plyolo_bn_act_fwd is given `st`. */
 int plyolo_bn_finalize(const plyolo_bn_stats* st, int C, float* coef, void* stream);
 /* eval mode: coef from running statistics */
 int plyolo_bn_eval_coef(int C, const float* gamma, const float* beta, const float* running_mean,
                         const float* running_var, float eps, float* coef, void* stream);
+/* same, for one module of a merged convolution: coef rows are C_total wide, this module's C channels
+ * start at column c_off */
+int plyolo_bn_eval_coef_at(int C, const float* gamma, const float* beta, const float* running_mean,
+                           const float* running_var, float eps, float* coef, int C_total, int c_off, void* stream);
 /* out = act(z*scale+shift) (+ res).  z [M][C] pitch z_ld; out pitch o_ld; res pitch r_ld or NULL.
  * st == NULL: coef is an INPUT.  st != NULL (train mode): every workgroup derives scale/shift from
  * the stat slots, and coef (the 4C values above, needed by the backward kernels) plus the running
  * statistics are WRITTEN by this launch. */
 int plyolo_bn_act_fwd(int dtype, int M, int C, const void* z, int z_ld, float* coef, int act,
-                      const void* res, int r_ld, void* out, int o_ld, const plyolo_bn_stats* st, void* stream);
+                      const void* res, int r_ld, void* out, int o_ld, const plyolo_bn_stats* st,
+                      const plyolo_split* out_split, void* stream);
 /* bslots (fp64 [PLYOLO_STAT_SLOTS][2][C], zeroed by the caller) += sum du, sum du*zhat
  * with du = dout * act'(u) */
 int plyolo_bn_act_bwd_reduce(int dtype, int M, int C, const void* dout, int d_ld, const void* z, int z_ld,
-                             const float* coef, int act, double* bslots, void* stream);
+                             const float* coef, int act, double* bslots, const plyolo_split* dout_split,
+                             void* stream);
 /* dz = A*du + B*z + Cc with A,B,Cc derived from bslots inside the launch; also writes
  * dgamma / dbeta (fp32 [C], may be NULL; accumulate != 0: +=). */
+/* par2 (optional): {split, gamma2, dgamma2, dbeta2} for channels [split, C) of a merged convolution. */
+typedef struct plyolo_bn_bwd_split {
+  int split;
+  const float* gamma2;
+  float* dgamma2;
+  float* dbeta2;
+} plyolo_bn_bwd_split;
 int plyolo_bn_act_bwd_dz(int dtype, int M, int C, const void* dout, int d_ld, const void* z, int z_ld,
                          const float* coef, const double* bslots, const float* gamma, float* dgamma,
-                         float* dbeta, int accumulate, int act, void* dz, int dz_ld, void* stream);
+                         float* dbeta, int accumulate, int act, void* dz, int dz_ld,
+                         const plyolo_split* dout_split, const plyolo_bn_bwd_split* par2, void* stream);
 
 /* -------------------------------------------------- data movement kernels */
 /* Focus space-to-depth (network_blocks.py:50-65): NCHW fp32 image ->

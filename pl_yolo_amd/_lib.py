@@ -28,7 +28,17 @@ STAT_SLOTS = 8  # PLYOLO_STAT_SLOTS
 class BnStats(C.Structure):
     _fields_ = [("slots", C.c_void_p), ("count", C.c_double), ("gamma", C.c_void_p), ("beta", C.c_void_p),
                 ("eps", C.c_float), ("momentum", C.c_float), ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
-                ("num_batches_tracked", C.c_void_p)]
+                ("num_batches_tracked", C.c_void_p),
+                ("split", C.c_int), ("gamma2", C.c_void_p), ("beta2", C.c_void_p), ("running_mean2", C.c_void_p),
+                ("running_var2", C.c_void_p), ("num_batches_tracked2", C.c_void_p)]
+
+
+class Split(C.Structure):          # plyolo_split
+    _fields_ = [("split", C.c_int), ("p2", C.c_void_p), ("ld2", C.c_int)]
+
+
+class BnBwdSplit(C.Structure):     # plyolo_bn_bwd_split
+    _fields_ = [("split", C.c_int), ("gamma2", C.c_void_p), ("dgamma2", C.c_void_p), ("dbeta2", C.c_void_p)]
 
 
 class PackEntry(C.Structure):
@@ -116,9 +126,10 @@ SIGNATURES = {
     "plyolo_unpack_wgrads": (_i, [_vp, _i, _i, _i, _vp]),
     "plyolo_bn_finalize": (_i, [_P(BnStats), _i, _vp, _vp]),
     "plyolo_bn_eval_coef": (_i, [_i, _vp, _vp, _vp, _vp, _f, _vp, _vp]),
-    "plyolo_bn_act_fwd": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _P(BnStats), _vp]),
-    "plyolo_bn_act_bwd_reduce": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp]),
-    "plyolo_bn_act_bwd_dz": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp]),
+    "plyolo_bn_eval_coef_at": (_i, [_i, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _vp]),
+    "plyolo_bn_act_fwd": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _P(BnStats), _P(Split), _vp]),
+    "plyolo_bn_act_bwd_reduce": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _P(Split), _vp]),
+    "plyolo_bn_act_bwd_dz": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _P(Split), _P(BnBwdSplit), _vp]),
     "plyolo_focus_s2d": (_i, [_i, _vp, _i, _i, _i, _vp, _i, _vp]),
     "plyolo_copy_add": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _i, _vp]),
     "plyolo_upsample2x_fwd": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),

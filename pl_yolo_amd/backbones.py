@@ -1,7 +1,7 @@
 """CSPDarkNet backbone (reference models/backbones/darknet_csp.py:15-75)."""
 from torch import nn
 
-from .layers import Focus, BaseConv, CSPLayer, SPPBottleneck, HipModule
+from .layers import emit_pair, Focus, BaseConv, CSPLayer, SPPBottleneck, HipModule
 
 
 class CSPDarkNet(HipModule):
@@ -60,8 +60,7 @@ class ELANLayer(HipModule):
         self.conv5 = BaseConv(4 * hi_channel, out_channel, 1, stride=1, norm=norm, act=act)
 
     def emit(self, g, x):
-        x_1 = self.conv1.emit(g, x)
-        x_2 = self.conv2.emit(g, x)
+        x_1, x_2 = emit_pair(g, x, self.conv1, self.conv2)
         x_3 = x_2
         for m in self.conv3:
             x_3 = m.emit(g, x_3)

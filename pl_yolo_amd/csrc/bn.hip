@@ -47,7 +47,11 @@ DEVINL void bn_coef(const plyolo_bn_stats& st, int C, int c, bool publish, float
   double var = ss / st.count - mean * mean;
   if (var < 0.0) var = 0.0;
   const float invstd = (float)(1.0 / sqrt(var + (double)st.eps));
-  const float g = st.gamma ? st.gamma[c] : 1.f, b = st.beta ? st.beta[c] : 0.f;
+  const bool second = st.split > 0 && c >= st.split;
+  const int cp = second ? c - st.split : c;
+  const float* gam = second ? st.gamma2 : st.gamma;
+  const float* bet = second ? st.beta2 : st.beta;
+  const float g = gam ? gam[cp] : 1.f, b = bet ? bet[cp] : 0.f;
   const float scale = g * invstd, shift = b - (float)mean * scale;
   *scale_o = scale;
   *shift_o = shift;
@@ -57,12 +61,15 @@ DEVINL void bn_coef(const plyolo_bn_stats& st, int C, int c, bool publish, float
     coef[2 * C + c] = (float)mean;
     coef[3 * C + c] = invstd;
     const float mom = st.momentum;
-    if (st.running_mean) st.running_mean[c] = (1.f - mom) * st.running_mean[c] + mom * (float)mean;
-    if (st.running_var) {
+    float* rm = second ? st.running_mean2 : st.running_mean;
+    float* rv = second ? st.running_var2 : st.running_var;
+    if (rm) rm[cp] = (1.f - mom) * rm[cp] + mom * (float)mean;
+    if (rv) {
       const double unb = st.count > 1.0 ? var * st.count / (st.count - 1.0) : var;
-      st.running_var[c] = (1.f - mom) * st.running_var[c] + mom * (float)unb;
+      rv[cp] = (1.f - mom) * rv[cp] + mom * (float)unb;
     }
     if (c == 0 && st.num_batches_tracked) *st.num_batches_tracked += 1;
+    if (second && cp == 0 && st.num_batches_tracked2) *st.num_batches_tracked2 += 1;
   }
 }
 
@@ -73,16 +80,17 @@ __global__ void bn_finalize_kernel(plyolo_bn_stats st, int C, float* coef) {
   bn_coef(st, C, c, true, coef, &sc, &sh);
 }
 
+// coef rows have Ct channels; this module's C channels start at column c_off (merged convolutions)
 __global__ void bn_eval_coef_kernel(int C, const float* gamma, const float* beta, const float* rmean, const float* rvar,
-                                    float eps, float* coef) {
+                                    float eps, float* coef, int Ct, int c_off) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const float invstd = 1.0f / sqrtf(rvar[c] + eps);
   const float scale = (gamma ? gamma[c] : 1.f) * invstd;
-  coef[c] = scale;
-  coef[C + c] = (beta ? beta[c] : 0.f) - rmean[c] * scale;
-  coef[2 * C + c] = rmean[c];
-  coef[3 * C + c] = invstd;
+  coef[c_off + c] = scale;
+  coef[Ct + c_off + c] = (beta ? beta[c] : 0.f) - rmean[c] * scale;
+  coef[2 * Ct + c_off + c] = rmean[c];
+  coef[3 * Ct + c_off + c] = invstd;
 }
 
 // column-fixed streaming layout: cols = min(C/V, 256) vector columns, rpb = 256/cols rows per block pass
@@ -99,7 +107,7 @@ struct ColMap {
 template <typename T, bool FUSED>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(int M, int C, const T* __restrict__ z, int z_ld, float* coef, int act,
                                                          const T* __restrict__ res, int r_ld, T* __restrict__ out, int o_ld,
-                                                         plyolo_bn_stats st) {
+                                                         plyolo_bn_stats st, plyolo_split sp) {
   constexpr int V = Vec<T>::N;
   __shared__ float s_co[FUSED ? 2 * BN_MAXC : 2];
   if (FUSED) {
@@ -112,6 +120,10 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(int M, int C, const T* 
   const int step = gridDim.x * cm.rpb;
   for (int cv = cm.tcol; cv < cvn; cv += cm.cols) {
     const int c = cv * V;
+    // column-fixed: the destination matrix of this thread's channel vector is chosen once
+    const bool second = sp.split > 0 && c >= sp.split;
+    T* ob = second ? (T*)sp.p2 + (c - sp.split) : out + c;
+    const int ol = second ? sp.ld2 : o_ld;
     float sc[V], sh[V];
 #pragma unroll
     for (int i = 0; i < V; ++i) {
@@ -128,7 +140,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(int M, int C, const T* 
         const float u = actf<Vec<T>::precise>(fmaf(f[i], sc[i], sh[i]), act);
         f[i] = res ? u + r[i] : u;
       }
-      Vec<T>::store(out + (size_t)m * o_ld + c, f);
+      Vec<T>::store(ob + (size_t)m * ol, f);
     }
   }
 }
@@ -136,7 +148,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(int M, int C, const T* 
 // bslots[slot][0][c] += sum du ; bslots[slot][1][c] += sum du * zhat ; one add per block and channel
 template <typename T>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(int M, int C, const T* __restrict__ dout, int d_ld, const T* __restrict__ z,
-                                                                int z_ld, const float* __restrict__ coef, int act, double* bslots) {
+                                                                int z_ld, const float* __restrict__ coef, int act, double* bslots,
+                                                                plyolo_split sp) {
   constexpr int V = Vec<T>::N;
   __shared__ float red[256 * 2 * V];
   const int cvn = C / V;
@@ -153,10 +166,13 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(int M, int C, co
       float sc[V], sh[V], mu[V], is[V];
 #pragma unroll
       for (int i = 0; i < V; ++i) { sc[i] = coef[c + i]; sh[i] = coef[C + c + i]; mu[i] = coef[2 * C + c + i]; is[i] = coef[3 * C + c + i]; }
+      const bool second = sp.split > 0 && c >= sp.split;
+      const T* db = second ? (const T*)sp.p2 + (c - sp.split) : dout + c;
+      const int dl = second ? sp.ld2 : d_ld;
 #pragma unroll 2
       for (int m = blockIdx.x * cm.rpb + cm.trow; m < M; m += step) {
         float d[V], zz[V];
-        Vec<T>::load(dout + (size_t)m * d_ld + c, d);
+        Vec<T>::load(db + (size_t)m * dl, d);
         Vec<T>::load(z + (size_t)m * z_ld + c, zz);
 #pragma unroll
         for (int i = 0; i < V; ++i) {
@@ -201,7 +217,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_act_bwd_dz_kernel(int M, int C, const T* __restrict__ dout, int d_ld, const T* __restrict__ z,
                                                             int z_ld, const float* __restrict__ coef, const double* __restrict__ bslots,
                                                             double count, const float* gamma, float* dgamma, float* dbeta,
-                                                            int accumulate, int act, T* __restrict__ dz, int dz_ld) {
+                                                            int accumulate, int act, T* __restrict__ dz, int dz_ld, plyolo_split sp,
+                                                            plyolo_bn_bwd_split p2) {
   constexpr int V = Vec<T>::N;
   __shared__ float s_b[3 * BN_MAXC];
   // dz = A*du + B*z + Cc with A = gamma*invstd, B = -A*invstd*mean(du*zhat), Cc = -A*mean(du) - B*mean
@@ -209,14 +226,19 @@ __global__ __launch_bounds__(256) void bn_act_bwd_dz_kernel(int M, int C, const 
     double s, ss;
     slot_sums(bslots, C, c, &s, &ss);
     const float mean = coef[2 * C + c], invstd = coef[3 * C + c];
-    const float A = (gamma ? gamma[c] : 1.f) * invstd;
+    const bool sec = p2.split > 0 && c >= p2.split;
+    const int cp = sec ? c - p2.split : c;
+    const float* gam = sec ? p2.gamma2 : gamma;
+    const float A = (gam ? gam[cp] : 1.f) * invstd;
     const float B = (float)(-(double)A * (ss / count) * (double)invstd);
     s_b[c] = A;
     s_b[C + c] = B;
     s_b[2 * C + c] = (float)(-(double)A * (s / count) - (double)B * (double)mean);
     if (blockIdx.x == 0) {
-      if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s;
-      if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)ss;
+      float* db_ = sec ? p2.dbeta2 : dbeta;
+      float* dg_ = sec ? p2.dgamma2 : dgamma;
+      if (db_) db_[cp] = (accumulate ? db_[cp] : 0.f) + (float)s;
+      if (dg_) dg_[cp] = (accumulate ? dg_[cp] : 0.f) + (float)ss;
     }
   }
   __syncthreads();
@@ -232,10 +254,13 @@ __global__ __launch_bounds__(256) void bn_act_bwd_dz_kernel(int M, int C, const 
       sc[i] = coef[c + i]; sh[i] = coef[C + c + i];
       A[i] = s_b[c + i]; B[i] = s_b[C + c + i]; Cc[i] = s_b[2 * C + c + i];
     }
+    const bool second = sp.split > 0 && c >= sp.split;
+    const T* db = second ? (const T*)sp.p2 + (c - sp.split) : dout + c;
+    const int dl = second ? sp.ld2 : d_ld;
 #pragma unroll 2
     for (int m = blockIdx.x * cm.rpb + cm.trow; m < M; m += step) {
       float d[V], zz[V];
-      Vec<T>::load(dout + (size_t)m * d_ld + c, d);
+      Vec<T>::load(db + (size_t)m * dl, d);
       Vec<T>::load(z + (size_t)m * z_ld + c, zz);
 #pragma unroll
       for (int i = 0; i < V; ++i) {
@@ -279,61 +304,90 @@ int plyolo_bn_finalize(const plyolo_bn_stats* stp, int C, float* coef, void* str
 int plyolo_bn_eval_coef(int C, const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                         float eps, float* coef, void* stream) {
   return submit(stream, [=](hipStream_t s) -> hipError_t {
-    hipLaunchKernelGGL(bn_eval_coef_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, C, gamma, beta, running_mean, running_var, eps, coef);
+    hipLaunchKernelGGL(bn_eval_coef_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, C, gamma, beta, running_mean, running_var, eps, coef, C, 0);
     return hipGetLastError();
   });
 }
 
+int plyolo_bn_eval_coef_at(int C, const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                           float eps, float* coef, int C_total, int c_off, void* stream) {
+  PLY_CHECK_ARG(C > 0 && c_off >= 0 && c_off + C <= C_total, "bn_eval_coef_at: bad channel window");
+  return submit(stream, [=](hipStream_t s) -> hipError_t {
+    hipLaunchKernelGGL(bn_eval_coef_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, C, gamma, beta, running_mean, running_var, eps, coef,
+                       C_total, c_off);
+    return hipGetLastError();
+  });
+}
+
+static int check_split(const plyolo_split* sp, int C, int V, const char* who) {
+  if (!sp || sp->split == 0) return 0;
+  PLY_CHECK_ARG(sp->split > 0 && sp->split < C && sp->split % V == 0 && sp->p2 && sp->ld2 % V == 0 && sp->ld2 >= C - sp->split,
+                "%s: bad channel split", who);
+  return 0;
+}
+
 int plyolo_bn_act_fwd(int dtype, int M, int C, const void* z, int z_ld, float* coef, int act, const void* res, int r_ld,
-                      void* out, int o_ld, const plyolo_bn_stats* stp, void* stream) {
+                      void* out, int o_ld, const plyolo_bn_stats* stp, const plyolo_split* osp, void* stream) {
   const int V = dtype == PLYOLO_BF16 ? 8 : 4;
   PLY_CHECK_ARG(C % V == 0 && z_ld % V == 0 && o_ld % V == 0 && (!res || r_ld % V == 0), "bn_act_fwd: C/ld must be multiples of %d", V);
   PLY_CHECK_ARG(!stp || (stp->slots && stp->count > 0 && coef && C <= BN_MAXC), "bn_act_fwd: incomplete plyolo_bn_stats (or C > %d)", BN_MAXC);
+  if (check_split(osp, C, V, "bn_act_fwd")) return -1;
+  PLY_CHECK_ARG(!(osp && osp->split) || !res, "bn_act_fwd: a split output cannot take a residual");
   const int grid = stream_grid(M, C / V);
   plyolo_bn_stats st{};
   if (stp) st = *stp;
+  plyolo_split sp{};
+  if (osp) sp = *osp;
   const bool fused = stp != nullptr;
   plyolo::annotate("bn_act_fwd", 0.0, (double)M * C * (dtype == PLYOLO_BF16 ? 2.0 : 4.0) * (res ? 3.0 : 2.0));
   return submit(stream, [=](hipStream_t s) -> hipError_t {
     DISPATCH_T(dtype, {
       if (fused)
         hipLaunchKernelGGL((bn_act_fwd_kernel<T, true>), dim3(grid), dim3(256), 0, s, M, C, (const T*)z, z_ld, coef, act, (const T*)res,
-                           r_ld, (T*)out, o_ld, st);
+                           r_ld, (T*)out, o_ld, st, sp);
       else
         hipLaunchKernelGGL((bn_act_fwd_kernel<T, false>), dim3(grid), dim3(256), 0, s, M, C, (const T*)z, z_ld, coef, act, (const T*)res,
-                           r_ld, (T*)out, o_ld, st);
+                           r_ld, (T*)out, o_ld, st, sp);
     })
     return hipGetLastError();
   });
 }
 
 int plyolo_bn_act_bwd_reduce(int dtype, int M, int C, const void* dout, int d_ld, const void* z, int z_ld, const float* coef,
-                             int act, double* bslots, void* stream) {
+                             int act, double* bslots, const plyolo_split* dsp, void* stream) {
   const int V = dtype == PLYOLO_BF16 ? 8 : 4;
   PLY_CHECK_ARG(C % V == 0 && z_ld % V == 0 && d_ld % V == 0, "bn_act_bwd_reduce: C/ld must be multiples of %d", V);
+  if (check_split(dsp, C, V, "bn_act_bwd_reduce")) return -1;
+  plyolo_split sp{};
+  if (dsp) sp = *dsp;
   int rows = M / 64;
   if (rows < 1) rows = 1;
   if (rows > 1024) rows = 1024;
   plyolo::annotate("bn_act_bwd_reduce", 0.0, (double)M * C * (dtype == PLYOLO_BF16 ? 2.0 : 4.0) * 2.0);
   return submit(stream, [=](hipStream_t s) -> hipError_t {
     DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<T>, dim3(rows), dim3(256), 0, s, M, C, (const T*)dout, d_ld,
-                                         (const T*)z, z_ld, coef, act, bslots);)
+                                         (const T*)z, z_ld, coef, act, bslots, sp);)
     return hipGetLastError();
   });
 }
 
 int plyolo_bn_act_bwd_dz(int dtype, int M, int C, const void* dout, int d_ld, const void* z, int z_ld, const float* coef,
                          const double* bslots, const float* gamma, float* dgamma, float* dbeta, int accumulate, int act, void* dz,
-                         int dz_ld, void* stream) {
+                         int dz_ld, const plyolo_split* dsp, const plyolo_bn_bwd_split* par2, void* stream) {
   const int V = dtype == PLYOLO_BF16 ? 8 : 4;
   PLY_CHECK_ARG(C % V == 0 && z_ld % V == 0 && d_ld % V == 0 && dz_ld % V == 0, "bn_act_bwd_dz: C/ld must be multiples of %d", V);
   PLY_CHECK_ARG(C <= BN_MAXC && bslots && coef, "bn_act_bwd_dz: C > %d or missing slots/coef", BN_MAXC);
+  if (check_split(dsp, C, V, "bn_act_bwd_dz")) return -1;
+  plyolo_split sp{};
+  if (dsp) sp = *dsp;
+  plyolo_bn_bwd_split p2{};
+  if (par2) p2 = *par2;
   const int grid = stream_grid(M, C / V);
   const double count = (double)M;
   plyolo::annotate("bn_act_bwd_dz", 0.0, (double)M * C * (dtype == PLYOLO_BF16 ? 2.0 : 4.0) * 3.0);
   return submit(stream, [=](hipStream_t s) -> hipError_t {
     DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_bwd_dz_kernel<T>, dim3(grid), dim3(256), 0, s, M, C, (const T*)dout, d_ld, (const T*)z,
-                                         z_ld, coef, bslots, count, gamma, dgamma, dbeta, accumulate, act, (T*)dz, dz_ld);)
+                                         z_ld, coef, bslots, count, gamma, dgamma, dbeta, accumulate, act, (T*)dz, dz_ld, sp, p2);)
     return hipGetLastError();
   });
 }

@@ -21,7 +21,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import BF16, F32, ACT, STAT_SLOTS, BnStats, ConvDesc, PackEntry, YoloxDesc, yolov7_desc, call, ptr
+from ._lib import BF16, F32, ACT, STAT_SLOTS, BnStats, Split, BnBwdSplit, ConvDesc, PackEntry, YoloxDesc, yolov7_desc, call, ptr
 
 BN_EPS_DEFAULT = 1e-3
 
@@ -88,6 +88,7 @@ class Graph:
         # weight gradients on their own lane (PLYOLO_LANES=0 keeps every launch on lane 0)
         self.use_lanes = os.environ.get("PLYOLO_LANES", "1") != "0"
         self.reduce_slabs = os.environ.get("PLYOLO_REDUCE_SLABS", "1") == "1"
+        self.pair_convs = os.environ.get("PLYOLO_PAIR", "1") == "1"   # merge same-input 1x1 conv pairs (ConvPairOp)
 
     # ------------------------------------------------------------------ lanes
     def add_op(self, op):
@@ -140,7 +141,7 @@ class Graph:
                 self.storages.remove(old)
             else:
                 dst = Act(st, a.C, off)
-                self.ops.append(CopyOp(self, a, dst))
+                self.add_op(CopyOp(self, a, dst))
             off += a.C
         out = Act(st, total, 0)
         out.fixed = True
@@ -161,7 +162,7 @@ class Graph:
         # one memset per plan zeroes a whole arena (zero_fwd_stats / zero_bwd_stats)
         off = 0
         for op in self.ops:
-            if isinstance(op, ConvUnitOp) and op.bn is not None:
+            if isinstance(op, (ConvUnitOp, ConvPairOp)) and op.bn is not None:
                 op.slot_off = off
                 off += STAT_SLOTS * 2 * op.Cout
         self.stat_arena = torch.zeros(max(off, 8), dtype=torch.float64, device=dev)
@@ -276,6 +277,7 @@ class Graph:
 
 
 DZ_BUFS = 4
+_OLD_ISSUE = os.environ.get("PLYOLO_ISSUE_OLD", "0") == "1"   # A/B switch for the issue-order experiments
 WGRAD_LANE = 1      # weight gradients (+ their slab reductions); branch lanes are 2, 3, ...
 
 
@@ -317,26 +319,44 @@ class _Branch:
 
 def record_ops(g, plan, ops, method):
     """Record `op.<method>()` for every op in `ops` (forward order, or reversed for the backward plan)
-    with the fork / join events of the regions they belong to."""
-    started, remaining = {}, {}
-    for op in ops:
+    with the fork / join events of the regions they belong to.  Inside a region the branches are issued
+    round-robin (lane 0 first): the branches are independent, so any interleaving that keeps each lane's
+    order is a valid serial order, and every lane gets work while the host is still issuing the others."""
+    i, n = 0, len(ops)
+    while i < n:
+        op = ops[i]
         r = op.region
-        lane = op.lane if r is not None else 0
-        if r is not None:
-            if id(r) not in started:
-                started[id(r)] = (plan.record(0), set())
-                remaining[id(r)] = len(r.ops)
-            ev, waited = started[id(r)]
-            if lane != 0 and lane not in waited:
-                plan.wait(lane, ev)
-                waited.add(lane)
-        plan.lane(lane)
-        getattr(op, method)()
-        if r is not None:
-            remaining[id(r)] -= 1
-            if remaining[id(r)] == 0:       # join: lane 0 continues after every branch lane
-                for l in sorted(r.lanes):
-                    plan.wait(0, plan.record(l))
+        if r is None:
+            plan.lane(0)
+            getattr(op, method)()
+            i += 1
+            continue
+        j = i
+        while j < n and ops[j].region is r:
+            j += 1
+        assert j - i == len(r.ops), "a fork region must be contiguous in the op list"
+        queues = {}
+        for o in ops[i:j]:
+            queues.setdefault(o.lane, []).append(o)
+        order = sorted(queues)           # lane 0 (the critical path) first
+        fork = plan.record(0)
+        for l in order:
+            if l != 0:
+                plan.wait(l, fork)
+        if _OLD_ISSUE:                   # branch after branch, in list order
+            for o in ops[i:j]:
+                plan.lane(o.lane)
+                getattr(o, method)()
+            queues = {}
+        while any(queues.values()):
+            for l in order:
+                if queues[l]:
+                    plan.lane(l)
+                    getattr(queues[l].pop(0), method)()
+        for l in order:                 # join: lane 0 continues after every branch lane
+            if l != 0:
+                plan.wait(0, plan.record(l))
+        i = j
     plan.lane(0)
 
 
@@ -450,7 +470,7 @@ class ConvUnitOp:
                      ptr(bn.running_var), float(bn.eps), coef, None)
         call("plyolo_bn_act_fwd", g.dtype, self.out.M, self.Cout, zt.data_ptr(), self.Cout, coef, self.act,
              g.aptr(self.res) if self.res is not None else None, self.res.ld if self.res is not None else 0,
-             g.aptr(self.out), self.out.ld, C.byref(st) if st is not None else None, None)
+             g.aptr(self.out), self.out.ld, C.byref(st) if st is not None else None, None, None)
 
     def bwd(self):
         g, bn = self.g, self.bn
@@ -464,17 +484,122 @@ class ConvUnitOp:
             acc = g.grad_mode(self.res)
             call("plyolo_copy_add", g.dtype, M, Cout, dout, self.out.ld, g.gptr(self.res), self.res.ld, acc, None)
         bslots = g.bstat_arena.data_ptr() + self.slot_off * 8
-        call("plyolo_bn_act_bwd_reduce", g.dtype, M, Cout, dout, self.out.ld, zt, Cout, self.coef.data_ptr(), self.act, bslots, None)
+        call("plyolo_bn_act_bwd_reduce", g.dtype, M, Cout, dout, self.out.ld, zt, Cout, self.coef.data_ptr(), self.act, bslots, None, None)
         plan, lanes, me = g.plan, g.use_lanes, self.lane
         dz, key = g.dz_buffer(me)
         if lanes and g.dz_event.get(key) is not None:
             plan.wait(me, g.dz_event.pop(key))   # the wgrad that last read this buffer has finished
         call("plyolo_bn_act_bwd_dz", g.dtype, M, Cout, dout, self.out.ld, zt, Cout, self.coef.data_ptr(), bslots, ptr(bn.weight),
-             g.grad_ptr_of(bn.weight), g.grad_ptr_of(bn.bias), 0, self.act, dz, Cout, None)
+             g.grad_ptr_of(bn.weight), g.grad_ptr_of(bn.bias), 0, self.act, dz, Cout, None, None, None)
+        def dgrad():
+            if self.need_dgrad:
+                acc = g.grad_mode(self.x)
+                call("plyolo_conv2d_dgrad", C.byref(self.desc), dz, self.pc.wpd, g.gptr(self.x), acc, None)
+
         if lanes:
             # the weight gradient only feeds the optimizer: it runs on its own lane, concurrently with the
-            # data-gradient chain of the layers upstream
+            # data-gradient chain of the layers upstream.  The main lane's dgrad is ISSUED first: the host
+            # needs a few microseconds per launch/event, and the main lane is the critical path.
             ev = plan.record(me)
+            if not _OLD_ISSUE:
+                dgrad()
+            plan.lane(WGRAD_LANE)
+            plan.wait(WGRAD_LANE, ev)
+            call("plyolo_conv2d_wgrad", C.byref(self.desc), g.aptr(self.x), dz, self.pc.dwp, None)
+            self.pc.reduce_slabs()
+            g.dz_event[key] = plan.record(WGRAD_LANE)
+            plan.lane(me)
+            if _OLD_ISSUE:
+                dgrad()
+        else:
+            call("plyolo_conv2d_wgrad", C.byref(self.desc), g.aptr(self.x), dz, self.pc.dwp, None)
+            self.pc.reduce_slabs()
+            dgrad()
+
+
+class ConvPairOp:
+    """Two BaseConv units with the SAME input, kernel size, stride and activation (CSPLayer conv1 || conv2,
+    network_blocks.py:108-110,123-124; the ELAN conv1 || conv2 pairs) run as ONE convolution with the
+    output channels concatenated: one conv + one bn_act launch forward, one reduce / dz / dgrad / wgrad
+    backward (the input gradient is written once instead of overwrite + accumulate), x is read once.
+    The two BatchNorm modules keep their own parameters (second parameter set of the BN kernels) and the
+    two activated outputs go to their own matrices (channel-split store)."""
+
+    def __init__(self, g, x, conv_a, bn_a, conv_b, bn_b, act, stride=1):
+        self.g, self.x, self.bn_a, self.bn_b, self.act, self.stride = g, x, bn_a, bn_b, ACT[act], stride
+        Ca, Cin, k, _ = conv_a.shape
+        Cb = conv_b.shape[0]
+        assert tuple(conv_b.shape[1:]) == (Cin, k, k) and x.C == Cin and Ca % g.vec == 0 and Cb % g.vec == 0
+        self.k, self.Cin_p, self.Ca, self.Cb, self.Cout = k, Cin, Ca, Cb, Ca + Cb
+        pad = (k - 1) // 2
+        self.OH = (x.H + 2 * pad - k) // stride + 1
+        self.OW = (x.W + 2 * pad - k) // stride + 1
+        self.pc = PackedConv(g, [(conv_a, None, 0), (conv_b, None, Ca)], k, Cin, True)
+        self.out_a = g.new_act(x.N, self.OH, self.OW, Ca, "a")
+        self.out_b = g.new_act(x.N, self.OH, self.OW, Cb, "a")
+        self.out = self.out_a
+        self.z = Storage(x.N, self.OH, self.OW, self.Cout, "z")
+        g.storages.append(self.z)
+        self.desc = conv_desc(g, x.N, x.H, x.W, Cin, self.Cout, k, stride, Cin, self.Cout)
+        self.pc.set_slabs(self.desc)
+        g.scratch_elems = max(g.scratch_elems, self.z.rows * self.Cout)
+        self.need_dgrad, self.bn, self.res = True, bn_a, None
+        g.add_op(self)
+
+    def _split(self, base_ptr_fn, act_b):
+        sp = Split()
+        sp.split, sp.p2, sp.ld2 = self.Ca, base_ptr_fn(act_b), act_b.ld
+        return sp
+
+    def fwd(self):
+        g, a, b = self.g, self.bn_a, self.bn_b
+        if not hasattr(self, "coef"):
+            self.desc.x_ld = self.x.ld
+            self.coef = torch.empty(4 * self.Cout, dtype=torch.float32, device=g.device)
+        zt = self.z.tensor
+        slots = g.stat_arena.data_ptr() + self.slot_off * 8 if g.training else None
+        call("plyolo_conv2d_fwd", C.byref(self.desc), g.aptr(self.x), self.pc.wp, None, zt.data_ptr(), slots, None)
+        st = None
+        if g.training:
+            st = BnStats()
+            st.slots, st.count = slots, float(self.out_a.M)
+            st.gamma, st.beta, st.gamma2, st.beta2 = ptr(a.weight), ptr(a.bias), ptr(b.weight), ptr(b.bias)
+            st.eps, st.momentum, st.split = float(a.eps), float(a.momentum), self.Ca
+            st.running_mean, st.running_var, st.num_batches_tracked = ptr(a.running_mean), ptr(a.running_var), ptr(a.num_batches_tracked)
+            st.running_mean2, st.running_var2, st.num_batches_tracked2 = ptr(b.running_mean), ptr(b.running_var), ptr(b.num_batches_tracked)
+        else:
+            for bn, off, n in ((a, 0, self.Ca), (b, self.Ca, self.Cb)):
+                call("plyolo_bn_eval_coef_at", n, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var),
+                     float(bn.eps), self.coef.data_ptr(), self.Cout, off, None)
+        sp = self._split(g.aptr, self.out_b)
+        call("plyolo_bn_act_fwd", g.dtype, self.out_a.M, self.Cout, zt.data_ptr(), self.Cout, self.coef.data_ptr(), self.act,
+             None, 0, g.aptr(self.out_a), self.out_a.ld, C.byref(st) if st is not None else None, C.byref(sp), None)
+
+    def bwd(self):
+        g, a, b = self.g, self.bn_a, self.bn_b
+        ra, rb = g.grad_ready(self.out_a), g.grad_ready(self.out_b)
+        if not (ra or rb):
+            return
+        if not (ra and rb):
+            raise NotImplementedError("ConvPairOp: both outputs must receive a gradient")
+        M, Cout = self.out_a.M, self.Cout
+        zt = self.z.tensor.data_ptr()
+        dsp = self._split(g.gptr, self.out_b)
+        bslots = g.bstat_arena.data_ptr() + self.slot_off * 8
+        call("plyolo_bn_act_bwd_reduce", g.dtype, M, Cout, g.gptr(self.out_a), self.out_a.ld, zt, Cout, self.coef.data_ptr(), self.act,
+             bslots, C.byref(dsp), None)
+        plan, lanes, me = g.plan, g.use_lanes, self.lane
+        dz, key = g.dz_buffer(me)
+        if lanes and g.dz_event.get(key) is not None:
+            plan.wait(me, g.dz_event.pop(key))
+        p2 = BnBwdSplit()
+        p2.split, p2.gamma2, p2.dgamma2, p2.dbeta2 = self.Ca, ptr(b.weight), g.grad_ptr_of(b.weight), g.grad_ptr_of(b.bias)
+        call("plyolo_bn_act_bwd_dz", g.dtype, M, Cout, g.gptr(self.out_a), self.out_a.ld, zt, Cout, self.coef.data_ptr(), bslots,
+             ptr(a.weight), g.grad_ptr_of(a.weight), g.grad_ptr_of(a.bias), 0, self.act, dz, Cout, C.byref(dsp), C.byref(p2), None)
+        acc = g.grad_mode(self.x)
+        if lanes:
+            ev = plan.record(me)
+            call("plyolo_conv2d_dgrad", C.byref(self.desc), dz, self.pc.wpd, g.gptr(self.x), acc, None)
             plan.lane(WGRAD_LANE)
             plan.wait(WGRAD_LANE, ev)
             call("plyolo_conv2d_wgrad", C.byref(self.desc), g.aptr(self.x), dz, self.pc.dwp, None)
@@ -484,8 +609,6 @@ class ConvUnitOp:
         else:
             call("plyolo_conv2d_wgrad", C.byref(self.desc), g.aptr(self.x), dz, self.pc.dwp, None)
             self.pc.reduce_slabs()
-        if self.need_dgrad:
-            acc = g.grad_mode(self.x)
             call("plyolo_conv2d_dgrad", C.byref(self.desc), dz, self.pc.wpd, g.gptr(self.x), acc, None)
 
 

@@ -70,6 +70,23 @@ class BaseConv(HipModule):
         return op.out
 
 
+def emit_pair(g, x, unit_a, unit_b):
+    """Two BaseConv units applied to the same input.  When they agree in kernel size, stride, activation
+    and BatchNorm hyper-parameters they are lowered to ONE merged convolution (graph.ConvPairOp); the two
+    modules keep their own parameters and state_dict keys.  Returns (out_a, out_b)."""
+    ca, cb = unit_a.conv, unit_b.conv
+    na, nb = unit_a.norm, unit_b.norm
+    act_a = unit_a.act.act_name if unit_a.act is not None else None
+    act_b = unit_b.act.act_name if unit_b.act is not None else None
+    same = (g.pair_convs and ca.kernel_size == cb.kernel_size and unit_a.stride == unit_b.stride and act_a == act_b
+            and na is not None and nb is not None and na.eps == nb.eps and na.momentum == nb.momentum
+            and ca.out_channels % g.vec == 0 and cb.out_channels % g.vec == 0)
+    if not same:
+        return unit_a.emit(g, x), unit_b.emit(g, x)
+    op = G.ConvPairOp(g, x, ca.weight, na, cb.weight, nb, act_a, unit_a.stride)
+    return op.out_a, op.out_b
+
+
 class Focus(HipModule):
     """Focus width and height information into channel space (network_blocks.py:43-65)."""
 
@@ -113,8 +130,7 @@ class CSPLayer(HipModule):
         self.m = nn.Sequential(*[Bottleneck(hidden_channels, hidden_channels, shortcut, 1.0, norm=norm, act=act) for _ in range(num_bottle)])
 
     def emit(self, g, x):
-        x_1 = self.conv1.emit(g, x)
-        x_2 = self.conv2.emit(g, x)
+        x_1, x_2 = emit_pair(g, x, self.conv1, self.conv2)
         for b in self.m:
             x_1 = b.emit(g, x_1)
         return self.conv3.emit(g, g.concat([x_1, x_2]))
@@ -154,8 +170,8 @@ class SPPCSPC(HipModule):
         self.cv7 = BaseConv(2 * c2, c2, 1, 1)
 
     def emit(self, g, x):
-        x1 = self.cv4.emit(g, self.cv3.emit(g, self.cv1.emit(g, x)))
+        t1, y2 = emit_pair(g, x, self.cv1, self.cv2)
+        x1 = self.cv4.emit(g, self.cv3.emit(g, t1))
         pools = G.SppPoolsOp(g, x1, self.kernel_sizes)
         y1 = self.cv6.emit(g, self.cv5.emit(g, g.concat([x1] + pools.outs)))
-        y2 = self.cv2.emit(g, x)
         return self.cv7.emit(g, g.concat([y1, y2]))

@@ -2,7 +2,7 @@
 import torch.nn as nn
 
 from . import graph as G
-from .layers import BaseConv, CSPLayer, HipModule
+from .layers import emit_pair, BaseConv, CSPLayer, HipModule
 
 
 class CSPPAFPN(HipModule):
@@ -54,8 +54,7 @@ class ELANWLayer(HipModule):
         self.conv5 = BaseConv(cat_channel, out_channel, 1, stride=1, norm=norm, act=act)
 
     def emit(self, g, x):
-        x_1 = self.conv1.emit(g, x)
-        x_2 = self.conv2.emit(g, x)
+        x_1, x_2 = emit_pair(g, x, self.conv1, self.conv2)
         x_3 = self.conv3.emit(g, x_2)
         x_all = [x_1, x_2, x_3]
         for m in self.conv4:

@@ -180,8 +180,11 @@ class DetectorRunner:
                     op.post_unpack()
             seen = set()
             for op in g.ops:
-                if isinstance(op, G.ConvUnitOp) and op.bn is not None:
-                    for p in (op.bn.weight, op.bn.bias):
+                bns = [op.bn] if isinstance(op, G.ConvUnitOp) else ([op.bn_a, op.bn_b] if isinstance(op, G.ConvPairOp) else [])
+                for bn in bns:
+                    if bn is None:
+                        continue
+                    for p in (bn.weight, bn.bias):
                         if p is not None and id(p) not in seen:
                             seen.add(id(p))
                             s.used_params.append(p)

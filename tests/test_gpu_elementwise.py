@@ -64,12 +64,12 @@ def test_bn_act_fwd_bwd(dt, act):
     st.running_mean, st.running_var, st.num_batches_tracked = rm.data_ptr(), rv.data_ptr(), nbt.data_ptr()
     out = torch.full((M, Cc + 16), 2.0, dtype=hu.tdtype(dt), device=hu.DEV)
     call("plyolo_bn_act_fwd", dt, M, Cc, zm.data_ptr(), Cc, coef.data_ptr(), hu._lib.ACT[act], resm.data_ptr(), Cc + 8,
-         out.data_ptr(), Cc + 16, C.byref(st), hu.stream())
+         out.data_ptr(), Cc + 16, C.byref(st), None, hu.stream())
     torch.cuda.synchronize()
     assert torch.equal(coef, coef2)
     out_b = torch.full((M, Cc + 16), 2.0, dtype=hu.tdtype(dt), device=hu.DEV)   # coef as an input gives the same bytes
     call("plyolo_bn_act_fwd", dt, M, Cc, zm.data_ptr(), Cc, coef.data_ptr(), hu._lib.ACT[act], resm.data_ptr(), Cc + 8,
-         out_b.data_ptr(), Cc + 16, None, hu.stream())
+         out_b.data_ptr(), Cc + 16, None, None, hu.stream())
     torch.cuda.synchronize()
     assert torch.equal(out, out_b)
     torch.cuda.synchronize()
@@ -84,9 +84,9 @@ def test_bn_act_fwd_bwd(dt, act):
     bslots = torch.zeros(hu._lib.STAT_SLOTS, 2, Cc, dtype=torch.float64, device=hu.DEV)
     dg, db = torch.zeros(Cc, device=hu.DEV), torch.zeros(Cc, device=hu.DEV)
     dz = torch.zeros(M, Cc, dtype=hu.tdtype(dt), device=hu.DEV)
-    call("plyolo_bn_act_bwd_reduce", dt, M, Cc, dm.data_ptr(), Cc + 8, zm.data_ptr(), Cc, coef.data_ptr(), hu._lib.ACT[act], bslots.data_ptr(), hu.stream())
+    call("plyolo_bn_act_bwd_reduce", dt, M, Cc, dm.data_ptr(), Cc + 8, zm.data_ptr(), Cc, coef.data_ptr(), hu._lib.ACT[act], bslots.data_ptr(), None, hu.stream())
     call("plyolo_bn_act_bwd_dz", dt, M, Cc, dm.data_ptr(), Cc + 8, zm.data_ptr(), Cc, coef.data_ptr(), bslots.data_ptr(), gamma.data_ptr(),
-         dg.data_ptr(), db.data_ptr(), 0, hu._lib.ACT[act], dz.data_ptr(), Cc, hu.stream())
+         dg.data_ptr(), db.data_ptr(), 0, hu._lib.ACT[act], dz.data_ptr(), Cc, None, None, hu.stream())
     torch.cuda.synchronize()
     e1, e2, e3 = hu.relerr(hu.from_nhwc(dz, N, H, W, Cc), gz), hu.relerr(dg, gg), hu.relerr(db, gb)
     print("bn_act_bwd", act, "dz %.3g dgamma %.3g dbeta %.3g" % (e1, e2, e3))

@@ -19,7 +19,7 @@ def mk(N, H, W, Cin, Cout, k):
     return dict(x=x, y=y, d=d, pk=pk, z=z, coef=coef, M=N * H * W, C=Cout)
 
 def conv(b, st): call("plyolo_conv2d_fwd", C.byref(b["d"]), b["x"].data_ptr(), b["pk"].wp.data_ptr(), None, b["y"].data_ptr(), None, st)
-def bn(b, st): call("plyolo_bn_act_fwd", BF16, b["M"], b["C"], b["z"].data_ptr(), b["C"], b["coef"].data_ptr(), 1, None, 0, b["y"].data_ptr(), b["C"], None, st)
+def bn(b, st): call("plyolo_bn_act_fwd", BF16, b["M"], b["C"], b["z"].data_ptr(), b["C"], b["coef"].data_ptr(), 1, None, 0, b["y"].data_ptr(), b["C"], None, None, st)
 
 for name, shape in [("3x3 128->128 @40", (32, 40, 40, 128, 128, 3)), ("1x1 256->128 @40", (32, 40, 40, 256, 128, 1)), ("3x3 128->128 @20", (32, 20, 20, 128, 128, 3)),
                     ("1x1 512->256 @20", (32, 20, 20, 512, 256, 1)), ("3x3 64->64 @80", (32, 80, 80, 64, 64, 3))]:
