@@ -5,7 +5,7 @@ import torch
 import torch.nn as nn
 
 from . import graph as G
-from .layers import BaseConv, HipModule
+from .layers import emit_pair, BaseConv, HipModule
 
 
 class DecoupledHead(HipModule):
@@ -51,10 +51,11 @@ class DecoupledHead(HipModule):
             for k, x in enumerate(inputs):
                 with region.branch(0 if k == 0 else 1 + k):
                     x = self.stems[k].emit(g, x)
-                    cls_feat, reg_feat = x, x
-                    for m in self.cls_convs[k]:
+                    # the first conv of the cls and of the reg branch read the same stem output: one merged conv
+                    cls_feat, reg_feat = emit_pair(g, x, self.cls_convs[k][0], self.reg_convs[k][0])
+                    for m in list(self.cls_convs[k])[1:]:
                         cls_feat = m.emit(g, cls_feat)
-                    for m in self.reg_convs[k]:
+                    for m in list(self.reg_convs[k])[1:]:
                         reg_feat = m.emit(g, reg_feat)
                     G.HeadPredOp(g, head_buffers, k, cls_feat, reg_feat, self.cls_preds[k], self.reg_preds[k], self.obj_preds[k])
         return head_buffers
