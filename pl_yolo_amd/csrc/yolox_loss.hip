@@ -33,6 +33,8 @@ struct LossWs {
   int* lastg;      // [B,A]
   int* G;          // [B]
   float* partial;  // [nblk,4]
+  float* costm;    // [B,M,A] pair cost of (GT g, anchor a), written for candidate anchors only
+  float* ioum;     // [B,M,A] pair IoU
 };
 
 constexpr int MAXM = 256;  // label rows per image supported by the LDS staging
@@ -98,17 +100,38 @@ DEVINL float pair_cost(const plyolo_yolox_desc& d, const float* raw_a, const flo
   return (cls_cost + 3.0f * iou_cost) + 100000.0f * ((ib && ic) ? 0.0f : 1.0f);
 }
 
-__global__ void k_prep(const plyolo_yolox_desc d, const float* raw, const float* labels, LossWs ws) {
-  __shared__ float lab[MAXM * 5];
-  __shared__ int sG;
-  const int b = blockIdx.y;
+// One workgroup = up to 128 consecutive anchors of ONE level of one image.  Their raw rows are contiguous
+// in the level-major head output, so they are staged into LDS with coalesced dword loads (a thread walking
+// its own 340-byte row straight from global costs a cache line per lane and load: x16 L2 traffic); each
+// thread then owns one anchor: decode, candidate test, the class-independent cost term S, and -- for
+// candidates -- the pair cost / IoU against every GT of the image, written to the [G, A] matrices that
+// k_topk and k_resolve read (one definition of the cost, computed once).
+constexpr int PREP_T = 128;
+__global__ __launch_bounds__(PREP_T) void k_prep(const plyolo_yolox_desc d, const float* raw, const float* labels, LossWs ws) {
+  extern __shared__ float prep_smem[];
   const int nch = 5 + d.C;
-  for (int i = threadIdx.x; i < d.M * 5; i += blockDim.x) lab[i] = labels[(size_t)b * d.M * 5 + i];
-  if (threadIdx.x == 0) sG = 0;
+  float* rows = prep_smem;                 // [PREP_T][nch]
+  float* lab = prep_smem + PREP_T * nch;   // [M][5]
+  __shared__ int sG;
+  const int b = blockIdx.y, tid = threadIdx.x;
+  // level and chunk of this workgroup
+  int l = 0, chunk = blockIdx.x;
+  for (; l < d.nlevels; ++l) {
+    const int nc = (d.lvl_h[l] * d.lvl_w[l] + PREP_T - 1) / PREP_T;
+    if (chunk < nc) break;
+    chunk -= nc;
+  }
+  if (l >= d.nlevels) return;
+  const int hw = d.lvl_h[l] * d.lvl_w[l];
+  const int f0 = chunk * PREP_T, n = min(PREP_T, hw - f0);
+  const float* src = raw + ((size_t)d.lvl_row[l] + (size_t)b * hw + f0) * nch;
+  for (int i = tid; i < n * nch; i += PREP_T) rows[i] = src[i];
+  for (int i = tid; i < d.M * 5; i += PREP_T) lab[i] = labels[(size_t)b * d.M * 5 + i];
+  if (tid == 0) sG = 0;
   __syncthreads();
   {
     int local = 0;
-    for (int g = threadIdx.x; g < d.M; g += blockDim.x) {
+    for (int g = tid; g < d.M; g += PREP_T) {
       const float s = lab[g * 5] + lab[g * 5 + 1] + lab[g * 5 + 2] + lab[g * 5 + 3] + lab[g * 5 + 4];
       local += s > 0.f ? 1 : 0;
     }
@@ -116,11 +139,11 @@ __global__ void k_prep(const plyolo_yolox_desc d, const float* raw, const float*
   }
   __syncthreads();
   const int G = sG;
-  if (blockIdx.x == 0 && threadIdx.x == 0) ws.G[b] = G;
-  const int a = blockIdx.x * blockDim.x + threadIdx.x;
-  if (a >= d.A) return;
+  if (blockIdx.x == 0 && tid == 0) ws.G[b] = G;
+  if (tid >= n) return;
+  const int a = d.lvl_off[l] + f0 + tid;
   const size_t ba = (size_t)b * d.A + a;
-  const float* r = raw + raw_row(d, b, a) * nch;
+  const float* r = rows + tid * nch;
   float xs, ys, st;
   anchor_geom(d, a, &xs, &ys, &st);
   float dec[4];
@@ -145,6 +168,13 @@ __global__ void k_prep(const plyolo_yolox_desc d, const float* raw, const float*
     for (int c = 0; c < d.C; ++c) {
       const float p = sqrtf(sigmoidf_(r[5 + c]) * so);
       S += -fmaxf(log1pf(-p), -100.0f);
+    }
+    for (int g = 0; g < G; ++g) {
+      float iou;
+      const float cost = pair_cost(d, r, dec, S, lab + g * 5, xc, yc, st, &iou);
+      const size_t o = ((size_t)b * d.M + g) * d.A + a;
+      ws.costm[o] = cost;
+      ws.ioum[o] = iou;
     }
   }
   ws.S[ba] = S;
@@ -196,16 +226,14 @@ __global__ __launch_bounds__(256) void k_topk(const plyolo_yolox_desc d, const f
   unsigned long long top_ik[10], top_key[10];
 #pragma unroll
   for (int i = 0; i < 10; ++i) { top_ik[i] = 0ull; top_key[i] = ~0ull; }
+  const float* crow = ws.costm + ((size_t)b * d.M + g) * d.A;
+  const float* irow = ws.ioum + ((size_t)b * d.M + g) * d.A;
   int nc = 0;
   for (int a = tid; a < d.A; a += 256) {
     const size_t ba = (size_t)b * d.A + a;
     if (!ws.cand[ba]) continue;
     ++nc;
-    float xs, ys, st;
-    anchor_geom(d, a, &xs, &ys, &st);
-    const float xc = xs * st + 0.5f * st, yc = ys * st + 0.5f * st;
-    float iou;
-    const float cost = pair_cost(d, raw + raw_row(d, b, a) * nch, ws.dec + ba * 4, ws.S[ba], gl, xc, yc, st, &iou);
+    const float iou = irow[a], cost = crow[a];   // computed once by k_prep
     unsigned long long x = iou_key(iou, a);
     unsigned long long k = cost_key(cost, a);
 #pragma unroll
@@ -293,25 +321,17 @@ __global__ void k_resolve(const plyolo_yolox_desc d, const float* raw, const flo
     miou[ba] = 0.f;
     return;
   }
-  const int nch = 5 + d.C;
-  float xs, ys, st;
-  anchor_geom(d, a, &xs, &ys, &st);
-  const float xc = xs * st + 0.5f * st, yc = ys * st + 0.5f * st;
-  const float* lab = labels + (size_t)b * d.M * 5;
-  const float* rawa = raw + raw_row(d, b, a) * nch;
   int g = ws.lastg[ba];
-  float iou;
-  if (c > 1) {
+  if (c > 1) {   // several GTs voted for this anchor: it goes to the cheapest one (first minimum)
     const int G = ws.G[b];
     float best = INFINITY;
     g = 0;
     for (int gg = 0; gg < G; ++gg) {
-      float io;
-      const float cost = pair_cost(d, rawa, ws.dec + ba * 4, ws.S[ba], lab + gg * 5, xc, yc, st, &io);
+      const float cost = ws.costm[((size_t)b * d.M + gg) * d.A + a];
       if (cost < best) { best = cost; g = gg; }
     }
   }
-  pair_cost(d, rawa, ws.dec + ba * 4, ws.S[ba], lab + g * 5, xc, yc, st, &iou);
+  const float iou = ws.ioum[((size_t)b * d.M + g) * d.A + a];
   fg[ba] = 1;
   mgt[ba] = g;
   miou[ba] = iou;
@@ -544,6 +564,8 @@ LossWs carve(const plyolo_yolox_desc* d, void* workspace, size_t* used) {
   ws.G = (int*)(p + off); off += align256((size_t)d->B * 4);
   const size_t nblk = (BA + 255) / 256;
   ws.partial = (float*)(p + off); off += align256(nblk * 16);
+  ws.costm = (float*)(p + off); off += align256(BA * d->M * 4);
+  ws.ioum = (float*)(p + off); off += align256(BA * d->M * 4);
   *used = off;
   return ws;
 }
@@ -574,7 +596,14 @@ int plyolo_yolox_loss_fwd(const plyolo_yolox_desc* dp, const float* raw, const f
   return submit(stream, [=](hipStream_t s) -> hipError_t {
     hipError_t e = plyolo::fill_async(ws.cnt, 0, BA * 4, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_prep, dim3(cdiv(d.A, 256), d.B), dim3(256), 0, s, d, raw, labels, ws);
+    int nchunk = 0;
+    for (int l = 0; l < d.nlevels; ++l) nchunk += cdiv(d.lvl_h[l] * d.lvl_w[l], PREP_T);
+    const size_t prep_lds = ((size_t)PREP_T * (5 + d.C) + (size_t)d.M * 5) * 4;
+    if (prep_lds > 64 * 1024) {
+      hipError_t ea = hipFuncSetAttribute((const void*)k_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds);
+      if (ea != hipSuccess) return ea;
+    }
+    hipLaunchKernelGGL(k_prep, dim3(nchunk, d.B), dim3(PREP_T), prep_lds, s, d, raw, labels, ws);
     hipLaunchKernelGGL(k_topk, dim3(d.M, d.B), dim3(256), 0, s, d, raw, labels, ws);
     hipLaunchKernelGGL(k_resolve, dim3(cdiv(d.A, 256), d.B), dim3(256), 0, s, d, raw, labels, ws, fg, matched_gt, matched_iou);
     hipLaunchKernelGGL(k_loss, dim3(nblk), dim3(256), 0, s, d, raw, labels, ws, fg, matched_gt, matched_iou);

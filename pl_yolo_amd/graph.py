@@ -876,16 +876,26 @@ class HeadPredOp:
             d_ro, d_cl = self.d_ro, self.d_cls
             ld_ro = ld_cl = hd.nch
         self.keep = (d_ro, d_cl)
+        # the data gradients continue the main chain; the parameter gradients (bias sums, weight gradients)
+        # only feed the optimizer and go to the weight-gradient lane (their inputs -- the loss gradients and the
+        # forward features -- are not written again in this plan)
+        plan, lanes, me = g.plan, g.use_lanes, self.lane
+        ev = plan.record(me) if lanes else None
+        acc = g.grad_mode(self.reg_feat)
+        call("plyolo_conv2d_dgrad", C.byref(d_ro), dro, self.pc_ro.wpd, g.gptr(self.reg_feat), acc, None)
+        acc = g.grad_mode(self.cls_feat)
+        call("plyolo_conv2d_dgrad", C.byref(d_cl), dcl, self.pc_cls.wpd, g.gptr(self.cls_feat), acc, None)
+        if lanes:
+            plan.lane(WGRAD_LANE)
+            plan.wait(WGRAD_LANE, ev)
         call("plyolo_bias_grad", g.dtype, dro, M, 5, ld_ro, self.pc_ro.dbp, None)
         call("plyolo_bias_grad", g.dtype, dcl, M, self.nc, ld_cl, self.pc_cls.dbp, None)
         call("plyolo_conv2d_wgrad", C.byref(d_ro), g.aptr(self.reg_feat), dro, self.pc_ro.dwp, None)
         self.pc_ro.reduce_slabs()
         call("plyolo_conv2d_wgrad", C.byref(d_cl), g.aptr(self.cls_feat), dcl, self.pc_cls.dwp, None)
         self.pc_cls.reduce_slabs()
-        acc = g.grad_mode(self.reg_feat)
-        call("plyolo_conv2d_dgrad", C.byref(d_ro), dro, self.pc_ro.wpd, g.gptr(self.reg_feat), acc, None)
-        acc = g.grad_mode(self.cls_feat)
-        call("plyolo_conv2d_dgrad", C.byref(d_cl), dcl, self.pc_cls.wpd, g.gptr(self.cls_feat), acc, None)
+        if lanes:
+            plan.lane(me)
 
 
 class HeadBuffers:
