@@ -40,6 +40,10 @@ struct LossWs {
 constexpr int MAXM = 256;  // label rows per image supported by the LDS staging
 
 DEVINL float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// Hardware-rate versions for the SimOTA cost only (v_exp / v_log / v_rcp / v_sqrt: ~1-2 ulp).  The cost
+// feeds discrete choices, never the loss value; its libm-precise form made k_prep VALU-bound (80 classes x
+// exp, div, sqrt, log1p per candidate anchor).
+DEVINL float sig_fast(float x) { return __frcp_rn(1.0f + __expf(-x)); }
 
 DEVINL int anchor_level(const plyolo_yolox_desc& d, int a) {
   int l = 0;
@@ -84,17 +88,14 @@ DEVINL void in_masks(const float* gt, float xc, float yc, float st, bool* in_box
 }
 
 // cost[g,a] and iou[g,a] -- the ONE definition used by both k_topk and k_resolve
-DEVINL float pair_cost(const plyolo_yolox_desc& d, const float* raw_a, const float* dec_a, float S_a, const float* lab_g, float xc,
-                       float yc, float st, float* iou_out) {
+DEVINL float pair_cost(const float* delta_a, const float* dec_a, float S_a, const float* lab_g, float xc, float yc, float st,
+                       float* iou_out) {
   const float iou = pair_iou(lab_g + 1, dec_a);
   *iou_out = iou;
-  const float iou_cost = -logf(iou + 1e-8f);
-  const int cg = (int)lab_g[0];
-  const float p = sqrtf(sigmoidf_(raw_a[5 + cg]) * sigmoidf_(raw_a[4]));
-  // F.binary_cross_entropy: -(t*max(log p,-100) + (1-t)*max(log1p(-p),-100)); S_a holds the t=0 terms of all classes
-  const float t0 = -fmaxf(log1pf(-p), -100.0f);
-  const float t1 = -fmaxf(logf(p), -100.0f);
-  const float cls_cost = (S_a - t0) + t1;
+  const float iou_cost = -__logf(iou + 1e-8f);
+  // F.binary_cross_entropy(sqrt(sig(cls)*sig(obj)), onehot).sum(C): S_a holds the t=0 terms of all classes,
+  // delta_a[c] = (t=1 term) - (t=0 term) of class c (both clamped at 100 like torch)
+  const float cls_cost = S_a + delta_a[(int)lab_g[0]];
   bool ib, ic;
   in_masks(lab_g + 1, xc, yc, st, &ib, &ic);
   return (cls_cost + 3.0f * iou_cost) + 100000.0f * ((ib && ic) ? 0.0f : 1.0f);
@@ -108,7 +109,7 @@ DEVINL float pair_cost(const plyolo_yolox_desc& d, const float* raw_a, const flo
 // k_topk and k_resolve read (one definition of the cost, computed once).
 constexpr int PREP_T = 128;
 __global__ __launch_bounds__(PREP_T) void k_prep(const plyolo_yolox_desc d, const float* raw, const float* labels, LossWs ws) {
-  extern __shared__ float prep_smem[];
+  extern __shared__ __align__(16) float prep_smem[];
   const int nch = 5 + d.C;
   float* rows = prep_smem;                 // [PREP_T][nch]
   float* lab = prep_smem + PREP_T * nch;   // [M][5]
@@ -125,7 +126,45 @@ __global__ __launch_bounds__(PREP_T) void k_prep(const plyolo_yolox_desc d, cons
   const int hw = d.lvl_h[l] * d.lvl_w[l];
   const int f0 = chunk * PREP_T, n = min(PREP_T, hw - f0);
   const float* src = raw + ((size_t)d.lvl_row[l] + (size_t)b * hw + f0) * nch;
-  for (int i = tid; i < n * nch; i += PREP_T) rows[i] = src[i];
+  {
+    // batched copy: BATCH loads in flight per thread before the first LDS store (a load -> store loop
+    // serialises the round trips), 16-byte vectors when the block of rows is 16-byte aligned
+    constexpr int BATCH = 8;
+    const int total = n * nch;
+    if ((((size_t)src) & 15) == 0) {
+      const int nv = total >> 2;
+      const f32x4* s4 = (const f32x4*)src;
+      f32x4* r4 = (f32x4*)rows;
+      for (int i0 = 0; i0 < nv; i0 += BATCH * PREP_T) {
+        f32x4 v[BATCH];
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+          const int i = i0 + tid + k * PREP_T;
+          v[k] = i < nv ? s4[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+          const int i = i0 + tid + k * PREP_T;
+          if (i < nv) r4[i] = v[k];
+        }
+      }
+      for (int i = (nv << 2) + tid; i < total; i += PREP_T) rows[i] = src[i];
+    } else {
+      for (int i0 = 0; i0 < total; i0 += BATCH * PREP_T) {
+        float v[BATCH];
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+          const int i = i0 + tid + k * PREP_T;
+          v[k] = i < total ? src[i] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+          const int i = i0 + tid + k * PREP_T;
+          if (i < total) rows[i] = v[k];
+        }
+      }
+    }
+  }
   for (int i = tid; i < d.M * 5; i += PREP_T) lab[i] = labels[(size_t)b * d.M * 5 + i];
   if (tid == 0) sG = 0;
   __syncthreads();
@@ -143,7 +182,7 @@ __global__ __launch_bounds__(PREP_T) void k_prep(const plyolo_yolox_desc d, cons
   if (tid >= n) return;
   const int a = d.lvl_off[l] + f0 + tid;
   const size_t ba = (size_t)b * d.A + a;
-  const float* r = rows + tid * nch;
+  float* r = rows + tid * nch;
   float xs, ys, st;
   anchor_geom(d, a, &xs, &ys, &st);
   float dec[4];
@@ -164,14 +203,17 @@ __global__ __launch_bounds__(PREP_T) void k_prep(const plyolo_yolox_desc d, cons
   ws.cand[ba] = cand ? 1 : 0;
   float S = 0.f;
   if (cand) {
-    const float so = sigmoidf_(r[4]);
+    const float so = sig_fast(r[4]);
     for (int c = 0; c < d.C; ++c) {
-      const float p = sqrtf(sigmoidf_(r[5 + c]) * so);
-      S += -fmaxf(log1pf(-p), -100.0f);
+      const float p = __fsqrt_rn(sig_fast(r[5 + c]) * so);
+      const float t0 = -fmaxf(__logf(1.0f - p), -100.0f);
+      const float t1 = -fmaxf(__logf(p), -100.0f);
+      S += t0;
+      r[5 + c] = t1 - t0;   // the raw class logit of this (private) LDS row is not needed again
     }
     for (int g = 0; g < G; ++g) {
       float iou;
-      const float cost = pair_cost(d, r, dec, S, lab + g * 5, xc, yc, st, &iou);
+      const float cost = pair_cost(r + 5, dec, S, lab + g * 5, xc, yc, st, &iou);
       const size_t o = ((size_t)b * d.M + g) * d.A + a;
       ws.costm[o] = cost;
       ws.ioum[o] = iou;
@@ -394,9 +436,26 @@ __global__ __launch_bounds__(256) void k_loss(const plyolo_yolox_desc d, const f
       const float* lg = labels + ((size_t)b * d.M + mgt[ba]) * 5;
       s_fg = 1.f;
       s_iou = giou_loss(ws.dec + ba * 4, lg + 1, nullptr);
+    }
+  }
+  {
+    // class term of the (rare) foreground anchors: the whole wave walks the 80 logits of each foreground
+    // lane together (coalesced row read, 2 steps) instead of one lane looping 80 times while 63 idle
+    const int lane = threadIdx.x & 63;
+    const size_t wave_ba0 = ba - lane;
+    unsigned long long m = __ballot(ba < total && fg[ba < total ? ba : 0] != 0);
+    while (m) {
+      const int src = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      const size_t fba = wave_ba0 + src;
+      const int fb = (int)(fba / d.A);
+      const float* fr = raw + raw_row(d, fb, (int)(fba - (size_t)fb * d.A)) * nch;
+      const float* lg = labels + ((size_t)fb * d.M + mgt[fba]) * 5;
       const int cg = (int)lg[0];
-      const float io = miou[ba];
-      for (int c = 0; c < d.C; ++c) s_cls += bce_logits(r[5 + c], c == cg ? io : 0.0f);
+      const float io = miou[fba];
+      float part = 0.f;
+      for (int c = lane; c < d.C; c += 64) part += bce_logits(fr[5 + c], c == cg ? io : 0.0f);
+      s_cls += part;   // every lane carries a share; the block reduction below sums them all
     }
   }
   __shared__ float red[4][4];
@@ -451,31 +510,32 @@ __global__ void k_bwd(const plyolo_yolox_desc d, const float* raw, const float* 
   const size_t total = (size_t)d.B * d.A * nch;
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
-  const size_t row = idx / nch;
-  const int c = (int)(idx - row * nch);
+  // 32-bit index arithmetic (the host checks total < 2^32): a 64-bit division costs ~100 instructions per element
+  const unsigned row = (unsigned)idx / (unsigned)nch;
+  const int c = (int)((unsigned)idx - row * (unsigned)nch);
   int l = 0;
 #pragma unroll
   for (int i = 1; i < 8; ++i)
-    if (i < d.nlevels && row >= (size_t)d.lvl_row[i]) l = i;
+    if (i < d.nlevels && row >= (unsigned)d.lvl_row[i]) l = i;
   const int hw = d.lvl_h[l] * d.lvl_w[l];
-  const int rr = (int)(row - d.lvl_row[l]);
-  const int b = rr / hw;
+  const int rr = (int)(row - (unsigned)d.lvl_row[l]);
+  const int b = (int)((unsigned)rr / (unsigned)hw);
   const int a = d.lvl_off[l] + (rr - b * hw);
   const size_t ba = (size_t)b * d.A + a;
   const float g0 = gout ? gout[0] : 1.0f;
   const float w_iou = gout ? 5.0f * g0 + gout[1] : 5.0f, w_obj = gout ? g0 + gout[2] : 1.0f, w_cls = gout ? g0 + gout[3] : 1.0f;
   const float nfg = losses[4];
   const float invN = 1.0f / (nfg > 1.0f ? nfg : 1.0f);
-  const float* r = raw + row * nch;
+  const float* r = raw + (size_t)row * nch;
   const bool f = fg[ba] != 0;
   float g = 0.f;
   if (c == 4) {
-    g = (sigmoidf_(r[4]) - (f ? 1.0f : 0.0f)) * invN * w_obj;
+    g = (sig_fast(r[4]) - (f ? 1.0f : 0.0f)) * invN * w_obj;
   } else if (f) {
     const float* lg = labels + ((size_t)b * d.M + mgt[ba]) * 5;
     if (c >= 5) {
       const float t = (c - 5 == (int)lg[0]) ? miou[ba] : 0.0f;
-      g = (sigmoidf_(r[c]) - t) * invN * w_cls;
+      g = (sig_fast(r[c]) - t) * invN * w_cls;
     } else {
       float xs, ys, st;
       anchor_geom(d, a, &xs, &ys, &st);
@@ -487,8 +547,8 @@ __global__ void k_bwd(const plyolo_yolox_desc d, const float* raw, const float* 
     }
   }
   if (BF16OUT) {
-    if (c < 5) d_regobj[row * 16 + c] = f2bf(g);
-    else d_cls[row * cls_ld + (c - 5)] = f2bf(g);
+    if (c < 5) d_regobj[(size_t)row * 16 + c] = f2bf(g);
+    else d_cls[(size_t)row * cls_ld + (c - 5)] = f2bf(g);
   } else {
     draw[idx] = g;
   }
@@ -618,6 +678,7 @@ int plyolo_yolox_loss_bwd(const plyolo_yolox_desc* dp, const float* raw, const f
   const plyolo_yolox_desc d = *dp;
   PLY_CHECK_ARG((draw_f32 != nullptr) != (d_regobj != nullptr && d_cls != nullptr), "yolox_loss_bwd: give draw_f32 OR (d_regobj, d_cls)");
   const size_t total = (size_t)d.B * d.A * (5 + d.C);
+  PLY_CHECK_ARG(total < (1ull << 32), "yolox_loss_bwd: B*A*(5+C) must be below 2^32");
   const unsigned grid = (unsigned)cdivz(total, 256);
   plyolo::annotate("yolox_loss_bwd", 0.0, (double)total * 6.0);
   return submit(stream, [=](hipStream_t s) -> hipError_t {
