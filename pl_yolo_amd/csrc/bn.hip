@@ -18,6 +18,8 @@
 //                      workgroup 0 also publishes coef (for the backward) + running statistics
 //   bn_act_bwd_reduce  per-channel  sum du, sum du*zhat  (du = dout*act'(u))  -> slots
 //   bn_act_bwd_dz      dz = A*du + B*z + Cc ; workgroup 0 publishes dgamma / dbeta
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -360,7 +362,9 @@ int plyolo_bn_act_bwd_reduce(int dtype, int M, int C, const void* dout, int d_ld
   if (check_split(dsp, C, V, "bn_act_bwd_reduce")) return -1;
   plyolo_split sp{};
   if (dsp) sp = *dsp;
-  int rows = M / 64;
+  int div = 32;   // pixel rows per workgroup (measured: 32 beats 64 on the 40x40 / 20x20 maps, equal on the large ones) (every workgroup ends with 2*C fp64 slot atomics)
+  if (const char* e = getenv("PLYOLO_BN_RED_DIV")) { const int v = atoi(e); if (v >= 1) div = v; }
+  int rows = M / div;
   if (rows < 1) rows = 1;
   if (rows > 1024) rows = 1024;
   plyolo::annotate("bn_act_bwd_reduce", 0.0, (double)M * C * (dtype == PLYOLO_BF16 ? 2.0 : 4.0) * 2.0);
