@@ -352,6 +352,9 @@ hipError_t launch_bn(const ConvP& p, int BN, int CK, int TH, hipStream_t s) {
   PLY_CASE(64, 16) PLY_CASE(64, 32) PLY_CASE(64, 64)
   if (!OUT_F32) {
     PLY_CASE(128, 16) PLY_CASE(128, 32) PLY_CASE(128, 64)
+    // whole-K chunks for Cin = 128 on the small tile: no chunk boundary (barrier + exposed halo reload) at all
+    if (BN == 128 && CK == 128 && TH == 8) return launch_inst<128, 128, 8, false>(p, s);
+    if (BN == 64 && CK == 128 && TH == 8) return launch_inst<64, 128, 8, false>(p, s);
   }
 #undef PLY_CASE
   return hipErrorInvalidValue;
@@ -368,6 +371,7 @@ void pick_tiles(const ConvP& p, int ext_y, bool out_f32, int* BN, int* CK, int* 
   // few tiles: prefer the small tile so that the launch still spreads over the CUs
   const long tiles16 = (long)p.N * ((p.OHt + 15) / 16) * ((p.OWt + TW - 1) / TW) * ((p.Cout + bn - 1) / bn);
   if (th == 16 && tiles16 < 384) th = 8;
+  if (th == 8 && p.si == 1 && p.Cin == 128 && !out_f32 && bn >= 64 && getenv("PLYOLO_NO_CK128") == nullptr) ck = 128;
   if (const char* e = getenv("PLYOLO_FORCE_CK")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) ck = v < ck ? v : ck; }
   if (const char* e = getenv("PLYOLO_FORCE_BN")) { const int v = atoi(e); if (v == 32 || v == 64 || v == 128) bn = v < bn ? v : bn; }
   if (const char* e = getenv("PLYOLO_FORCE_TH")) { const int v = atoi(e); if (v == 8 || v == 16) th = v; }
