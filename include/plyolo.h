@@ -196,6 +196,12 @@ int plyolo_bn_eval_coef_at(int C, const float* gamma, const float* beta, const f
 int plyolo_bn_act_fwd(int dtype, int M, int C, const void* z, int z_ld, float* coef, int act,
                       const void* res, int r_ld, void* out, int o_ld, const plyolo_bn_stats* st,
                       const plyolo_split* out_split, void* stream);
+/* slots += per-channel (sum, sum of squares) of an activation matrix x [M][C] (pitch x_ld): statistics of
+ * a BatchNorm applied directly to a tensor (RepConv's identity branch, yolov7_neck.py:191). */
+int plyolo_channel_stats(int dtype, int M, int C, const void* x, int x_ld, double* slots, void* stream);
+/* din (+)= dout * act'(z): backward of a bare activation layer (forward = plyolo_bn_act_fwd with coef NULL). */
+int plyolo_act_bwd(int dtype, int M, int C, const void* dout, int d_ld, const void* z, int z_ld, int act,
+                   void* din, int di_ld, int accumulate, void* stream);
 /* bslots (fp64 [PLYOLO_STAT_SLOTS][2][C], zeroed by the caller) += sum du, sum du*zhat
  * with du = dout * act'(u) */
 int plyolo_bn_act_bwd_reduce(int dtype, int M, int C, const void* dout, int d_ld, const void* z, int z_ld,

@@ -125,3 +125,17 @@ def eval_decode(maps, strides, anchors, num_classes):
     P = torch.cat(preds, 1)
     box = torch.stack([P[..., 0] - P[..., 2] / 2, P[..., 1] - P[..., 3] / 2, P[..., 0] + P[..., 2] / 2, P[..., 1] + P[..., 3] / 2], -1)
     return torch.cat([box, P[..., 4:]], -1)
+
+
+def repconv(state, prefix, x, training, act="silu"):
+    """RepConv, train-time form (models/necks/yolov7_neck.py:167-211): act(bn(conv3x3(x)) + bn(conv1x1(x))
+    [+ bn_id(x) when c1 == c2 and stride 1]).  Plain nn.BatchNorm2d defaults (eps 1e-5, momentum 0.1).
+    state keys: <prefix>.rbr_dense.{0.weight,1.*}, <prefix>.rbr_1x1.{0.weight,1.*}, <prefix>.rbr_identity.*"""
+    def bn(p, t):
+        return F.batch_norm(t, state[p + ".running_mean"], state[p + ".running_var"], state[p + ".weight"], state[p + ".bias"],
+                            training, 0.1, 1e-5)
+    out = bn(prefix + ".rbr_dense.1", F.conv2d(x, state[prefix + ".rbr_dense.0.weight"], None, 1, 1))
+    out = out + bn(prefix + ".rbr_1x1.1", F.conv2d(x, state[prefix + ".rbr_1x1.0.weight"], None, 1, 0))
+    if prefix + ".rbr_identity.weight" in state:
+        out = out + bn(prefix + ".rbr_identity", x)
+    return F.silu(out) if act == "silu" else out

@@ -128,6 +128,8 @@ SIGNATURES = {
     "plyolo_bn_eval_coef": (_i, [_i, _vp, _vp, _vp, _vp, _f, _vp, _vp]),
     "plyolo_bn_eval_coef_at": (_i, [_i, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _vp]),
     "plyolo_bn_act_fwd": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _P(BnStats), _P(Split), _vp]),
+    "plyolo_channel_stats": (_i, [_i, _i, _i, _vp, _i, _vp, _vp]),
+    "plyolo_act_bwd": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _i, _vp, _i, _i, _vp]),
     "plyolo_bn_act_bwd_reduce": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _P(Split), _vp]),
     "plyolo_bn_act_bwd_dz": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _P(Split), _P(BnBwdSplit), _vp]),
     "plyolo_focus_s2d": (_i, [_i, _vp, _i, _i, _i, _vp, _i, _vp]),

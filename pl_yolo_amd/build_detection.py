@@ -92,7 +92,7 @@ def eelan(cfg):
 
 
 def yolov7neck(cfg):
-    return YOLOv7NECK(cfg['depths'], cfg['channels'], cfg['norm'], cfg['act'])
+    return YOLOv7NECK(cfg['depths'], cfg['channels'], cfg['norm'], cfg['act'], repconv=bool(cfg.get('repconv', False)))
 
 
 def implicit_head(cfg, num_classes):

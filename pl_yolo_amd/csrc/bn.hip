@@ -275,6 +275,72 @@ __global__ __launch_bounds__(256) void bn_act_bwd_dz_kernel(int M, int C, const 
   }
 }
 
+// slots += per-channel sum / sum of squares of an activation matrix (BatchNorm applied directly to a tensor:
+// the identity branch of RepConv, yolov7_neck.py:191,204-209)
+template <typename T>
+__global__ __launch_bounds__(256) void channel_stats_kernel(int M, int C, const T* __restrict__ x, int x_ld, double* slots) {
+  constexpr int V = Vec<T>::N;
+  __shared__ float red[256 * 2 * V];
+  const int cvn = C / V;
+  const ColMap cm(cvn);
+  const int step = gridDim.x * cm.rpb;
+  double* slot = slots + (size_t)(blockIdx.x % NSLOT) * 2 * C;
+  for (int cv0 = 0; cv0 < cvn; cv0 += cm.cols) {
+    const int cv = cv0 + cm.tcol;
+    float s1[V], s2[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) s1[i] = s2[i] = 0.f;
+    if (cm.trow < cm.rpb && cv < cvn)
+      for (int m = blockIdx.x * cm.rpb + cm.trow; m < M; m += step) {
+        float f[V];
+        Vec<T>::load(x + (size_t)m * x_ld + cv * V, f);
+#pragma unroll
+        for (int i = 0; i < V; ++i) { s1[i] += f[i]; s2[i] += f[i] * f[i]; }
+      }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < V; ++i) { red[(threadIdx.x * 2 + 0) * V + i] = s1[i]; red[(threadIdx.x * 2 + 1) * V + i] = s2[i]; }
+    __syncthreads();
+    if (cm.trow == 0 && cv < cvn) {
+      for (int k = 1; k < cm.rpb; ++k)
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          s1[i] += red[((k * cm.cols + cm.tcol) * 2 + 0) * V + i];
+          s2[i] += red[((k * cm.cols + cm.tcol) * 2 + 1) * V + i];
+        }
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        slot_add(slot + cv * V + i, (double)s1[i]);
+        slot_add(slot + C + cv * V + i, (double)s2[i]);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// din (+)= dout * act'(z): backward of a bare activation (RepConv applies SiLU to a SUM of BatchNorm outputs)
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_kernel(int M, int C, const T* __restrict__ dout, int d_ld, const T* __restrict__ z, int z_ld,
+                                                      int act, T* __restrict__ din, int di_ld, int accumulate) {
+  constexpr int V = Vec<T>::N;
+  const int cvn = C / V;
+  const ColMap cm(cvn);
+  if (cm.trow >= cm.rpb) return;
+  const int step = gridDim.x * cm.rpb;
+  for (int cv = cm.tcol; cv < cvn; cv += cm.cols) {
+    const int c = cv * V;
+    for (int m = blockIdx.x * cm.rpb + cm.trow; m < M; m += step) {
+      float d[V], zz[V], o[V];
+      Vec<T>::load(dout + (size_t)m * d_ld + c, d);
+      Vec<T>::load(z + (size_t)m * z_ld + c, zz);
+      if (accumulate) Vec<T>::load(din + (size_t)m * di_ld + c, o);
+#pragma unroll
+      for (int i = 0; i < V; ++i) d[i] = d[i] * act_grad(zz[i], act) + (accumulate ? o[i] : 0.f);
+      Vec<T>::store(din + (size_t)m * di_ld + c, d);
+    }
+  }
+}
+
 // 256 CUs x 4 workgroups; every workgroup re-reads the stat slots, so keep the grid bounded
 inline int stream_grid(int M, int cvn) {
   const int cols = cvn < 256 ? cvn : 256, rpb = 256 / cols;
@@ -351,6 +417,32 @@ int plyolo_bn_act_fwd(int dtype, int M, int C, const void* z, int z_ld, float* c
         hipLaunchKernelGGL((bn_act_fwd_kernel<T, false>), dim3(grid), dim3(256), 0, s, M, C, (const T*)z, z_ld, coef, act, (const T*)res,
                            r_ld, (T*)out, o_ld, st, sp);
     })
+    return hipGetLastError();
+  });
+}
+
+int plyolo_channel_stats(int dtype, int M, int C, const void* x, int x_ld, double* slots, void* stream) {
+  const int V = dtype == PLYOLO_BF16 ? 8 : 4;
+  PLY_CHECK_ARG(C % V == 0 && x_ld % V == 0 && slots, "channel_stats: C/ld must be multiples of %d", V);
+  int rows = M / 32;
+  if (rows < 1) rows = 1;
+  if (rows > 1024) rows = 1024;
+  plyolo::annotate("channel_stats", 0.0, (double)M * C * (dtype == PLYOLO_BF16 ? 2.0 : 4.0));
+  return submit(stream, [=](hipStream_t s) -> hipError_t {
+    DISPATCH_T(dtype, hipLaunchKernelGGL(channel_stats_kernel<T>, dim3(rows), dim3(256), 0, s, M, C, (const T*)x, x_ld, slots);)
+    return hipGetLastError();
+  });
+}
+
+int plyolo_act_bwd(int dtype, int M, int C, const void* dout, int d_ld, const void* z, int z_ld, int act, void* din, int di_ld,
+                   int accumulate, void* stream) {
+  const int V = dtype == PLYOLO_BF16 ? 8 : 4;
+  PLY_CHECK_ARG(C % V == 0 && z_ld % V == 0 && d_ld % V == 0 && di_ld % V == 0, "act_bwd: C/ld must be multiples of %d", V);
+  const int grid = stream_grid(M, C / V);
+  plyolo::annotate("act_bwd", 0.0, (double)M * C * (dtype == PLYOLO_BF16 ? 2.0 : 4.0) * 3.0);
+  return submit(stream, [=](hipStream_t s) -> hipError_t {
+    DISPATCH_T(dtype, hipLaunchKernelGGL(act_bwd_kernel<T>, dim3(grid), dim3(256), 0, s, M, C, (const T*)dout, d_ld, (const T*)z, z_ld,
+                                         act, (T*)din, di_ld, accumulate);)
     return hipGetLastError();
   });
 }

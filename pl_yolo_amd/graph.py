@@ -162,7 +162,7 @@ class Graph:
         # one memset per plan zeroes a whole arena (zero_fwd_stats / zero_bwd_stats)
         off = 0
         for op in self.ops:
-            if isinstance(op, (ConvUnitOp, ConvPairOp)) and op.bn is not None:
+            if isinstance(op, (ConvUnitOp, ConvPairOp, BnOnlyOp)) and op.bn is not None:
                 op.slot_off = off
                 off += STAT_SLOTS * 2 * op.Cout
         self.stat_arena = torch.zeros(max(off, 8), dtype=torch.float64, device=dev)
@@ -610,6 +610,80 @@ class ConvPairOp:
             call("plyolo_conv2d_wgrad", C.byref(self.desc), g.aptr(self.x), dz, self.pc.dwp, None)
             self.pc.reduce_slabs()
             call("plyolo_conv2d_dgrad", C.byref(self.desc), dz, self.pc.wpd, g.gptr(self.x), acc, None)
+
+
+class ActOp:
+    """A bare activation out = act(x) (RepConv applies SiLU to a SUM of BatchNorm outputs,
+    yolov7_neck.py:211).  Forward = bn_act_fwd without coefficients; backward din (+)= dout*act'(x)."""
+
+    def __init__(self, g, x, act):
+        self.g, self.x, self.act = g, x, ACT[act]
+        self.out = g.new_act(x.N, x.H, x.W, x.C, "act")
+        g.add_op(self)
+
+    def fwd(self):
+        g, x = self.g, self.x
+        call("plyolo_bn_act_fwd", g.dtype, x.M, x.C, g.aptr(x), x.ld, None, self.act, None, 0, g.aptr(self.out), self.out.ld, None, None, None)
+
+    def bwd(self):
+        g, x = self.g, self.x
+        if not g.grad_ready(self.out):
+            return
+        acc = g.grad_mode(x)
+        call("plyolo_act_bwd", g.dtype, x.M, x.C, g.gptr(self.out), self.out.ld, g.aptr(x), x.ld, self.act, g.gptr(x), x.ld, acc, None)
+
+
+class BnOnlyOp:
+    """BatchNorm applied directly to a tensor (no convolution, no activation), optionally + residual:
+    the identity branch of RepConv (yolov7_neck.py:191,204-209)."""
+
+    def __init__(self, g, x, bn, residual=None):
+        self.g, self.x, self.bn, self.res = g, x, bn, residual
+        self.Cout = x.C
+        self.out = g.new_act(x.N, x.H, x.W, x.C, "bn")
+        g.scratch_elems = max(g.scratch_elems, x.M * x.C)
+        g.add_op(self)
+
+    def fwd(self):
+        g, x, bn = self.g, self.x, self.bn
+        if not hasattr(self, "coef"):
+            self.coef = torch.empty(4 * x.C, dtype=torch.float32, device=g.device)
+        st = None
+        if g.training:
+            slots = g.stat_arena.data_ptr() + self.slot_off * 8
+            call("plyolo_channel_stats", g.dtype, x.M, x.C, g.aptr(x), x.ld, slots, None)
+            st = BnStats()
+            st.slots, st.count = slots, float(x.M)
+            st.gamma, st.beta = ptr(bn.weight), ptr(bn.bias)
+            st.eps, st.momentum = float(bn.eps), float(bn.momentum)
+            st.running_mean, st.running_var = ptr(bn.running_mean), ptr(bn.running_var)
+            st.num_batches_tracked = ptr(bn.num_batches_tracked)
+        else:
+            call("plyolo_bn_eval_coef", x.C, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var),
+                 float(bn.eps), self.coef.data_ptr(), None)
+        call("plyolo_bn_act_fwd", g.dtype, x.M, x.C, g.aptr(x), x.ld, self.coef.data_ptr(), 0,
+             g.aptr(self.res) if self.res is not None else None, self.res.ld if self.res is not None else 0,
+             g.aptr(self.out), self.out.ld, C.byref(st) if st is not None else None, None, None)
+
+    def bwd(self):
+        g, x, bn = self.g, self.x, self.bn
+        if not g.grad_ready(self.out):
+            return
+        M, Cc = x.M, x.C
+        dout = g.gptr(self.out)
+        if self.res is not None:
+            acc = g.grad_mode(self.res)
+            call("plyolo_copy_add", g.dtype, M, Cc, dout, self.out.ld, g.gptr(self.res), self.res.ld, acc, None)
+        bslots = g.bstat_arena.data_ptr() + self.slot_off * 8
+        call("plyolo_bn_act_bwd_reduce", g.dtype, M, Cc, dout, self.out.ld, g.aptr(x), x.ld, self.coef.data_ptr(), 0, bslots, None, None)
+        plan, me = g.plan, self.lane
+        dz, key = g.dz_buffer(me)
+        if g.use_lanes and g.dz_event.get(key) is not None:
+            plan.wait(me, g.dz_event.pop(key))
+        call("plyolo_bn_act_bwd_dz", g.dtype, M, Cc, dout, self.out.ld, g.aptr(x), x.ld, self.coef.data_ptr(), bslots, ptr(bn.weight),
+             g.grad_ptr_of(bn.weight), g.grad_ptr_of(bn.bias), 0, 0, dz, Cc, None, None, None)
+        acc = g.grad_mode(x)    # here dz IS the gradient w.r.t. the normalised tensor itself
+        call("plyolo_copy_add", g.dtype, M, Cc, dz, Cc, g.gptr(x), x.ld, acc, None)
 
 
 class UpsampleOp:

@@ -81,11 +81,40 @@ class NeckTransition(HipModule):
         return g.concat([x_2, x_1])
 
 
+class RepConv(HipModule):
+    """RepConv, train-time form (reference models/necks/yolov7_neck.py:167-211):
+    act(bn(conv3x3(x)) + bn(conv1x1(x)) [+ bn(x) when c1 == c2 and s == 1]), plain nn.BatchNorm2d defaults.
+    The reference defines it next to the YOLOv7 neck but wires it into no config (n3/n4/n5 are BaseConv,
+    yolov7_neck.py:67-69); here it is an optional block (`YOLOv7NECK(..., repconv=True)`).  Same constructor
+    signature and state_dict keys (rbr_dense.0/1, rbr_1x1.0/1, rbr_identity).  The deploy-time
+    re-parameterisation (:213-348) is export tooling and not part of the hot path."""
+
+    def __init__(self, c1, c2, k=3, s=1, p=None, g=1, act=True, deploy=False):
+        super().__init__()
+        if k != 3 or (p is not None and p != 1):
+            raise AssertionError("RepConv: k == 3 and padding 1 (yolov7_neck.py:180-181)")
+        if deploy or g != 1 or s != 1 or act is not True:
+            raise NotImplementedError("RepConv: only the train-time form with stride 1, groups 1 and SiLU has HIP kernels")
+        self.in_channels, self.out_channels, self.groups, self.deploy = c1, c2, g, deploy
+        self.act = nn.SiLU()
+        self.rbr_identity = nn.BatchNorm2d(num_features=c1) if c2 == c1 and s == 1 else None
+        self.rbr_dense = nn.Sequential(nn.Conv2d(c1, c2, 3, s, 1, groups=g, bias=False), nn.BatchNorm2d(num_features=c2))
+        self.rbr_1x1 = nn.Sequential(nn.Conv2d(c1, c2, 1, s, 0, groups=g, bias=False), nn.BatchNorm2d(num_features=c2))
+
+    def emit(self, g, x):
+        # three BatchNorm branches accumulated through the residual input of the BN-apply kernel, then SiLU
+        t = G.ConvUnitOp(g, x, self.rbr_dense[0].weight, self.rbr_dense[1], None, 1).out
+        t = G.ConvUnitOp(g, x, self.rbr_1x1[0].weight, self.rbr_1x1[1], None, 1, residual=t).out
+        if self.rbr_identity is not None:
+            t = G.BnOnlyOp(g, x, self.rbr_identity, residual=t).out
+        return G.ActOp(g, t, "silu").out
+
+
 class YOLOv7NECK(HipModule):
     """models/necks/yolov7_neck.py:7-101.  (RepConv, :167-348, is defined upstream but never
     instantiated by any config -- n3/n4/n5 are plain BaseConv, :67-69.)"""
 
-    def __init__(self, depths=(1, 1, 1, 1), in_channels=(512, 1024, 1024), norm="bn", act="silu"):
+    def __init__(self, depths=(1, 1, 1, 1), in_channels=(512, 1024, 1024), norm="bn", act="silu", repconv=False):
         super().__init__()
         from .layers import SPPCSPC
         c = in_channels
@@ -101,9 +130,14 @@ class YOLOv7NECK(HipModule):
         self.n3_n4 = ELANWLayer(c[2] // 2, c[2] // 4, expansion=0.5, num_bottle=depths[0], norm=norm, act=act)
         self.downsample_conv2 = NeckTransition(c[2] // 4, c[2] // 2, mpk=2, norm=norm, act=act)
         self.n4_n5 = ELANWLayer(c[2], c[2] // 2, expansion=0.5, num_bottle=depths[0], norm=norm, act=act)
-        self.n3 = BaseConv(c[2] // 8, c[2] // 4, 3, 1, norm=norm, act=act)
-        self.n4 = BaseConv(c[2] // 4, c[2] // 2, 3, 1, norm=norm, act=act)
-        self.n5 = BaseConv(c[2] // 2, c[2], 3, 1, norm=norm, act=act)
+        if repconv:   # BASELINE cfg 3 names "ELAN backbone + RepConv": optional, the reference itself uses BaseConv here
+            self.n3 = RepConv(c[2] // 8, c[2] // 4, 3, 1)
+            self.n4 = RepConv(c[2] // 4, c[2] // 2, 3, 1)
+            self.n5 = RepConv(c[2] // 2, c[2], 3, 1)
+        else:
+            self.n3 = BaseConv(c[2] // 8, c[2] // 4, 3, 1, norm=norm, act=act)
+            self.n4 = BaseConv(c[2] // 4, c[2] // 2, 3, 1, norm=norm, act=act)
+            self.n5 = BaseConv(c[2] // 2, c[2], 3, 1, norm=norm, act=act)
 
     def emit(self, g, inputs):
         c3, c4, c5 = inputs

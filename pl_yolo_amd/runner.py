@@ -180,7 +180,7 @@ class DetectorRunner:
                     op.post_unpack()
             seen = set()
             for op in g.ops:
-                bns = [op.bn] if isinstance(op, G.ConvUnitOp) else ([op.bn_a, op.bn_b] if isinstance(op, G.ConvPairOp) else [])
+                bns = [op.bn] if isinstance(op, (G.ConvUnitOp, G.BnOnlyOp)) else ([op.bn_a, op.bn_b] if isinstance(op, G.ConvPairOp) else [])
                 for bn in bns:
                     if bn is None:
                         continue

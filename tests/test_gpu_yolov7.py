@@ -162,3 +162,91 @@ def test_v7_loss_kernels_vs_reference(case):
     err = np.abs(draw.cpu().numpy() - dref).max() / max(1e-12, np.abs(dref).max())
     print("   d loss / d raw: max rel err %.3g" % err)
     assert err <= 2e-5
+
+
+# ---- RepConv (row a13): the train-time block through the launch plans vs the reference class -----------
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("tag", ["ne", "id"])
+def test_repconv_block_vs_reference(tag, dtype):
+    from pl_yolo_amd import graph as G
+    from pl_yolo_amd.necks import RepConv
+    from pl_yolo_amd._lib import BF16, F32, call
+    g = load_golden("repconv_blocks")
+    sd = {k[len(tag) + 7:]: torch.from_numpy(v.copy()) for k, v in g.items() if k.startswith(tag + "/state/")}
+    c1, c2 = g[tag + "/x"].shape[1], g[tag + "/y"].shape[1]
+    m = RepConv(c1, c2, 3, 1)
+    assert set(sd) == set(m.state_dict())
+    m.load_state_dict(sd)
+    m = m.to(hu.DEV).train()
+    dt = BF16 if dtype == "bf16" else F32
+    x = torch.from_numpy(g[tag + "/x"]).to(hu.DEV)
+    r = torch.from_numpy(g[tag + "/r"]).to(hu.DEV)
+    N, _, H, W = x.shape
+    gr = G.Graph(dt, True, torch.device(hu.DEV))
+    gr.use_lanes = False
+    grads = {id(p): torch.zeros_like(p) for p in m.parameters()}
+    gr.grad_ptr_of = lambda p: grads[id(p)].data_ptr() if p is not None and id(p) in grads else None
+    xin = gr.new_act(N, H, W, c1, "x")
+    out = m.emit(gr, xin)
+    gr.allocate()
+    gr.build_pack_table(gr.grad_ptr_of)
+    xin.storage.tensor.view(-1, xin.ld)[:, :c1] = x.permute(0, 2, 3, 1).reshape(-1, c1).to(gr.tdtype)
+    fwd, bwd = G.Plan(), G.Plan()
+    with fwd:
+        gr.plan = fwd
+        call("plyolo_pack_weights", gr.pack_table.data_ptr(), gr.n_pack, gr.dtype, gr.max_pack_elems, None)
+        gr.zero_fwd_stats()
+        G.record_ops(gr, fwd, gr.ops, "fwd")
+    fwd.run(hu.stream())
+    y = out.storage.tensor.view(-1, out.ld)[:, out.c_off:out.c_off + c2].float().reshape(N, H, W, c2).permute(0, 3, 1, 2)
+    tol = 2e-2 if dtype == "bf16" else 2e-5
+    assert hu.relerr(y, torch.from_numpy(g[tag + "/y"]).to(hu.DEV)) <= tol
+    # backward: seed d(out) = r
+    gout = gr.grad_storage(out.storage)
+    gout.view(-1, out.ld)[:, out.c_off:out.c_off + c2] = r.permute(0, 2, 3, 1).reshape(-1, c2).to(gr.tdtype)
+    for i in range(out.c_off, out.c_off + c2):
+        out.storage.ginit[i] = True
+    with bwd:
+        gr.plan = bwd
+        if dt != BF16:
+            call("plyolo_memset_async", gr.dwp_arena.data_ptr(), 0, gr.dwp_arena.numel() * 4, None)
+        gr.zero_bwd_stats()
+        G.record_ops(gr, bwd, list(reversed(gr.ops)), "bwd")
+        call("plyolo_unpack_wgrads", gr.pack_table.data_ptr(), gr.n_pack, gr.max_pack_elems, 0, None)
+    bwd.run(hu.stream())
+    torch.cuda.synchronize()
+    dx = gr.grad_storage(xin.storage).view(-1, xin.ld)[:, :c1].float().reshape(N, H, W, c1).permute(0, 3, 1, 2)
+    e = hu.relerr(dx, torch.from_numpy(g[tag + "/dx"]).to(hu.DEV))
+    print("repconv", tag, dtype, "dx relerr %.3g" % e)
+    assert e <= (5e-2 if dtype == "bf16" else 2e-4)
+    for n, p in m.named_parameters():
+        ref = torch.from_numpy(g["%s/grad/%s" % (tag, n)]).to(hu.DEV)
+        e = hu.relerr(grads[id(p)], ref)
+        assert e <= (6e-2 if dtype == "bf16" else 5e-4), (n, e)
+    sd2 = m.state_dict()
+    for k, v in g.items():
+        if k.startswith(tag + "/state_after/") and "running" in k:
+            np.testing.assert_allclose(sd2[k[len(tag) + 13:]].cpu().numpy(), v, rtol=2e-2 if dtype == "bf16" else 1e-4, atol=1e-3 if dtype == "bf16" else 1e-5, err_msg=k)
+
+
+def test_v7_with_repconv_neck_trains():
+    """`neck.repconv: true` (BASELINE cfg 3 wording; the reference wires BaseConv there): the whole detector
+    steps with the RepConv n3/n4/n5 blocks -- finite loss, every parameter receives a finite gradient."""
+    with open(os.path.join(ROOT, "configs", "model", "yolov7", "yolov7_test.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    cfg["neck"]["repconv"] = True
+    torch.manual_seed(3)
+    model = pl_yolo_amd.build_model(cfg, 3)
+    assert any("rbr_dense" in k for k in model.state_dict())
+    model.compute_dtype = "bf16"
+    model = model.to(hu.DEV).train()
+    x = (torch.rand(2, 3, 128, 128, generator=torch.Generator().manual_seed(2)) * 255).to(hu.DEV)
+    labels = torch.zeros(2, 6, 5)
+    labels[0, :2] = torch.tensor([[1, 40.0, 50.0, 30.0, 36.0], [0, 90.0, 70.0, 50.0, 44.0]])
+    labels[1, :1] = torch.tensor([[2, 64.0, 64.0, 80.0, 60.0]])
+    out = model(x, labels.to(hu.DEV))
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(out["loss"]).all()
+    for n, p in model.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), n

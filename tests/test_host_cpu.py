@@ -100,3 +100,14 @@ def test_lr_schedule_matches_reference_vectors():
         warm, T = float(g["sched%d_warm" % i]), int(g["sched%d_T" % i])
         for t in (0, 1, int(warm), int(warm) + 1, T // 2, T):
             assert abs(trainer.lr_factor(t, warm, T) - float(g["sched%d_factor" % i][t])) < 1e-12
+
+
+def test_repconv_module_keys_match_reference_fixture():
+    """RepConv (row a13) keeps the reference's sub-module names, so its checkpoints load unchanged."""
+    from conftest import load_golden
+    from pl_yolo_amd.necks import RepConv
+    g = load_golden("repconv_blocks")
+    for tag, c1, c2 in (("ne", 16, 32), ("id", 24, 24)):
+        want = {k[len(tag) + 7:]: v.shape for k, v in g.items() if k.startswith(tag + "/state/")}
+        got = {k: tuple(v.shape) for k, v in RepConv(c1, c2, 3, 1).state_dict().items()}
+        assert got == {k: tuple(v) for k, v in want.items()}

@@ -101,3 +101,21 @@ def test_v7_network_training_loss_and_grads():
             continue
         ref = g["lossgrad/" + k]
         assert float(np.abs(state[k].grad.numpy() - ref).max()) <= 5e-4 * max(1e-3, float(np.abs(ref).max())), k
+
+
+@pytest.mark.parametrize("tag", ["ne", "id"])
+def test_repconv_oracle_vs_reference(tag):
+    """RepConv train-time form (row a13) vs the reference class: output, input gradient, parameter gradients."""
+    g = load_golden("repconv_blocks")
+    state = {k[len(tag) + 7:]: torch.from_numpy(v.copy()) for k, v in g.items() if k.startswith(tag + "/state/")}
+    state = {"m." + k: v for k, v in state.items()}
+    names = [k for k in state if k.endswith(".weight") or k.endswith(".bias")]
+    for k in names:
+        state[k].requires_grad_(True)
+    x = torch.from_numpy(g[tag + "/x"]).requires_grad_(True)
+    y = net_v7.repconv(state, "m", x, True)
+    np.testing.assert_allclose(y.detach().numpy(), g[tag + "/y"], rtol=1e-5, atol=1e-5)
+    (y * torch.from_numpy(g[tag + "/r"])).sum().backward()
+    np.testing.assert_allclose(x.grad.numpy(), g[tag + "/dx"], rtol=1e-4, atol=1e-5)
+    for k in names:
+        np.testing.assert_allclose(state[k].grad.numpy(), g["%s/grad/%s" % (tag, k[2:])], rtol=2e-4, atol=2e-5, err_msg=k)

@@ -436,11 +436,44 @@ def gen_v7loss_cases():
     _v7_case("v7loss_case_D", 2, 3, 128, 192, lab, 14, scale=3.0)
 
 
+def gen_repconv():
+    """RepConv blocks (train-time form) straight from the reference class: with and without the identity branch."""
+    from models.necks.yolov7_neck import RepConv
+    d = {}
+    gen = torch.Generator().manual_seed(77)
+    for tag, c1, c2 in (("ne", 16, 32), ("id", 24, 24)):
+        torch.manual_seed(5)
+        m = RepConv(c1, c2, 3, 1)
+        for n, p in m.named_parameters():
+            if n.endswith("1.weight") or n == "rbr_identity.weight":
+                p.data = 0.5 + torch.rand(p.shape, generator=gen)
+            if n.endswith("1.bias") or n == "rbr_identity.bias":
+                p.data = torch.rand(p.shape, generator=gen) - 0.5
+        x = torch.randn(2, c1, 12, 10, generator=gen).requires_grad_(True)
+        for k, v in m.state_dict().items():
+            d["%s/state/%s" % (tag, k)] = v.clone()
+        m.train()
+        y = m(x)
+        r = torch.randn(y.shape, generator=gen)
+        (y * r).sum().backward()
+        d["%s/x" % tag], d["%s/y" % tag], d["%s/r" % tag], d["%s/dx" % tag] = x.detach(), y.detach(), r, x.grad
+        for n, p in m.named_parameters():
+            d["%s/grad/%s" % (tag, n)] = p.grad.clone()
+        for k, v in m.state_dict().items():
+            if "running" in k or "num_batches" in k:
+                d["%s/state_after/%s" % (tag, k)] = v.clone()
+    save("repconv_blocks", d)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "repconv":
+        gen_repconv()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "v7loss":
         gen_v7loss_cases()
         sys.exit(0)
     gen_v7loss_cases()
+    gen_repconv()
     gen_network_v7()
     gen_loss_cases()
     gen_blocks()
