@@ -75,8 +75,16 @@ DEVINL u32x4 add_bf16x8(u32x4 a, u32x4 b) {
 //     fragment order, so a wave's B fragment is ONE coalesced 1-KiB global load (L2/L1 resident),
 //     prefetched one tap ahead in registers.  No per-tap barrier: waves only meet when the halo
 //     tile is replaced, so MFMA, LDS reads and the loads of the co-resident workgroup overlap.
-template <int BN, int CK, int TH, bool OUT_F32, int ABL = 0>
-__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvP p) {
+// up to four independent convolutions of one tile configuration in ONE launch (the four parity classes of a
+// stride-2 data gradient): job j owns workgroups [start[j], start[j+1])
+struct ConvJobs {
+  ConvP c[4];
+  int n;
+  int start[5];
+};
+
+template <int BN, int CK, int TH, bool OUT_F32, int ABL>
+DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
   constexpr int BM = TH * TW;
   constexpr int WN = BN / 32, WM = 4 / WN, MT = BM / (32 * WM);
   constexpr int ROWB = CK * 2 + 16;  // LDS row pitch in bytes (pad: 16 B)
@@ -92,7 +100,6 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvP p) {
   // L2, give each such group a contiguous run of tiles so halo re-reads hit L2.
   int tile;
   {
-    const int nwg = gridDim.x, bid = blockIdx.x;
     const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
     tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
   }
@@ -301,6 +308,19 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvP p) {
   }
 }
 
+template <int BN, int CK, int TH, bool OUT_F32, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvP p) {
+  conv_mfma_body<BN, CK, TH, OUT_F32, ABL>(p, (int)blockIdx.x, (int)gridDim.x);
+}
+
+template <int BN, int CK, int TH>
+__global__ __launch_bounds__(256, 2) void conv_mfma_jobs_kernel(const ConvJobs jobs) {
+  int j = 0;
+  for (int k = 1; k < 4; ++k)
+    if (k < jobs.n && (int)blockIdx.x >= jobs.start[k]) j = k;
+  conv_mfma_body<BN, CK, TH, false, 0>(jobs.c[j], (int)blockIdx.x - jobs.start[j], jobs.start[j + 1] - jobs.start[j]);
+}
+
 template <int BN, int CK, int TH, bool OUT_F32>
 hipError_t launch_inst(ConvP p, hipStream_t s) {
   constexpr int BM = TH * TW, WN = BN / 32, WM = 4 / WN;
@@ -360,6 +380,47 @@ hipError_t launch_bn(const ConvP& p, int BN, int CK, int TH, hipStream_t s) {
   return hipErrorInvalidValue;
 }
 
+template <int BN, int CK, int TH>
+hipError_t launch_jobs_inst(ConvJobs jobs, hipStream_t s) {
+  constexpr int BM = TH * TW, WN = BN / 32, WM = 4 / WN;
+  constexpr int ROWB = CK * 2 + 16, SROW = BN * 2 + 16;
+  size_t lds = (size_t)BM * SROW + WM * 2 * BN * 4;
+  int total = 0, ny = 1;
+  for (int j = 0; j < jobs.n; ++j) {
+    ConvP& p = jobs.c[j];
+    p.rowp = p.ITW * ROWB;
+    if (p.si == 1) p.rowp = (p.rowp + 255) & ~255;
+    const size_t m = (size_t)p.ITH * p.rowp;
+    lds = m > lds ? m : lds;
+    jobs.start[j] = total;
+    total += p.nmb;
+    ny = (p.Cout + BN - 1) / BN;
+  }
+  jobs.start[jobs.n] = total;
+  auto kern = conv_mfma_jobs_kernel<BN, CK, TH>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kern, dim3(total, ny), dim3(256), lds, s, jobs);
+  return hipGetLastError();
+}
+
+hipError_t launch_jobs(const ConvJobs& jobs, int BN, int CK, int TH, hipStream_t s) {
+#define PLY_JCASE(bn, ck)                                                \
+  if (BN == bn && CK == ck) {                                            \
+    if (TH == 16) return launch_jobs_inst<bn, ck, 16>(jobs, s);          \
+    return launch_jobs_inst<bn, ck, 8>(jobs, s);                         \
+  }
+  PLY_JCASE(32, 16) PLY_JCASE(32, 32) PLY_JCASE(32, 64)
+  PLY_JCASE(64, 16) PLY_JCASE(64, 32) PLY_JCASE(64, 64)
+  PLY_JCASE(128, 16) PLY_JCASE(128, 32) PLY_JCASE(128, 64)
+  if (BN == 128 && CK == 128 && TH == 8) return launch_jobs_inst<128, 128, 8>(jobs, s);
+  if (BN == 64 && CK == 128 && TH == 8) return launch_jobs_inst<64, 128, 8>(jobs, s);
+#undef PLY_JCASE
+  return hipErrorInvalidValue;
+}
+
 // tile choice: BN output channels x CK-channel chunks x TH output rows (x 16 columns)
 void pick_tiles(const ConvP& p, int ext_y, bool out_f32, int* BN, int* CK, int* TH) {
   int bn = p.Cout > 64 ? 128 : (p.Cout > 32 ? 64 : 32);
@@ -391,15 +452,19 @@ void set_taps(ConvP& p) {
 }
 
 // choose the tiles, then derive the grid; ext = halo extent beyond (T-1)*si (per axis)
+void apply_tiles(ConvP& p, int ext_y, int ext_x, int TH) {
+  p.ITH = (TH - 1) * p.si + ext_y;
+  p.ITW = (TW - 1) * p.si + ext_x;
+  p.tiles_y = (p.OHt + TH - 1) / TH;
+  p.tiles_x = (p.OWt + TW - 1) / TW;
+  p.nmb = p.N * p.tiles_y * p.tiles_x;
+}
+
 void finish(ConvP& p, int ext_y, int ext_x, bool out_f32, int* BN, int* CK, int* TH) {
   set_taps(p);
   if (const char* e = getenv("PLYOLO_ABLATE")) p.ablate = atoi(e);
   pick_tiles(p, ext_y, out_f32, BN, CK, TH);
-  p.ITH = (*TH - 1) * p.si + ext_y;
-  p.ITW = (TW - 1) * p.si + ext_x;
-  p.tiles_y = (p.OHt + *TH - 1) / *TH;
-  p.tiles_x = (p.OWt + TW - 1) / TW;
-  p.nmb = p.N * p.tiles_y * p.tiles_x;
+  apply_tiles(p, ext_y, ext_x, *TH);
 }
 
 void setup_fwd(const plyolo_conv_desc* d, ConvP& p, int* BN, int* CK, int* TH) {
@@ -509,9 +574,12 @@ int conv_mfma_dgrad(const plyolo_conv_desc* d, const void* dy, const void* wpd, 
     }
     return submit(stream, [=](hipStream_t s) { return launch_bn<false>(p, BN, CK, TH, s); });
   }
-  // stride 2 (ksize 3 pad 1, or ksize 1): one launch per output parity class
-  for (int py = 0; py < 2 && rc == 0; ++py)
-    for (int px = 0; px < 2 && rc == 0; ++px) {
+  // stride 2 (ksize 3 pad 1, or ksize 1): one job per output parity class (1/2/2/4 taps), all four in ONE launch
+  ConvJobs jobs{};
+  int jBN = 0, jCK = 0, jTH = 0, ext[4][2] = {};
+  double fl = 0.0, by = 0.0;
+  for (int py = 0; py < 2; ++py)
+    for (int px = 0; px < 2; ++px) {
       ConvP p = b;
       p.OHt = (d->H - py + 1) / 2; p.OWt = (d->W - px + 1) / 2;
       if (p.OHt <= 0 || p.OWt <= 0) continue;
@@ -536,18 +604,25 @@ int conv_mfma_dgrad(const plyolo_conv_desc* d, const void* dy, const void* wpd, 
           p.tap_w[p.ntaps] = (signed char)(ky[i] * d->ksize + kx[j]);
           ++p.ntaps;
         }
-      finish(p, maxy - miny + 1, maxx - minx + 1, false, &BN, &CK, &TH);
-      {
-        char lab[64];
-        snprintf(lab, sizeof(lab), "conv_mfma_dgrad_s2<BN%d,CK%d,TH%d>", BN, CK, TH);
-        const double Mo = (double)d->N * OH * OW, Mi = (double)d->N * d->H * d->W;
-        // one quarter of the layer's algorithmic work per parity-class launch
-        annotate(lab, 0.25 * 2.0 * Mo * d->Cout * d->Cin * d->ksize * d->ksize, 0.25 * (Mo * Kc + Mi * d->Cin * (accumulate ? 2.0 : 1.0)) * 2.0);
-      }
-      const int bn = BN, ck = CK, th = TH;
-      rc = submit(stream, [=](hipStream_t s) { return launch_bn<false>(p, bn, ck, th, s); });
+      int bn_, ck_, th_;
+      finish(p, maxy - miny + 1, maxx - minx + 1, false, &bn_, &ck_, &th_);
+      if (jobs.n == 0) { jBN = bn_; jCK = ck_; jTH = th_; }
+      jTH = th_ < jTH ? th_ : jTH;   // the classes share one tile configuration (BN / CK agree by construction)
+      ext[jobs.n][0] = maxy - miny + 1; ext[jobs.n][1] = maxx - minx + 1;
+      jobs.c[jobs.n++] = p;
+      const double Mo = (double)d->N * OH * OW, Mi = (double)d->N * d->H * d->W;
+      fl += 0.25 * 2.0 * Mo * d->Cout * d->Cin * d->ksize * d->ksize;
+      by += 0.25 * (Mo * Kc + Mi * d->Cin * (accumulate ? 2.0 : 1.0)) * 2.0;
     }
-  return rc;
+  if (jobs.n == 0) return 0;
+  for (int j = 0; j < jobs.n; ++j) apply_tiles(jobs.c[j], ext[j][0], ext[j][1], jTH);
+  {
+    char lab[64];
+    snprintf(lab, sizeof(lab), "conv_mfma_dgrad_s2<BN%d,CK%d,TH%d>x%d", jBN, jCK, jTH, jobs.n);
+    annotate(lab, fl, by);
+  }
+  const int bn = jBN, ck = jCK, th = jTH;
+  return submit(stream, [=](hipStream_t s) { return launch_jobs(jobs, bn, ck, th, s); });
 }
 
 }  // namespace plyolo
