@@ -215,7 +215,7 @@ hipError_t launch_wg(const WgP& p, int S, hipStream_t s) {
 
 namespace plyolo {
 
-struct WgPlan { WgP p; int id, S, WK, CO_T, CI_T; };
+struct WgPlan { WgP p; int id, S, WK, CO_T, CI_T, th; };
 
 static WgPlan plan_wgrad(const plyolo_conv_desc* d) {
   const int pad = (d->ksize - 1) / 2;
@@ -251,6 +251,10 @@ static WgPlan plan_wgrad(const plyolo_conv_desc* d) {
     if (true_cout >= 128 && d->Cin >= 128 && d->stride == 1) { w.id = 5; w.CO_T = 128; w.CI_T = 128; th = 4; }
     else { w.id = 4; w.CO_T = 64; w.CI_T = 64; }
   }
+  // small-channel stride-1 3x3 layers (huge pixel counts, tiny per-pixel rows): 16-row tiles halve the
+  // per-tile barriers and prefetch hand-offs per pixel
+  if ((w.id == 2 || w.id == 3) && d->stride == 1 && getenv("PLYOLO_WG_TH8") == nullptr) th = 16;
+  w.th = th;
   p.ITH = (th - 1) * p.si + d->ksize;
   p.ITW = (TW - 1) * p.si + d->ksize;
   p.tiles_y = (p.OH + th - 1) / th;
@@ -288,6 +292,7 @@ int conv_mfma_wgrad(const plyolo_conv_desc* d, const void* x, const void* dy, fl
   p.dy = (const bf16_t*)dy;
   p.dw = dwp;
   const int id = w.id, S = w.S, ks = d->ksize;
+  const bool th16 = w.th == 16;
   {
     char lab[64];
     snprintf(lab, sizeof(lab), "conv_wgrad<%dx%d,k%d>", w.CO_T, w.CI_T, ks);
@@ -299,8 +304,8 @@ int conv_mfma_wgrad(const plyolo_conv_desc* d, const void* x, const void* dy, fl
     switch (id) {
       case 0: return launch_wg<64, 64, 3, 1, 1, 1, 8, 1>(p, S, s);
       case 1: return s2 ? launch_wg<128, 32, 3, 1, 1, 1, 8, 2>(p, S, s) : launch_wg<128, 32, 3, 1, 1, 1, 8, 1>(p, S, s);
-      case 2: return s2 ? launch_wg<64, 32, 3, 2, 1, 1, 8, 2>(p, S, s) : launch_wg<64, 32, 3, 2, 1, 1, 8, 1>(p, S, s);
-      case 3: return s2 ? launch_wg<32, 32, 3, 4, 1, 1, 8, 2>(p, S, s) : launch_wg<32, 32, 3, 4, 1, 1, 8, 1>(p, S, s);
+      case 2: return s2 ? launch_wg<64, 32, 3, 2, 1, 1, 8, 2>(p, S, s) : (th16 ? launch_wg<64, 32, 3, 2, 1, 1, 16, 1>(p, S, s) : launch_wg<64, 32, 3, 2, 1, 1, 8, 1>(p, S, s));
+      case 3: return s2 ? launch_wg<32, 32, 3, 4, 1, 1, 8, 2>(p, S, s) : (th16 ? launch_wg<32, 32, 3, 4, 1, 1, 16, 1>(p, S, s) : launch_wg<32, 32, 3, 4, 1, 1, 8, 1>(p, S, s));
       case 4: return s2 ? launch_wg<64, 64, 1, 1, 1, 1, 8, 2>(p, S, s) : launch_wg<64, 64, 1, 1, 1, 1, 8, 1>(p, S, s);
       default: return launch_wg<128, 128, 1, 1, 2, 2, 4, 1>(p, S, s);
     }
