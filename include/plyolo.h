@@ -99,6 +99,11 @@ typedef struct plyolo_conv_desc {
  * fused epilogue). */
 int plyolo_conv2d_fwd(const plyolo_conv_desc* d, const void* x, const void* wp, const float* bias,
                       void* y, double* stats, void* stream);
+/* Inference-mode BaseConv in ONE launch (bf16 path): y = act(conv(x) * coef[0:Cout] + coef[Cout:2*Cout]) with
+ * coef from plyolo_bn_eval_coef -- BatchNorm and the activation are applied to the accumulators in the
+ * epilogue, the raw convolution output is never written. */
+int plyolo_conv2d_fwd_bn_act(const plyolo_conv_desc* d, const void* x, const void* wp, const float* coef, int act,
+                             const void* res, int r_ld, void* y, void* stream);   /* res: + residual after act, or NULL */
 /* dx = conv_transpose(dy, w).  wpd: packed dgrad weights.  accumulate!=0: dx += */
 int plyolo_conv2d_dgrad(const plyolo_conv_desc* d, const void* dy, const void* wpd, void* dx,
                         int accumulate, void* stream);

@@ -36,7 +36,7 @@ void take_annotation(PlanOp* op) {
   g_ann_flops = g_ann_bytes = 0.0;
 }
 
-int conv_mfma_fwd(const plyolo_conv_desc*, const void*, const void*, const float*, void*, double*, void*);
+int conv_mfma_fwd(const plyolo_conv_desc*, const void*, const void*, const float*, void*, double*, const float*, int, const void*, int, void*);
 void conv_mfma_pack_elems(int Cout_total, int Cin_p, int ksize, size_t* wp, size_t* wpd);
 int conv_mfma_dgrad(const plyolo_conv_desc*, const void*, const void*, void*, int, void*);
 int conv_mfma_wgrad(const plyolo_conv_desc*, const void*, const void*, float*, void*);
@@ -261,8 +261,16 @@ int plyolo_plan_graph_launch(plyolo_plan* p, void* stream) {
 
 int plyolo_conv2d_fwd(const plyolo_conv_desc* d, const void* x, const void* wp, const float* bias, void* y, double* stats, void* stream) {
   if (check_conv(d, "conv2d_fwd", true)) return -1;
-  return d->dtype == PLYOLO_BF16 ? conv_mfma_fwd(d, x, wp, bias, y, stats, stream) : conv_ref_fwd(d, x, wp, bias, y, stats, stream);
+  return d->dtype == PLYOLO_BF16 ? conv_mfma_fwd(d, x, wp, bias, y, stats, nullptr, 0, nullptr, 0, stream) : conv_ref_fwd(d, x, wp, bias, y, stats, stream);
 }
+int plyolo_conv2d_fwd_bn_act(const plyolo_conv_desc* d, const void* x, const void* wp, const float* coef, int act,
+                             const void* res, int r_ld, void* y, void* stream) {
+  if (check_conv(d, "conv2d_fwd_bn_act", true)) return -1;
+  PLY_CHECK_ARG(d->dtype == PLYOLO_BF16 && !d->y_f32 && coef != nullptr, "conv2d_fwd_bn_act: bf16 activations and a coefficient vector required");
+  PLY_CHECK_ARG(!res || r_ld % 8 == 0, "conv2d_fwd_bn_act: residual pitch must be a multiple of 8");
+  return conv_mfma_fwd(d, x, wp, nullptr, y, nullptr, coef, act, res, r_ld, stream);
+}
+
 int plyolo_pack_elems(int dtype, int Cout_total, int Cin_p, int ksize, size_t* wp_elems, size_t* wpd_elems) {
   PLY_CHECK_ARG(wp_elems && wpd_elems && Cout_total > 0 && Cin_p > 0 && (ksize == 1 || ksize == 3), "pack_elems: bad arguments");
   if (dtype == PLYOLO_BF16) {

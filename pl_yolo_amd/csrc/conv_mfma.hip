@@ -30,6 +30,10 @@ struct ConvP {
   const bf16_t* w;   // fragment-native packed weights (see frag_index)
   void* y;
   const float* bias;
+  const float* ep_coef;  // inference: fused BatchNorm (scale[Cout], shift[Cout]) + activation in the epilogue, or NULL
+  int ep_act;
+  const bf16_t* ep_res;  // fused epilogue only: residual added after the activation (Bottleneck shortcut), or NULL
+  int ep_res_ld;
   double* stats;  // fp64 stat slots [PLYOLO_STAT_SLOTS][2][Cout] or NULL
   int N, H, W, Cin, Cout, x_ld, y_ld;
   int OHt, OWt;  // extent of the output position grid handled by this launch
@@ -239,6 +243,14 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
       red[(wm * 2 + 1) * BN + wn * 32 + r] = s2;
     }
   }
+  // inference-mode BaseConv: BatchNorm is a fixed per-channel affine, so BN + activation are applied to the
+  // accumulators here and the activated tensor is the ONLY thing written (no z, no bn_act launch)
+  const bool fused = !OUT_F32 && p.ep_coef != nullptr;
+  float ep_sc = 1.f, ep_sh = 0.f;
+  if (fused) {
+    const int co = cout0 + wn * 32 + r;
+    if (co < p.Cout) { ep_sc = p.ep_coef[co]; ep_sh = p.ep_coef[p.Cout + co]; }
+  }
   if (!(abl & 256))
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -249,7 +261,7 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
       if (OUT_F32)
         *(float*)(smem + m * SROW + col * 4) = acc[mt][i];
       else
-        *(bf16_t*)(smem + m * SROW + col * 2) = f2bf(acc[mt][i]);
+        *(bf16_t*)(smem + m * SROW + col * 2) = f2bf(fused ? act_fwd(fmaf(acc[mt][i], ep_sc, ep_sh), p.ep_act) : acc[mt][i]);
     }
   __syncthreads();
 
@@ -300,7 +312,9 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
       if (a < p.OHt && b < p.OWt && co < p.Cout) {
         const int oy = a * p.so + p.oy_off, ox = b * p.so + p.ox_off;
         u32x4 val = *(const u32x4*)(smem + m * SROW + v * 16);
-        bf16_t* dst = y + ((size_t)(n * p.OHf + oy) * p.OWf + ox) * p.y_ld + co;
+        const size_t pix = (size_t)(n * p.OHf + oy) * p.OWf + ox;
+        bf16_t* dst = y + pix * p.y_ld + co;
+        if (p.ep_res) val = add_bf16x8(*(const u32x4*)(p.ep_res + pix * p.ep_res_ld + co), val);
         if (p.accumulate) val = add_bf16x8(*(const u32x4*)dst, val);
         *(u32x4*)dst = val;
       }
@@ -508,13 +522,17 @@ void conv_mfma_pack_elems(int Cout_total, int Cin_p, int ksize, size_t* wp, size
 }
 
 int conv_mfma_fwd(const plyolo_conv_desc* d, const void* x, const void* wp, const float* bias, void* y,
-                  double* stats, void* stream) {
+                  double* stats, const float* ep_coef, int ep_act, const void* ep_res, int ep_res_ld, void* stream) {
   ConvP p{};
   p.x = (const bf16_t*)x;
   p.w = (const bf16_t*)wp;
   p.y = y;
   p.bias = bias;
   p.stats = stats;
+  p.ep_coef = ep_coef;
+  p.ep_act = ep_act;
+  p.ep_res = (const bf16_t*)ep_res;
+  p.ep_res_ld = ep_res_ld;
   int BN, CK, TH;
   setup_fwd(d, p, &BN, &CK, &TH);
   const bool f32 = d->y_f32 != 0;

@@ -88,7 +88,10 @@ class Graph:
         # weight gradients on their own lane (PLYOLO_LANES=0 keeps every launch on lane 0)
         self.use_lanes = os.environ.get("PLYOLO_LANES", "1") != "0"
         self.reduce_slabs = os.environ.get("PLYOLO_REDUCE_SLABS", "1") == "1"
-        self.pair_convs = os.environ.get("PLYOLO_PAIR", "1") == "1"   # merge same-input 1x1 conv pairs (ConvPairOp)
+        # merge same-input conv pairs (ConvPairOp) in training plans; inference plans fuse BatchNorm + activation
+        # into each convolution's epilogue instead (ConvUnitOp.fwd), which needs one output matrix per conv
+        self.pair_convs = os.environ.get("PLYOLO_PAIR", "1") == "1" and training
+        self.fuse_eval = os.environ.get("PLYOLO_FUSE_EVAL", "1") == "1"
 
     # ------------------------------------------------------------------ lanes
     def add_op(self, op):
@@ -453,6 +456,17 @@ class ConvUnitOp:
         self._alloc_small()
         zt = self.z.tensor
         train_stats = g.training and bn is not None
+        if (not g.training) and bn is not None and g.dtype == BF16 and g.fuse_eval:
+            # inference: BatchNorm is a fixed affine -> applied with the activation in the conv epilogue; the
+            # activated tensor is written straight into its (possibly concat-slice) destination
+            call("plyolo_bn_eval_coef", self.Cout, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var),
+                 float(bn.eps), self.coef.data_ptr(), None)
+            if not hasattr(self, "desc_eval"):
+                self.desc_eval = conv_desc(g, self.desc.N, self.desc.H, self.desc.W, self.Cin_p, self.Cout, self.k, self.stride,
+                                           self.x.ld, self.out.ld)
+            call("plyolo_conv2d_fwd_bn_act", C.byref(self.desc_eval), g.aptr(self.x), self.pc.wp, self.coef.data_ptr(), self.act,
+                 g.aptr(self.res) if self.res is not None else None, self.res.ld if self.res is not None else 0, g.aptr(self.out), None)
+            return
         slots = g.stat_arena.data_ptr() + self.slot_off * 8 if train_stats else None
         call("plyolo_conv2d_fwd", C.byref(self.desc), g.aptr(self.x), self.pc.wp, None, zt.data_ptr(), slots, None)
         coef, st = None, None

@@ -202,3 +202,34 @@ def test_head_pred_backward_bf16(cout):
     e3 = hu.relerr(pk.db, gb)
     print("head_pred_bwd", cout, "dgrad %.3g wgrad %.3g bias %.3g" % (e1, e2, e3))
     assert e1 <= 2.0 ** -6 and e2 <= 1e-4 and e3 <= 1e-4
+
+@pytest.mark.parametrize("shape", [(2, 20, 20, 128, 128, 3, 1), (2, 32, 32, 32, 64, 3, 2), (2, 16, 16, 64, 64, 1, 1), (16, 80, 80, 64, 128, 3, 1)], ids=str)
+@pytest.mark.parametrize("with_res", [False, True])
+def test_conv_fwd_fused_bn_act_inference(shape, with_res):
+    """plyolo_conv2d_fwd_bn_act: eval-mode BaseConv (+ Bottleneck shortcut) in one launch ==
+    x_res + silu(batch_norm_eval(conv(x)))."""
+    N, H, W, Cin, Cout, k, s = shape
+    torch.manual_seed(sum(shape) + with_res)
+    x = hu.rnd_bf16(torch.randn(N, Cin, H, W, device=hu.DEV))
+    w = hu.rnd_bf16(torch.randn(Cout, Cin, k, k, device=hu.DEV) / (Cin * k * k) ** 0.5)
+    gamma, beta = torch.rand(Cout, device=hu.DEV) + 0.5, torch.rand(Cout, device=hu.DEV) - 0.5
+    rm, rv = torch.randn(Cout, device=hu.DEV) * 0.1, torch.rand(Cout, device=hu.DEV) + 0.5
+    ref = F.silu(F.batch_norm(_ref_conv(x, w, s), rm, rv, gamma, beta, False, 0.03, 1e-3))
+    OH, OW = ref.shape[2:]
+    res = hu.rnd_bf16(torch.randn_like(ref)) if with_res else None
+    if with_res:
+        ref = ref + res
+    coef = torch.zeros(4 * Cout, device=hu.DEV)
+    call("plyolo_bn_eval_coef", Cout, gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(), 1e-3, coef.data_ptr(), hu.stream())
+    x_ld, y_ld = Cin + 8, Cout + 16
+    xm = hu.to_nhwc(x, BF16, x_ld)
+    resm = hu.to_nhwc(res, BF16, Cout + 8) if with_res else None
+    pk = hu.Packed(w, BF16)
+    y = torch.full((N * OH * OW, y_ld), 3.0, dtype=torch.bfloat16, device=hu.DEV)
+    d = hu.conv_desc(BF16, N, H, W, Cin, Cout, k, s, x_ld, y_ld)
+    call("plyolo_conv2d_fwd_bn_act", C.byref(d), xm.data_ptr(), pk.wp.data_ptr(), coef.data_ptr(), 1,
+         resm.data_ptr() if with_res else None, Cout + 8 if with_res else 0, y.data_ptr(), hu.stream())
+    torch.cuda.synchronize()
+    err = hu.relerr(hu.from_nhwc(y, N, OH, OW, Cout), ref)
+    assert err <= 2.0 ** -6, err
+    assert torch.all(y[:, Cout:].float() == 3.0)
