@@ -84,6 +84,7 @@ class Graph:
         self.post_unpack = []   # ops with work that must follow unpack_wgrads
         self.plan = None        # the Plan being recorded (ops use it for lanes / events)
         self.cur_lane, self.cur_region = 0, None
+        self.pending = {}       # lane -> queued weight-gradient closures (defer_param_grads)
         # weight gradients on their own lane (PLYOLO_LANES=0 keeps every launch on lane 0)
         self.use_lanes = os.environ.get("PLYOLO_LANES", "1") != "0"
         self.reduce_slabs = os.environ.get("PLYOLO_REDUCE_SLABS", "1") == "1"
@@ -105,6 +106,30 @@ class Graph:
         independent of each other; everything before / after the region happens before / after all of it.
         Regions do not nest and only open from lane 0; otherwise (or with PLYOLO_LANES=0) the ops stay inline."""
         return _Region(self, self.use_lanes and self.cur_region is None and self.cur_lane == 0)
+
+    def defer_param_grads(self, lane, fn):
+        """Queue weight-gradient work (a closure issuing launches) for the weight-gradient lane.  The hand-off
+        costs an event on the main lane (a ~7 us bubble between two kernels), so it is paid once per
+        WGRAD_BATCH conv units instead of once per unit: with private dz buffers the queued wgrads may start
+        any time after their dz kernel, a few layers of lag cost nothing."""
+        q = self.pending.setdefault(lane, [])
+        q.append(fn)
+        if len(q) >= WGRAD_BATCH:
+            self.flush_param_grads(lane)
+
+    def flush_param_grads(self, lane=None):
+        for l in ([lane] if lane is not None else list(self.pending)):
+            q = self.pending.get(l) or []
+            if not q:
+                continue
+            plan = self.plan
+            ev = plan.record(l)
+            plan.lane(WGRAD_LANE)
+            plan.wait(WGRAD_LANE, ev)
+            for fn in q:
+                fn()
+            plan.lane(l)
+            self.pending[l] = []
 
     def dz_buffer(self, op, elems):
         """dz scratch of one conv unit's backward.  With lanes every unit owns its buffer (the weight-gradient
@@ -213,6 +238,7 @@ class Graph:
     def join_lanes(self):
         """Everything recorded on the weight-gradient lane so far happens before what lane 0 records next."""
         if self.use_lanes:
+            self.flush_param_grads()
             self.plan.wait(0, self.plan.record(WGRAD_LANE))
 
     def zero_fwd_stats(self):
@@ -283,6 +309,7 @@ class Graph:
 
 _OLD_ISSUE = os.environ.get("PLYOLO_ISSUE_OLD", "0") == "1"   # A/B switch for the issue-order experiments
 WGRAD_LANE = 1      # weight gradients (+ their slab reductions); branch lanes are 2, 3, ...
+WGRAD_BATCH = int(os.environ.get("PLYOLO_WGRAD_BATCH", "1"))   # conv units per hand-off event to the weight-gradient lane (measured: 1 == 4 > 8)
 
 
 class _Region:
@@ -359,6 +386,7 @@ def record_ops(g, plan, ops, method):
                     getattr(queues[l].pop(0), method)()
         for l in order:                 # join: lane 0 continues after every branch lane
             if l != 0:
+                g.flush_param_grads(l)  # weight-gradient work queued by this branch leaves with the branch
                 plan.wait(0, plan.record(l))
         i = j
     plan.lane(0)
@@ -509,23 +537,17 @@ class ConvUnitOp:
                 acc = g.grad_mode(self.x)
                 call("plyolo_conv2d_dgrad", C.byref(self.desc), dz, self.pc.wpd, g.gptr(self.x), acc, None)
 
+        def wgrad():
+            call("plyolo_conv2d_wgrad", C.byref(self.desc), g.aptr(self.x), dz, self.pc.dwp, None)
+            self.pc.reduce_slabs()
+
         if lanes:
             # the weight gradient only feeds the optimizer: it runs on its own lane, concurrently with the
-            # data-gradient chain of the layers upstream.  The main lane's dgrad is ISSUED first: the host
-            # needs a few microseconds per launch/event, and the main lane is the critical path.
-            ev = plan.record(me)
-            if not _OLD_ISSUE:
-                dgrad()
-            plan.lane(WGRAD_LANE)
-            plan.wait(WGRAD_LANE, ev)
-            call("plyolo_conv2d_wgrad", C.byref(self.desc), g.aptr(self.x), dz, self.pc.dwp, None)
-            self.pc.reduce_slabs()
-            plan.lane(me)
-            if _OLD_ISSUE:
-                dgrad()
+            # data-gradient chain of the layers upstream
+            dgrad()
+            g.defer_param_grads(me, wgrad)
         else:
-            call("plyolo_conv2d_wgrad", C.byref(self.desc), g.aptr(self.x), dz, self.pc.dwp, None)
-            self.pc.reduce_slabs()
+            wgrad()
             dgrad()
 
 
@@ -607,17 +629,16 @@ class ConvPairOp:
         call("plyolo_bn_act_bwd_dz", g.dtype, M, Cout, g.gptr(self.out_a), self.out_a.ld, zt, Cout, self.coef.data_ptr(), bslots,
              ptr(a.weight), g.grad_ptr_of(a.weight), g.grad_ptr_of(a.bias), 0, self.act, dz, Cout, C.byref(dsp), C.byref(p2), None)
         acc = g.grad_mode(self.x)
+
+        def wgrad():
+            call("plyolo_conv2d_wgrad", C.byref(self.desc), g.aptr(self.x), dz, self.pc.dwp, None)
+            self.pc.reduce_slabs()
+
         if lanes:
-            ev = plan.record(me)
             call("plyolo_conv2d_dgrad", C.byref(self.desc), dz, self.pc.wpd, g.gptr(self.x), acc, None)
-            plan.lane(WGRAD_LANE)
-            plan.wait(WGRAD_LANE, ev)
-            call("plyolo_conv2d_wgrad", C.byref(self.desc), g.aptr(self.x), dz, self.pc.dwp, None)
-            self.pc.reduce_slabs()
-            plan.lane(me)
+            g.defer_param_grads(me, wgrad)
         else:
-            call("plyolo_conv2d_wgrad", C.byref(self.desc), g.aptr(self.x), dz, self.pc.dwp, None)
-            self.pc.reduce_slabs()
+            wgrad()
             call("plyolo_conv2d_dgrad", C.byref(self.desc), dz, self.pc.wpd, g.gptr(self.x), acc, None)
 
 
@@ -960,23 +981,24 @@ class HeadPredOp:
         # the data gradients continue the main chain; the parameter gradients (bias sums, weight gradients)
         # only feed the optimizer and go to the weight-gradient lane (their inputs -- the loss gradients and the
         # forward features -- are not written again in this plan)
-        plan, lanes, me = g.plan, g.use_lanes, self.lane
-        ev = plan.record(me) if lanes else None
+        lanes, me = g.use_lanes, self.lane
         acc = g.grad_mode(self.reg_feat)
         call("plyolo_conv2d_dgrad", C.byref(d_ro), dro, self.pc_ro.wpd, g.gptr(self.reg_feat), acc, None)
         acc = g.grad_mode(self.cls_feat)
         call("plyolo_conv2d_dgrad", C.byref(d_cl), dcl, self.pc_cls.wpd, g.gptr(self.cls_feat), acc, None)
+
+        def param_grads():
+            call("plyolo_bias_grad", g.dtype, dro, M, 5, ld_ro, self.pc_ro.dbp, None)
+            call("plyolo_bias_grad", g.dtype, dcl, M, self.nc, ld_cl, self.pc_cls.dbp, None)
+            call("plyolo_conv2d_wgrad", C.byref(d_ro), g.aptr(self.reg_feat), dro, self.pc_ro.dwp, None)
+            self.pc_ro.reduce_slabs()
+            call("plyolo_conv2d_wgrad", C.byref(d_cl), g.aptr(self.cls_feat), dcl, self.pc_cls.dwp, None)
+            self.pc_cls.reduce_slabs()
+
         if lanes:
-            plan.lane(WGRAD_LANE)
-            plan.wait(WGRAD_LANE, ev)
-        call("plyolo_bias_grad", g.dtype, dro, M, 5, ld_ro, self.pc_ro.dbp, None)
-        call("plyolo_bias_grad", g.dtype, dcl, M, self.nc, ld_cl, self.pc_cls.dbp, None)
-        call("plyolo_conv2d_wgrad", C.byref(d_ro), g.aptr(self.reg_feat), dro, self.pc_ro.dwp, None)
-        self.pc_ro.reduce_slabs()
-        call("plyolo_conv2d_wgrad", C.byref(d_cl), g.aptr(self.cls_feat), dcl, self.pc_cls.dwp, None)
-        self.pc_cls.reduce_slabs()
-        if lanes:
-            plan.lane(me)
+            g.defer_param_grads(me, param_grads)
+        else:
+            param_grads()
 
 
 class HeadBuffers:
