@@ -133,19 +133,23 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
   const int total = nchunks * p.ntaps;
   const bool nb_ok = nb < p.nnb;
   // fragment (tap, nb, kb): 64 lanes x 8 bf16, contiguous
-  const bf16_t* wlane = p.w + ((size_t)nb * p.nkb) * 512 + lane * 8;
+  const bf16_t* wlane = p.w + ((size_t)(nb_ok ? nb : p.nnb - 1) * p.nkb) * 512 + lane * 8;
   const size_t wtap = (size_t)p.nnb * p.nkb * 512;
 
   u32x4 bcur[KS], bnext[KS];
+  // Branch-free: the loads are ALWAYS issued (from a clamped, valid fragment).  With the loads inside `if`s the
+  // compiler cannot count the outstanding ones and emits s_waitcnt vmcnt(0) at the top of every tap -- which
+  // also waits for the prefetch it has just issued.
   auto load_b = [&](int phase, u32x4* dst) {
     const int chunk = phase / p.ntaps, t = phase - chunk * p.ntaps;
     const bf16_t* wt = wlane + (size_t)(tap_code(p, t) >> 4) * wtap;
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
       const int kb = chunk * KS + kk;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (nb_ok && kb < p.nkb) v = *(const u32x4*)(wt + (size_t)kb * 512);
-      dst[kk] = v;
+      // No masking is needed: a k-block beyond Cin meets zero-filled halo columns (finite weights x 0 = 0), and a
+      // wave whose 32-channel block lies beyond Cout only produces accumulators that the epilogue never stores.
+      const int kbc = kb < p.nkb ? kb : p.nkb - 1;
+      dst[kk] = *(const u32x4*)(wt + (size_t)kbc * 512);
     }
   };
 
@@ -189,7 +193,12 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
     }
     __syncthreads();  // halo tile visible
     for (int t = 0; t < p.ntaps; ++t, ++phase) {
-      if (phase + 1 < total && !(abl & 16)) load_b(phase + 1, bnext);
+      // unconditional (the last tap re-loads its own fragments): a branch around the loads makes the waitcnt
+      // insertion fall back to vmcnt(0) at the join
+      if (!(abl & 16)) load_b(phase + 1 < total ? phase + 1 : phase, bnext);
+      // keep the prefetch ABOVE the MFMA block: left alone, the scheduler sinks these loads to the end of the tap
+      // (shorter live range) where the next tap's s_waitcnt vmcnt(0) exposes their full latency
+      __builtin_amdgcn_sched_barrier(0);
       const unsigned tc = tap_code(p, t);
       const int toff = (int)(tc & 3u) * p.rowp + (int)((tc >> 2) & 3u) * ROWB;
 #pragma unroll
