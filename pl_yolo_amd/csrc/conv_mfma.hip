@@ -201,18 +201,29 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
       __builtin_amdgcn_sched_barrier(0);
       const unsigned tc = tap_code(p, t);
       const int toff = (int)(tc & 3u) * p.rowp + (int)((tc >> 2) & 3u) * ROWB;
+      // software pipeline over the k-steps: the A fragments of step kk+1 are requested from LDS before the MFMAs
+      // of step kk are issued, so that no MFMA waits on a ds_read issued just before it
+      bf16x8 a[MT], an[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) a[mt] = *(const bf16x8*)(smem + arow[mt] + toff);
 #pragma unroll
       for (int kk = 0; kk < KS; ++kk) {
-        bf16x8 a[MT];
         const bf16x8 b = *(const bf16x8*)&bcur[kk];
+        if (kk + 1 < KS) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) a[mt] = (abl & 32) ? b : *(const bf16x8*)(smem + arow[mt] + toff + kk * 32);
-        if (!(abl & 8))
+          for (int mt = 0; mt < MT; ++mt) an[mt] = *(const bf16x8*)(smem + arow[mt] + toff + (kk + 1) * 32);
+        }
+        if (!(abl & 8)) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b, acc[mt], 0, 0, 0);
-        else
+          for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b, acc[mt], 0, 0, 0);
+        } else {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt][0] += (float)a[mt][0];
+          for (int mt = 0; mt < MT; ++mt) acc[mt][0] += (float)a[mt][0];
+        }
+        if (kk + 1 < KS) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) a[mt] = an[mt];
+        }
       }
 #pragma unroll
       for (int kk = 0; kk < KS; ++kk) bcur[kk] = bnext[kk];
