@@ -213,6 +213,9 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) an[mt] = *(const bf16x8*)(smem + arow[mt] + toff + (kk + 1) * 32);
         }
+        // fence: all reads of step kk+1 are issued BEFORE the MFMAs of step kk (counted lgkmcnt then lets the MFMAs
+        // start while those reads are still in flight); without it the scheduler pairs reads with the MFMAs again
+        __builtin_amdgcn_sched_barrier(0);
         if (!(abl & 8)) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b, acc[mt], 0, 0, 0);
@@ -220,6 +223,7 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) acc[mt][0] += (float)a[mt][0];
         }
+        __builtin_amdgcn_sched_barrier(0);
         if (kk + 1 < KS) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) a[mt] = an[mt];
