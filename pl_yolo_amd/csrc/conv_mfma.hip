@@ -155,16 +155,54 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
 
   constexpr int abl = ABL;  // compile-time diagnostics switch (see ConvP::ablate)
   load_b(0, bcur);
+
+  // ---- halo-tile loader.  The (pixel, channel-vector) -> (global offset, LDS offset) mapping of a thread's
+  // vectors is the same for every Cin chunk, so it is computed ONCE per tile: in-kernel stamps showed the halo
+  // phases at ~10k cycles each, most of it the per-vector index arithmetic (a runtime division by the tile
+  // width, bounds tests, 64-bit addresses) repeated for the loads, again for the LDS stores, and per chunk.
+  constexpr int HVT = ((TH + 2) * 18 * CV + 255) / 256;   // vectors per thread of a 3x3 stride-1 halo tile
+  const int nvec = p.ITH * p.ITW * CV;
+  const bool fastpath = nvec <= HVT * 256;                 // stride-2 forward tiles take the generic loop
+  const bf16_t* xn = p.x + (size_t)n * p.H * p.W * p.x_ld;
+  const int cvt = tid % CV;                                // 256 % CV == 0: a thread always owns the same channel vector
+  int goff[HVT], loff[HVT];
+  if (fastpath) {
+#pragma unroll
+    for (int v = 0; v < HVT; ++v) {
+      const int idx = tid + v * 256;
+      goff[v] = -1;
+      loff[v] = -1;
+      if (idx < nvec) {
+        const int pix = idx / CV;
+        const int iy = pix / p.ITW, ix = pix - iy * p.ITW;
+        const int gy = iy0 + iy, gx = ix0 + ix;
+        loff[v] = iy * p.rowp + ix * ROWB + cvt * 16;
+        if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) goff[v] = (gy * p.W + gx) * p.x_ld + cvt * 8;
+      }
+    }
+  }
   int phase = 0;
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     const int c0 = chunk * CK;
     __syncthreads();  // every wave is done reading the previous chunk's halo tile
-    if (!(abl & 4) || chunk == 0) {
-      // halo tile: issue a whole batch of 16-byte loads before the first LDS write so that
-      // HV loads per thread are in flight at once (a load->wait->write loop serialises them)
+    if (fastpath) {
+      if (!(abl & 4) || chunk == 0) {
+        const bool cok = c0 + cvt * 8 < p.Cin;
+        u32x4 hv[HVT];
+#pragma unroll
+        for (int v = 0; v < HVT; ++v) {
+          u32x4 val = {0u, 0u, 0u, 0u};
+          if (goff[v] >= 0 && cok) val = *(const u32x4*)(xn + goff[v] + c0);
+          hv[v] = val;
+        }
+#pragma unroll
+        for (int v = 0; v < HVT; ++v)
+          if (loff[v] >= 0) *(u32x4*)(smem + loff[v]) = hv[v];
+      }
+    } else if (!(abl & 4) || chunk == 0) {
+      // generic: batches of HV 16-byte loads in flight before the first LDS write (a load->wait->write loop
+      // serialises them)
       constexpr int HV = 6;
-      const int nvec = p.ITH * p.ITW * CV;
-      const bf16_t* xn = p.x + (size_t)n * p.H * p.W * p.x_ld;
       for (int base = 0; base < nvec; base += HV * 256) {
         u32x4 hv[HV];
 #pragma unroll
@@ -203,19 +241,20 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
       const int toff = (int)(tc & 3u) * p.rowp + (int)((tc >> 2) & 3u) * ROWB;
       // software pipeline over the k-steps: the A fragments of step kk+1 are requested from LDS before the MFMAs
       // of step kk are issued, so that no MFMA waits on a ds_read issued just before it
-      bf16x8 a[MT], an[MT];
+      constexpr bool PIPE = MT <= 4;   // the 8-fragment tile has no registers left for a second fragment set
+      bf16x8 a[MT], an[PIPE ? MT : 1];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) a[mt] = *(const bf16x8*)(smem + arow[mt] + toff);
 #pragma unroll
       for (int kk = 0; kk < KS; ++kk) {
         const bf16x8 b = *(const bf16x8*)&bcur[kk];
-        if (kk + 1 < KS) {
+        if (PIPE && kk + 1 < KS) {
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) an[mt] = *(const bf16x8*)(smem + arow[mt] + toff + (kk + 1) * 32);
+          for (int mt = 0; mt < MT; ++mt) an[PIPE ? mt : 0] = *(const bf16x8*)(smem + arow[mt] + toff + (kk + 1) * 32);
         }
         // fence: all reads of step kk+1 are issued BEFORE the MFMAs of step kk (counted lgkmcnt then lets the MFMAs
         // start while those reads are still in flight); without it the scheduler pairs reads with the MFMAs again
-        __builtin_amdgcn_sched_barrier(0);
+        if (PIPE) __builtin_amdgcn_sched_barrier(0);
         if (!(abl & 8)) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b, acc[mt], 0, 0, 0);
@@ -223,10 +262,10 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) acc[mt][0] += (float)a[mt][0];
         }
-        __builtin_amdgcn_sched_barrier(0);
+        if (PIPE) __builtin_amdgcn_sched_barrier(0);
         if (kk + 1 < KS) {
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) a[mt] = an[mt];
+          for (int mt = 0; mt < MT; ++mt) a[mt] = PIPE ? an[PIPE ? mt : 0] : *(const bf16x8*)(smem + arow[mt] + toff + (kk + 1) * 32);
         }
       }
 #pragma unroll
@@ -490,6 +529,9 @@ void set_taps(ConvP& p) {
 }
 
 // choose the tiles, then derive the grid; ext = halo extent beyond (T-1)*si (per axis)
+// the halo loader keeps 32-bit element offsets per image
+bool offsets_fit(const ConvP& p) { return (double)p.H * p.W * p.x_ld < 2147483000.0; }
+
 void apply_tiles(ConvP& p, int ext_y, int ext_x, int TH) {
   p.ITH = (TH - 1) * p.si + ext_y;
   p.ITW = (TW - 1) * p.si + ext_x;
