@@ -289,16 +289,27 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
 
   if (p.stats != nullptr && !(abl & 64)) {
     float s1 = 0.f, s2 = 0.f;
+    if (oy0 + TH <= p.OHt && ox0 + TW <= p.OWt) {
+      // interior tile (the common case): no per-element validity arithmetic
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int m = (wm * MT + mt) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        const bool valid = (oy0 + (m >> 4) < p.OHt) && (ox0 + (m & 15) < p.OWt);
-        const float v = valid ? acc[mt][i] : 0.f;
-        s1 += v;
-        s2 += v * v;
-      }
+        for (int i = 0; i < 16; ++i) {
+          s1 += acc[mt][i];
+          s2 = fmaf(acc[mt][i], acc[mt][i], s2);
+        }
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int m = (wm * MT + mt) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          const bool valid = (oy0 + (m >> 4) < p.OHt) && (ox0 + (m & 15) < p.OWt);
+          const float v = valid ? acc[mt][i] : 0.f;
+          s1 += v;
+          s2 = fmaf(v, v, s2);
+        }
+    }
     s1 += __shfl_xor(s1, 32);
     s2 += __shfl_xor(s2, 32);
     if (h == 0) {
