@@ -41,6 +41,7 @@ struct ConvP {
   int so, oy_off, ox_off;
   int si, iy_off, ix_off;
   int ITH, ITW;
+  int db, bufsz;  // double-buffered halo variant (PLYOLO_DB, default on): enabled / bytes of one halo buffer
   int rowp;  // LDS pitch of one halo-tile image row (bytes): a multiple of 256 when si == 1, so that the two
              // image rows a 32-pixel A fragment spans land on disjoint banks (conflict-free ds_read_b128)
   int ntaps;
@@ -87,7 +88,7 @@ struct ConvJobs {
   int start[5];
 };
 
-template <int BN, int CK, int TH, bool OUT_F32, int ABL>
+template <int BN, int CK, int TH, bool OUT_F32, int ABL, bool DB = false>
 DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
   constexpr int BM = TH * TW;
   constexpr int WN = BN / 32, WM = 4 / WN, MT = BM / (32 * WM);
@@ -181,95 +182,130 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
       }
     }
   }
-  int phase = 0;
-  for (int chunk = 0; chunk < nchunks; ++chunk) {
-    const int c0 = chunk * CK;
-    __syncthreads();  // every wave is done reading the previous chunk's halo tile
-    if (fastpath) {
-      if (!(abl & 4) || chunk == 0) {
-        const bool cok = c0 + cvt * 8 < p.Cin;
-        u32x4 hv[HVT];
+  // loads are ALWAYS issued (border / out-of-range vectors read the image's first 16 bytes and are replaced by
+  // zeros when they are written to LDS): a fixed number of VMEM instructions per call keeps the compiler's vmcnt
+  // bookkeeping exact, which the double-buffered variant below depends on
+  auto halo_load = [&](const int c0, u32x4* hv) {
+    const bool cok = c0 + cvt * 8 < p.Cin;
 #pragma unroll
-        for (int v = 0; v < HVT; ++v) {
-          u32x4 val = {0u, 0u, 0u, 0u};
-          if (goff[v] >= 0 && cok) val = *(const u32x4*)(xn + goff[v] + c0);
-          hv[v] = val;
+    for (int v = 0; v < HVT; ++v) hv[v] = *(const u32x4*)(xn + ((goff[v] >= 0 && cok) ? goff[v] + c0 : 0));
+  };
+  auto halo_store = [&](const int c0, const u32x4* hv, const int boff) {
+    const bool cok = c0 + cvt * 8 < p.Cin;
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int v = 0; v < HVT; ++v)
+      if (loff[v] >= 0) *(u32x4*)(smem + boff + loff[v]) = (goff[v] >= 0 && cok) ? hv[v] : zero;
+  };
+  // generic loader (stride-2 forward tiles): batches of HV 16-byte loads in flight before the first LDS write
+  auto halo_generic = [&](const int c0) {
+    constexpr int HV = 6;
+    for (int base = 0; base < nvec; base += HV * 256) {
+      u32x4 hv[HV];
+#pragma unroll
+      for (int v = 0; v < HV; ++v) {
+        const int idx = base + tid + v * 256;
+        u32x4 val = {0u, 0u, 0u, 0u};
+        if (idx < nvec) {
+          const int pix = idx / CV, cv = idx - pix * CV;
+          const int iy = pix / p.ITW, ix = pix - iy * p.ITW;
+          const int gy = iy0 + iy, gx = ix0 + ix, c = c0 + cv * 8;
+          if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && c < p.Cin)
+            val = *(const u32x4*)(xn + ((size_t)gy * p.W + gx) * p.x_ld + c);
         }
-#pragma unroll
-        for (int v = 0; v < HVT; ++v)
-          if (loff[v] >= 0) *(u32x4*)(smem + loff[v]) = hv[v];
+        hv[v] = val;
       }
-    } else if (!(abl & 4) || chunk == 0) {
-      // generic: batches of HV 16-byte loads in flight before the first LDS write (a load->wait->write loop
-      // serialises them)
-      constexpr int HV = 6;
-      for (int base = 0; base < nvec; base += HV * 256) {
-        u32x4 hv[HV];
 #pragma unroll
-        for (int v = 0; v < HV; ++v) {
-          const int idx = base + tid + v * 256;
-          u32x4 val = {0u, 0u, 0u, 0u};
-          if (idx < nvec) {
-            const int pix = idx / CV, cv = idx - pix * CV;
-            const int iy = pix / p.ITW, ix = pix - iy * p.ITW;
-            const int gy = iy0 + iy, gx = ix0 + ix, c = c0 + cv * 8;
-            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && c < p.Cin)
-              val = *(const u32x4*)(xn + ((size_t)gy * p.W + gx) * p.x_ld + c);
-          }
-          hv[v] = val;
-        }
-#pragma unroll
-        for (int v = 0; v < HV; ++v) {
-          const int idx = base + tid + v * 256;
-          if (idx < nvec) {
-            const int pix = idx / CV, cv = idx - pix * CV;
-            const int iy = pix / p.ITW, ix = pix - iy * p.ITW;
-            *(u32x4*)(smem + iy * p.rowp + ix * ROWB + cv * 16) = hv[v];
-          }
+      for (int v = 0; v < HV; ++v) {
+        const int idx = base + tid + v * 256;
+        if (idx < nvec) {
+          const int pix = idx / CV, cv = idx - pix * CV;
+          const int iy = pix / p.ITW, ix = pix - iy * p.ITW;
+          *(u32x4*)(smem + iy * p.rowp + ix * ROWB + cv * 16) = hv[v];
         }
       }
     }
-    __syncthreads();  // halo tile visible
-    for (int t = 0; t < p.ntaps; ++t, ++phase) {
-      // unconditional (the last tap re-loads its own fragments): a branch around the loads makes the waitcnt
-      // insertion fall back to vmcnt(0) at the join
-      if (!(abl & 16)) load_b(phase + 1 < total ? phase + 1 : phase, bnext);
-      // keep the prefetch ABOVE the MFMA block: left alone, the scheduler sinks these loads to the end of the tap
-      // (shorter live range) where the next tap's s_waitcnt vmcnt(0) exposes their full latency
-      __builtin_amdgcn_sched_barrier(0);
-      const unsigned tc = tap_code(p, t);
-      const int toff = (int)(tc & 3u) * p.rowp + (int)((tc >> 2) & 3u) * ROWB;
-      // software pipeline over the k-steps: the A fragments of step kk+1 are requested from LDS before the MFMAs
-      // of step kk are issued, so that no MFMA waits on a ds_read issued just before it
-      constexpr bool PIPE = MT <= 4;   // the 8-fragment tile has no registers left for a second fragment set
-      bf16x8 a[MT], an[PIPE ? MT : 1];
+  };
+
+  int phase = 0;
+  // one filter tap of the current chunk: KS k-steps x MT MFMAs on the halo tile at LDS offset `boff`;
+  // `extra_loads` is issued right after the weight prefetch (see the double-buffered loop)
+  auto run_tap = [&](const int t, const int boff, auto&& extra_loads) {
+    // unconditional (the last tap re-loads its own fragments): a branch around the loads makes the waitcnt
+    // insertion fall back to vmcnt(0) at the join
+    if (!(abl & 16)) load_b(phase + 1 < total ? phase + 1 : phase, bnext);
+    extra_loads();
+    // keep the prefetch ABOVE the MFMA block: left alone, the scheduler sinks these loads to the end of the tap
+    // (shorter live range) where the next tap's s_waitcnt vmcnt(0) exposes their full latency
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned tc = tap_code(p, t);
+    const int toff = boff + (int)(tc & 3u) * p.rowp + (int)((tc >> 2) & 3u) * ROWB;
+    // software pipeline over the k-steps: the A fragments of step kk+1 are requested from LDS before the MFMAs
+    // of step kk are issued, so that no MFMA waits on a ds_read issued just before it
+    constexpr bool PIPE = MT <= 4;   // the 8-fragment tile has no registers left for a second fragment set
+    bf16x8 a[MT], an[PIPE ? MT : 1];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) a[mt] = *(const bf16x8*)(smem + arow[mt] + toff);
+    for (int mt = 0; mt < MT; ++mt) a[mt] = *(const bf16x8*)(smem + arow[mt] + toff);
 #pragma unroll
-      for (int kk = 0; kk < KS; ++kk) {
-        const bf16x8 b = *(const bf16x8*)&bcur[kk];
-        if (PIPE && kk + 1 < KS) {
+    for (int kk = 0; kk < KS; ++kk) {
+      const bf16x8 b = *(const bf16x8*)&bcur[kk];
+      if (PIPE && kk + 1 < KS) {
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) an[PIPE ? mt : 0] = *(const bf16x8*)(smem + arow[mt] + toff + (kk + 1) * 32);
-        }
-        // fence: all reads of step kk+1 are issued BEFORE the MFMAs of step kk (counted lgkmcnt then lets the MFMAs
-        // start while those reads are still in flight); without it the scheduler pairs reads with the MFMAs again
-        if (PIPE) __builtin_amdgcn_sched_barrier(0);
-        if (!(abl & 8)) {
+        for (int mt = 0; mt < MT; ++mt) an[PIPE ? mt : 0] = *(const bf16x8*)(smem + arow[mt] + toff + (kk + 1) * 32);
+      }
+      // fence: all reads of step kk+1 are issued BEFORE the MFMAs of step kk (counted lgkmcnt then lets the MFMAs
+      // start while those reads are still in flight); without it the scheduler pairs reads with the MFMAs again
+      if (PIPE) __builtin_amdgcn_sched_barrier(0);
+      if (!(abl & 8)) {
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b, acc[mt], 0, 0, 0);
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b, acc[mt], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][0] += (float)a[mt][0];
+      }
+      if (PIPE) __builtin_amdgcn_sched_barrier(0);
+      if (kk + 1 < KS) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[mt] = PIPE ? an[PIPE ? mt : 0] : *(const bf16x8*)(smem + arow[mt] + toff + (kk + 1) * 32);
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) bcur[kk] = bnext[kk];
+    ++phase;
+  };
+
+  if constexpr (DB) {
+    // Double-buffered halo tile: the next chunk's vectors are requested right after tap 0's weight prefetch, stay
+    // in flight for the whole chunk (vmcnt is in-order: the first wait that covers them is tap 2's wait for its
+    // weights) and are written to the OTHER LDS buffer after the last tap.  One barrier per chunk, no exposed
+    // global-load latency between chunks.
+    u32x4 hv[HVT];
+    halo_load(0, hv);
+    halo_store(0, hv, 0);
+    __syncthreads();
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+      const int boff = (chunk & 1) * p.bufsz;
+      const int cnext = (chunk + 1) * CK;   // past Cin on the last chunk: every load collapses to the dummy address
+      run_tap(0, boff, [&]() { halo_load(cnext, hv); });
+      for (int t = 1; t < p.ntaps; ++t) run_tap(t, boff, []() {});
+      if (chunk + 1 < nchunks) halo_store(cnext, hv, p.bufsz - boff);
+      __syncthreads();  // next buffer complete; every wave is done with this one
+    }
+  } else {
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+      const int c0 = chunk * CK;
+      __syncthreads();  // every wave is done reading the previous chunk's halo tile
+      if (!(abl & 4) || chunk == 0) {
+        if (fastpath) {
+          u32x4 hv[HVT];
+          halo_load(c0, hv);
+          halo_store(c0, hv, 0);
         } else {
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) acc[mt][0] += (float)a[mt][0];
-        }
-        if (PIPE) __builtin_amdgcn_sched_barrier(0);
-        if (kk + 1 < KS) {
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) a[mt] = PIPE ? an[PIPE ? mt : 0] : *(const bf16x8*)(smem + arow[mt] + toff + (kk + 1) * 32);
+          halo_generic(c0);
         }
       }
-#pragma unroll
-      for (int kk = 0; kk < KS; ++kk) bcur[kk] = bnext[kk];
+      __syncthreads();  // halo tile visible
+      for (int t = 0; t < p.ntaps; ++t) run_tap(t, 0, []() {});
     }
   }
   __syncthreads();  // all LDS operand reads retired; LDS is reused for the epilogue
@@ -396,9 +432,9 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
   }
 }
 
-template <int BN, int CK, int TH, bool OUT_F32, int ABL = 0>
+template <int BN, int CK, int TH, bool OUT_F32, int ABL = 0, bool DB = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvP p) {
-  conv_mfma_body<BN, CK, TH, OUT_F32, ABL>(p, (int)blockIdx.x, (int)gridDim.x);
+  conv_mfma_body<BN, CK, TH, OUT_F32, ABL, DB>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 
 template <int BN, int CK, int TH>
@@ -420,6 +456,16 @@ hipError_t launch_inst(ConvP p, hipStream_t s) {
   size_t lds_epi = (size_t)BM * SROW + WM * 2 * BN * 4;
   size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
   auto kern = conv_mfma_kernel<BN, CK, TH, OUT_F32>;
+  // double-buffered halo tile: stride-1 tiles with more than one Cin chunk
+  constexpr bool HAS_DB = !OUT_F32 && ((TH == 8 && (CK == 32 || CK == 64)) || (TH == 16 && CK == 32));
+  if constexpr (HAS_DB) {
+    if (p.db && p.si == 1 && p.Cin > CK && !p.ablate) {
+      p.bufsz = p.ITH * p.rowp;
+      lds_main = 2 * (size_t)p.bufsz;
+      lds = lds_main > lds_epi ? lds_main : lds_epi;
+      kern = conv_mfma_kernel<BN, CK, TH, OUT_F32, 0, true>;
+    }
+  }
   if (BN == 128 && CK == 64 && TH == 16 && !OUT_F32 && p.ablate) {  // diagnostic instantiations of the main shape only
     switch (p.ablate) {
       case 1: kern = conv_mfma_kernel<128, 64, 16, false, 1>; break;
@@ -521,6 +567,8 @@ void pick_tiles(const ConvP& p, int ext_y, bool out_f32, int* BN, int* CK, int* 
   const long tiles16 = (long)p.N * ((p.OHt + 15) / 16) * ((p.OWt + TW - 1) / TW) * ((p.Cout + bn - 1) / bn);
   if (th == 16 && tiles16 < 384) th = 8;
   if (th == 8 && p.si == 1 && p.Cin == 128 && !out_f32 && bn >= 64 && getenv("PLYOLO_NO_CK128") == nullptr) ck = 128;
+  // the 16-row tile double-buffers its halo only with 32-channel chunks (two 64-channel buffers leave no LDS for a second workgroup)
+  if (th == 16 && p.si == 1 && ck == 64 && !out_f32 && p.db >= 2) ck = 32;
   if (const char* e = getenv("PLYOLO_FORCE_CK")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) ck = v < ck ? v : ck; }
   if (const char* e = getenv("PLYOLO_FORCE_BN")) { const int v = atoi(e); if (v == 32 || v == 64 || v == 128) bn = v < bn ? v : bn; }
   if (const char* e = getenv("PLYOLO_FORCE_TH")) { const int v = atoi(e); if (v == 8 || v == 16) th = v; }
@@ -554,6 +602,8 @@ void apply_tiles(ConvP& p, int ext_y, int ext_x, int TH) {
 void finish(ConvP& p, int ext_y, int ext_x, bool out_f32, int* BN, int* CK, int* TH) {
   set_taps(p);
   if (const char* e = getenv("PLYOLO_ABLATE")) p.ablate = atoi(e);
+  p.db = 1;
+  if (const char* e = getenv("PLYOLO_DB")) p.db = atoi(e);
   pick_tiles(p, ext_y, out_f32, BN, CK, TH);
   apply_tiles(p, ext_y, ext_x, *TH);
 }
