@@ -144,7 +144,7 @@ int plyolo_plan_lanes(const plyolo_plan* p) { return p ? ((const Plan*)p)->nlane
 int plyolo_plan_size(const plyolo_plan* p) { return p ? (int)((const Plan*)p)->ops.size() : 0; }
 // Issue every recorded launch: lane l on its own stream (forked from / joined into `s`), events as
 // recorded.  Used both under stream capture (hipGraph) and for eager multi-stream replay.
-static hipError_t issue_lanes(Plan* q, hipStream_t s, bool lanes, size_t* failed) {
+static hipError_t issue_lanes(Plan* q, hipStream_t s, bool lanes, size_t* failed, hipEvent_t* tev = nullptr) {
   if (!lanes || q->nlanes <= 1) {  // single stream, recorded order (a valid serialisation of the lanes)
     hipError_t le = hipSuccess;
     for (size_t i = 0; i < q->ops.size() && le == hipSuccess; ++i) {
@@ -170,7 +170,8 @@ static hipError_t issue_lanes(Plan* q, hipStream_t s, bool lanes, size_t* failed
   auto lane_stream = [&](int l) { return l == 0 ? s : q->side[(size_t)l - 1]; };
   hipEvent_t* fork_ev = q->events.data() + q->nevents;  // [nlanes] fork, [nlanes] join
   hipError_t le = hipSuccess;
-  if (q->nlanes > 1) {
+  if (tev) le = hipEventRecord(tev[0], s);
+  if (q->nlanes > 1 && le == hipSuccess) {
     le = hipEventRecord(fork_ev[0], s);
     for (int l = 1; l < q->nlanes && le == hipSuccess; ++l) le = hipStreamWaitEvent(lane_stream(l), fork_ev[0], 0);
   }
@@ -181,6 +182,8 @@ static hipError_t issue_lanes(Plan* q, hipStream_t s, bool lanes, size_t* failed
     else le = hipStreamWaitEvent(lane_stream(op.lane), q->events[(size_t)op.ev], 0);
     if (le != hipSuccess && failed) *failed = i;
   }
+  if (tev)
+    for (int l = 0; l < q->nlanes && le == hipSuccess; ++l) le = hipEventRecord(tev[1 + l], lane_stream(l));
   for (int l = 1; l < q->nlanes && le == hipSuccess; ++l) {
     le = hipEventRecord(fork_ev[q->nlanes + l], lane_stream(l));
     if (le == hipSuccess) le = hipStreamWaitEvent(s, fork_ev[q->nlanes + l], 0);
@@ -240,6 +243,27 @@ int plyolo_plan_profile(plyolo_plan* p, void* stream, float* ms_out, int n) {
     for (size_t i = 0; i < q->ops.size(); ++i) (void)hipEventElapsedTime(&ms_out[i], ev[i], ev[i + 1]);
   for (auto& e : ev) (void)hipEventDestroy(e);
   if (err != hipSuccess) { set_error("plan_profile: %s", hipGetErrorString(err)); return -2; }
+  return 0;
+}
+// Diagnostic multi-lane replay: ms_out[l] = time from the start of the replay to the end of lane l's last launch,
+// ms_out[nlanes] = to the join on the caller's stream.  Synchronises the stream.
+int plyolo_plan_lane_times(plyolo_plan* p, void* stream, float* ms_out, int n) {
+  PLY_CHECK_ARG(p != nullptr && ms_out != nullptr, "plan_lane_times: null argument");
+  PLY_CHECK_ARG(g_rec == nullptr, "plan_lane_times: cannot replay while recording");
+  Plan* q = (Plan*)p;
+  PLY_CHECK_ARG(q->nlanes > 1 && n >= q->nlanes + 1, "plan_lane_times: needs a multi-lane plan and %d outputs", q->nlanes + 1);
+  hipStream_t s = (hipStream_t)stream;
+  std::vector<hipEvent_t> ev((size_t)q->nlanes + 2);
+  for (auto& e : ev)
+    if (hipEventCreate(&e) != hipSuccess) { set_error("plan_lane_times: hipEventCreate failed"); return -2; }
+  size_t failed = 0;
+  hipError_t err = issue_lanes(q, s, true, &failed, ev.data());
+  if (err == hipSuccess) err = hipEventRecord(ev[(size_t)q->nlanes + 1], s);
+  if (err == hipSuccess) err = hipStreamSynchronize(s);
+  if (err == hipSuccess)
+    for (int l = 0; l <= q->nlanes; ++l) (void)hipEventElapsedTime(&ms_out[l], ev[0], ev[(size_t)l + 1]);
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  if (err != hipSuccess) { set_error("plan_lane_times: %s", hipGetErrorString(err)); return -2; }
   return 0;
 }
 int plyolo_plan_op_info(const plyolo_plan* p, int i, char* label, int label_cap, double* flops, double* bytes) {

@@ -433,18 +433,25 @@ __global__ void pack_weights_kernel(const plyolo_pack_entry* table) {
 
 // slab 0 += slabs 1..n-1 (fixed order).  Runs right after a wgrad launch (on the weight-gradient lane), so
 // that the final unpack only permutes one slab per convolution.
-__global__ void reduce_slabs_kernel(float* dwp, int nslab, size_t elems) {
+// blockIdx.y = slab group: group g folds slabs [g*per, min((g+1)*per, nslab)) into slab g*per (in place).  A small
+// weight tensor with up to 1024 slabs has only a handful of column blocks, so the slab range is first folded by
+// many groups in parallel and the few group heads are folded by a second launch (stride = per slabs); the
+// summation order is fixed by (per, nslab), never by timing.
+__global__ void reduce_slabs_kernel(float* dwp, int nslab, size_t elems, int per, size_t stride) {
+  const int first = blockIdx.y * per;
+  const int n = nslab - first < per ? nslab - first : per;
+  float* base = dwp + (size_t)first * stride;
   for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < elems; i += (size_t)gridDim.x * blockDim.x * 4) {
     if (i + 4 <= elems) {
-      f32x4 a = *(const f32x4*)(dwp + i);
+      f32x4 a = *(const f32x4*)(base + i);
 #pragma unroll 4
-      for (int sl = 1; sl < nslab; ++sl) a += *(const f32x4*)(dwp + (size_t)sl * elems + i);
-      *(f32x4*)(dwp + i) = a;
+      for (int sl = 1; sl < n; ++sl) a += *(const f32x4*)(base + (size_t)sl * stride + i);
+      *(f32x4*)(base + i) = a;
     } else {
       for (size_t k = i; k < elems; ++k) {
-        float a = dwp[k];
-        for (int sl = 1; sl < nslab; ++sl) a += dwp[(size_t)sl * elems + k];
-        dwp[k] = a;
+        float a = base[k];
+        for (int sl = 1; sl < n; ++sl) a += base[(size_t)sl * stride + k];
+        base[k] = a;
       }
     }
   }
@@ -747,8 +754,20 @@ int plyolo_reduce_slabs(float* dwp, int nslab, size_t elems, void* stream) {
   PLY_CHECK_ARG(dwp && nslab >= 1 && elems % 4 == 0, "reduce_slabs: slab length must be a multiple of 4 floats");
   if (nslab == 1) return 0;
   plyolo::annotate("reduce_slabs", 0.0, 4.0 * (double)elems * nslab);
+  // column blocks alone fill the chip only for the largest weight tensors: split the slab range into groups until
+  // about 1024 workgroups exist, at least 4 slabs per group
+  const int cols = grid_for(elems / 4);
+  int groups = 1;
+  if (cols < 512 && nslab >= 16) {
+    groups = (1024 + cols - 1) / cols;
+    if (groups > nslab / 4) groups = nslab / 4;
+  }
+  const int per = (nslab + groups - 1) / groups;
+  groups = (nslab + per - 1) / per;
   return submit(stream, [=](hipStream_t s) -> hipError_t {
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid_for(elems / 4)), dim3(256), 0, s, dwp, nslab, elems);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cols, groups), dim3(256), 0, s, dwp, nslab, elems, per, elems);
+    if (groups > 1)  // fold the group heads (slabs 0, per, 2*per, ...)
+      hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cols, 1), dim3(256), 0, s, dwp, groups, elems, groups, elems * (size_t)per);
     return hipGetLastError();
   });
 }

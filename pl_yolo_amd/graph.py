@@ -1164,6 +1164,13 @@ class Plan:
                 out.append((buf.value.decode(), float(ms[i]), fl.value, by.value))
         return out
 
+    def lane_times(self, stream):
+        """One eager multi-lane replay; returns [ms to the end of lane 0, lane 1, ..., ms to the join]."""
+        n = self.lanes() + 1
+        ms = (C.c_float * n)()
+        call("plyolo_plan_lane_times", self.h, stream, C.cast(ms, C.c_void_p), n)
+        return [float(v) for v in ms]
+
     def __del__(self):
         try:
             if self.h:

@@ -223,3 +223,21 @@ def test_sgd_ema():
     torch.cuda.synchronize()
     assert hu.relerr(p, ref_p.data) < 1e-6
     assert hu.relerr(ema, ema_ref) < 1e-6
+
+
+@pytest.mark.parametrize("nslab,elems", [(1, 1024), (5, 4100), (16, 9216), (100, 9216), (1024, 2304), (54, 147456), (333, 36)])
+def test_reduce_slabs(nslab, elems):
+    """slab 0 += slabs 1..n-1 through the grouped two-launch fold; the other slabs' contents are scratch."""
+    torch.manual_seed(nslab + elems)
+    slabs = torch.randn(nslab, elems, device=hu.DEV)
+    ref = slabs.double().sum(0)
+    call("plyolo_reduce_slabs", slabs.data_ptr(), nslab, elems, hu.stream())
+    torch.cuda.synchronize()
+    scale = float(ref.abs().max()) + 1e-6
+    assert float((slabs[0].double() - ref).abs().max()) <= 2e-6 * scale * max(1.0, nslab ** 0.5)
+    # deterministic: a second run on the same data gives the same bits
+    torch.manual_seed(nslab + elems)
+    slabs2 = torch.randn(nslab, elems, device=hu.DEV)
+    call("plyolo_reduce_slabs", slabs2.data_ptr(), nslab, elems, hu.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(slabs[0], slabs2[0])
