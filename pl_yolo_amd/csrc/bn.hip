@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(int M, int C, co
 #pragma unroll
         for (int i = 0; i < V; ++i) {
           const float u = fmaf(zz[i], sc[i], sh[i]);
-          const float du = d[i] * act_grad(u, act);
+          const float du = d[i] * act_grad<Vec<T>::precise>(u, act);
           s1[i] += du;
           s2[i] += du * ((zz[i] - mu[i]) * is[i]);
         }
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_dz_kernel(int M, int C, const 
 #pragma unroll
       for (int i = 0; i < V; ++i) {
         const float u = fmaf(zz[i], sc[i], sh[i]);
-        const float du = d[i] * act_grad(u, act);
+        const float du = d[i] * act_grad<Vec<T>::precise>(u, act);
         d[i] = fmaf(A[i], du, fmaf(B[i], zz[i], Cc[i]));
       }
       Vec<T>::store(dz + (size_t)m * dz_ld + c, d);
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(int M, int C, const T* __r
       Vec<T>::load(z + (size_t)m * z_ld + c, zz);
       if (accumulate) Vec<T>::load(din + (size_t)m * di_ld + c, o);
 #pragma unroll
-      for (int i = 0; i < V; ++i) d[i] = d[i] * act_grad(zz[i], act) + (accumulate ? o[i] : 0.f);
+      for (int i = 0; i < V; ++i) d[i] = d[i] * act_grad<Vec<T>::precise>(zz[i], act) + (accumulate ? o[i] : 0.f);
       Vec<T>::store(din + (size_t)m * di_ld + c, d);
     }
   }
@@ -345,7 +345,11 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(int M, int C, const T* __r
 inline int stream_grid(int M, int cvn) {
   const int cols = cvn < 256 ? cvn : 256, rpb = 256 / cols;
   int g = (M + rpb - 1) / rpb;
-  if (g > 1024) g = 1024;
+  // measured (tools/bench_bn.py): 2048 workgroups stream 5-8 % faster on tensors of 50 MB and more, 1024 is better
+  // below (each workgroup pays the slot-sum prologue)
+  static const int cap_env = getenv("PLYOLO_BN_GRID") ? atoi(getenv("PLYOLO_BN_GRID")) : 0;
+  const int cap = cap_env > 0 ? cap_env : ((double)M * cvn * 16.0 >= 48.0e6 ? 2048 : 1024);
+  if (g > cap) g = cap;
   return g < 1 ? 1 : g;
 }
 

@@ -39,7 +39,7 @@ template <> struct ActT<float> {
 
 DEVINL float act_fwd(float u, int act) {
   switch (act) {
-    case PLYOLO_ACT_SILU: return u / (1.0f + __expf(-u));
+    case PLYOLO_ACT_SILU: return u * __builtin_amdgcn_rcpf(1.0f + __expf(-u));  // hardware exp2 / rcp (1 ulp): bf16 storage path
     case PLYOLO_ACT_RELU: return u > 0.f ? u : 0.f;
     case PLYOLO_ACT_LRELU: return u > 0.f ? u : 0.1f * u;
     default: return u;
@@ -53,10 +53,13 @@ DEVINL float act_fwd_precise(float u, int act) {
     default: return u;
   }
 }
+// PRECISE = libm exp + IEEE divide (fp32 parity mode); otherwise the hardware exp2 / rcp instructions (1 ulp),
+// whose error vanishes under the bf16 rounding of the stored gradient
+template <bool PRECISE = true>
 DEVINL float act_grad(float u, int act) {
   switch (act) {
     case PLYOLO_ACT_SILU: {
-      float s = 1.0f / (1.0f + expf(-u));
+      const float s = PRECISE ? 1.0f / (1.0f + expf(-u)) : __builtin_amdgcn_rcpf(1.0f + __expf(-u));
       return s * (1.0f + u * (1.0f - s));
     }
     case PLYOLO_ACT_RELU: return u > 0.f ? 1.f : 0.f;
