@@ -407,6 +407,45 @@ __global__ void pack_weights_kernel(const plyolo_pack_entry* table) {
   constexpr bool FRAG = sizeof(T) == 2;
   const int nkb_f = (e.Cin_p + 15) / 16, nnb_f = (e.Cout_total + 31) / 32;
   const int nkb_d = (e.Cout_total + 15) / 16, nnb_d = (e.Cin_p + 31) / 32;
+  if (FRAG && (e.co_off & 7) == 0) {
+    // one 16-byte fragment chunk (8 consecutive j) per thread.  fwd chunk (co, kb, h, t): ci = kb*16 + h*8 + j
+    const int nck = nkb_f * 2;
+    const int nfw = e.Cout * nck * taps;
+    for (int idx = blockIdx.y * blockDim.x + threadIdx.x; idx < nfw; idx += gridDim.y * blockDim.x) {
+      const int t = idx % taps, ck = (idx / taps) % nck, co = idx / (taps * nck);
+      const int kb = ck >> 1, h = ck & 1, ci0 = kb * 16 + h * 8, cot = e.co_off + co;
+      const float* src = e.w + ((size_t)co * e.Cin + ci0) * taps + t;
+      float f[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = ci0 + j < e.Cin ? src[(size_t)j * taps] : 0.f;
+      u32x4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = pack2bf(f[2 * j], f[2 * j + 1]);
+      *(u32x4*)((bf16_t*)e.wp + (((size_t)t * nnb_f + (cot >> 5)) * nkb_f + kb) * 512 + (h * 32 + (cot & 31)) * 8) = v;
+    }
+    if (wpd) {
+      // dgrad chunk (ci, kbd, h, t): cot = kbd*16 + h*8 + j, restricted to this entry's rows
+      const int c8 = (e.Cout + 7) / 8;
+      const int ndg = e.Cin_p * c8 * taps;
+      for (int idx = blockIdx.y * blockDim.x + threadIdx.x; idx < ndg; idx += gridDim.y * blockDim.x) {
+        const int t = idx % taps, ci = (idx / taps) % e.Cin_p, g8 = idx / (taps * e.Cin_p);
+        const int co0 = g8 * 8, cot0 = e.co_off + co0;
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (ci < e.Cin && co0 + j < e.Cout) ? e.w[((size_t)(co0 + j) * e.Cin + ci) * taps + t] : 0.f;
+        u32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = pack2bf(f[2 * j], f[2 * j + 1]);
+        const int kb = cot0 >> 4, h = (cot0 >> 3) & 1;
+        bf16_t* dst = (bf16_t*)e.wpd + (((size_t)t * nnb_d + (ci >> 5)) * nkb_d + kb) * 512 + (h * 32 + (ci & 31)) * 8;
+        if (co0 + 8 <= e.Cout) {
+          *(u32x4*)dst = v;
+        } else {  // the next entry of a merged conv (or the zero pad) owns the rest of this chunk
+          for (int j = 0; co0 + j < e.Cout; ++j) dst[j] = f2bf(f[j]);
+        }
+      }
+    }
+  } else
   for (int idx = blockIdx.y * blockDim.x + threadIdx.x; idx < nf; idx += gridDim.y * blockDim.x) {
     const int ci = idx % e.Cin_p;
     const int co = (idx / e.Cin_p) % e.Cout;
@@ -461,20 +500,21 @@ __global__ void unpack_wgrads_kernel(const plyolo_pack_entry* table, int accumul
   const plyolo_pack_entry e = table[blockIdx.x];
   if (!e.dw) return;
   const int taps = e.ksize * e.ksize;
-  // walk the PACKED index space so that the nslab partial slabs are read coalesced; the
-  // permuted OIHW store is the strided side (|dW| bytes once)
-  const int slab = taps * e.Cout_total * e.Cin_p;
-  for (int idx = blockIdx.y * blockDim.x + threadIdx.x; idx < slab; idx += gridDim.y * blockDim.x) {
-    const int ci = idx % e.Cin_p;
-    const int row = (idx / e.Cin_p) % e.Cout_total;
-    const int t = idx / (e.Cin_p * e.Cout_total);
-    const int co = row - e.co_off;
-    if (ci >= e.Cin || co < 0 || co >= e.Cout) continue;
-    float g = 0.f;
-#pragma unroll 8
-    for (int sl = 0; sl < e.nslab; ++sl) g += e.dwp[(size_t)sl * slab + idx];  // fixed order: deterministic
-    float* dst = e.dw + ((size_t)co * e.Cin + ci) * taps + t;
-    *dst = (accumulate ? *dst : 0.f) + g;
+  // one thread per (co, ci): the slab reads are coalesced along ci for every tap, and the thread's taps are
+  // CONSECUTIVE floats of the OIHW gradient, so neighbouring threads store one contiguous run (a thread per
+  // packed element stored 4 bytes every 36)
+  const size_t plane = (size_t)e.Cout_total * e.Cin_p;
+  const size_t slab = (size_t)taps * plane;
+  const int n2 = e.Cout * e.Cin;
+  for (int idx = blockIdx.y * blockDim.x + threadIdx.x; idx < n2; idx += gridDim.y * blockDim.x) {
+    const int ci = idx % e.Cin, co = idx / e.Cin;
+    const float* src = e.dwp + (size_t)(e.co_off + co) * e.Cin_p + ci;
+    float* dst = e.dw + (size_t)idx * taps;
+    for (int t = 0; t < taps; ++t) {
+      float g = 0.f;
+      for (int sl = 0; sl < e.nslab; ++sl) g += src[(size_t)sl * slab + (size_t)t * plane];  // fixed order: deterministic
+      dst[t] = (accumulate ? dst[t] : 0.f) + g;
+    }
   }
   if (e.db && blockIdx.y == 0)
     for (int i = threadIdx.x; i < e.Cout; i += blockDim.x) e.db[i] = (accumulate ? e.db[i] : 0.f) + e.dbp[e.co_off + i];
@@ -497,6 +537,44 @@ __global__ void bias_grad_kernel(const T* dy, int M, int C, int ld, float* db) {
     if (trow == 0 && c < C) {
       for (int k = 1; k < rg; ++k) s += red[k * cols + tcol];
       atomicAdd(db + c, s);
+    }
+  }
+}
+
+// same sums with 16-byte row vectors (column-fixed threads); needs ld % V == 0 and the padded columns inside the row
+template <typename T>
+__global__ __launch_bounds__(256) void bias_grad_vec_kernel(const T* __restrict__ dy, int M, int C, int ld, float* db) {
+  constexpr int V = Vec<T>::N;
+  __shared__ float red[256 * V];
+  const int cvn = (C + V - 1) / V;
+  const int cols = cvn < 256 ? cvn : 256, rg = 256 / cols;
+  const int tcol = threadIdx.x % cols, trow = threadIdx.x / cols;
+  for (int cv0 = 0; cv0 < cvn; cv0 += cols) {
+    const int cv = cv0 + tcol;
+    float s[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) s[i] = 0.f;
+    if (trow < rg && cv < cvn) {
+#pragma unroll 4
+      for (int m = blockIdx.x * rg + trow; m < M; m += gridDim.x * rg) {
+        float f[V];
+        Vec<T>::load(dy + (size_t)m * ld + cv * V, f);
+#pragma unroll
+        for (int i = 0; i < V; ++i) s[i] += f[i];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < V; ++i) red[threadIdx.x * V + i] = s[i];
+    __syncthreads();
+    // column sums by cols*V threads in parallel (one thread summing all row groups serialised up to 2040 LDS reads)
+    for (int j = threadIdx.x; j < cols * V; j += 256) {
+      const int col = j / V, i = j - col * V, c = (cv0 + col) * V + i;
+      if (cv0 + col < cvn && c < C) {
+        float t = 0.f;
+        for (int k = 0; k < rg; ++k) t += red[(k * cols + col) * V + i];
+        atomicAdd(db + c, t);
+      }
     }
   }
 }
@@ -788,6 +866,15 @@ int plyolo_bias_grad(int dtype, const void* dy, int M, int C, int ld, float* dbi
   return submit(stream, [=](hipStream_t s) -> hipError_t {
     hipError_t e = plyolo::fill_async(dbias, 0, (size_t)C * 4, s);
     if (e != hipSuccess) return e;
+    const int V = dtype == PLYOLO_BF16 ? 8 : 4;
+    const int cvn = (C + V - 1) / V;
+    if (ld % V == 0 && cvn * V <= ld && ((uintptr_t)dy & 15) == 0) {
+      // few, fat workgroups: every workgroup ends with C same-address atomics
+      long nb = (long)M * cvn / 2048;
+      nb = nb < 1 ? 1 : (nb > 512 ? 512 : nb);
+      DISPATCH_T(dtype, hipLaunchKernelGGL(bias_grad_vec_kernel<T>, dim3((unsigned)nb), dim3(256), 0, s, (const T*)dy, M, C, ld, dbias);)
+      return hipGetLastError();
+    }
     int nb = M / 64;
     if (nb < 1) nb = 1;
     if (nb > 1024) nb = 1024;
