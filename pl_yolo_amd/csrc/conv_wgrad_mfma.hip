@@ -263,13 +263,15 @@ static WgPlan plan_wgrad(const plyolo_conv_desc* d) {
   p.nci = (p.Cin + w.CI_T - 1) / w.CI_T;
   const int nco = (p.Cout + w.CO_T - 1) / w.CO_T;
   // spatial split: a few workgroups per CU; every split writes a private fp32 slab (S*WK*|dW|
-  // bytes stored once and read once by the unpack pass), capped at ~32 MB and 1024 slabs per layer
+  // bytes stored once and read once by the unpack pass), capped at ~20 MB and 1024 slabs per layer
   const double dw_bytes = 4.0 * d->ksize * d->ksize * (double)d->Cout * d->Cin;
   int target = 768;  // workgroups per launch (3 per CU)
   if (const char* e = getenv("PLYOLO_WG_TARGET")) { const int v = atoi(e); if (v >= 64) target = v; }
   int S = target / (nco * p.nci * w.WK);
   if (S * w.WK > 1024) S = 1024 / w.WK;
-  const int s_budget = (int)(32.0e6 / (dw_bytes * w.WK));
+  double budget = 20.0e6;  // measured on the whole step (8 / 12 / 16 / 20 / 24 / 32 / 64 MB): slab stores + folds compete with the main lane for HBM
+  if (const char* e = getenv("PLYOLO_WG_BUDGET_MB")) { const double v = atof(e); if (v >= 1.0) budget = v * 1.0e6; }
+  const int s_budget = (int)(budget / (dw_bytes * w.WK));
   if (S > s_budget) S = s_budget;
   if (S < 1) S = 1;
   if (S > p.ntiles) S = p.ntiles;
