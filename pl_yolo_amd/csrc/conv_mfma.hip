@@ -400,17 +400,30 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
 
   if (abl & 128) return;
   if (OUT_F32) {
+    // fp32 rows (the raw head maps, pitch 5+C floats) are only 4-byte aligned: dwordx4 stores with a 4-byte
+    // aligned type (global memory takes them) instead of one dword per thread and iteration
+    typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
     float* y = (float*)p.y;
-    for (int idx = tid; idx < BM * BN; idx += 256) {
-      const int m = idx / BN, c = idx - m * BN;
-      const int a = oy0 + (m >> 4), b = ox0 + (m & 15), co = cout0 + c;
+    constexpr int VPR4 = BN / 4;
+    for (int idx = tid; idx < BM * VPR4; idx += 256) {
+      const int m = idx / VPR4, v = idx - m * VPR4;
+      const int a = oy0 + (m >> 4), b = ox0 + (m & 15), co = cout0 + v * 4;
       if (a < p.OHt && b < p.OWt && co < p.Cout) {
         const int oy = a * p.so + p.oy_off, ox = b * p.so + p.ox_off;
-        float v = *(const float*)(smem + m * SROW + c * 4);
-        if (p.bias) v += p.bias[co];
+        f32x4 val = *(const f32x4*)(smem + m * SROW + v * 16);
         float* dst = y + ((size_t)(n * p.OHf + oy) * p.OWf + ox) * p.y_ld + co;
-        if (p.accumulate) v += *dst;
-        *dst = v;
+        if (co + 4 <= p.Cout) {
+          if (p.bias) val += *(const f32x4_u*)(p.bias + co);
+          if (p.accumulate) val += *(const f32x4_u*)dst;
+          *(f32x4_u*)dst = val;
+        } else {
+          for (int j = 0; co + j < p.Cout; ++j) {
+            float t = val[j];
+            if (p.bias) t += p.bias[co + j];
+            if (p.accumulate) t += dst[j];
+            dst[j] = t;
+          }
+        }
       }
     }
   } else {
