@@ -573,13 +573,22 @@ void pick_tiles(const ConvP& p, int ext_y, bool out_f32, int* BN, int* CK, int* 
   int bn = p.Cout > 64 ? 128 : (p.Cout > 32 ? 64 : 32);
   if (out_f32 && bn > 64) bn = 64;
   int ck = p.Cin >= 64 ? 64 : (p.Cin >= 32 ? 32 : 16);
-  int th = p.OHt > 8 ? 16 : 8;
+  // Measured per layer INSIDE the training step (bench.py --profile-out under PLYOLO_FORCE_*; the stand-alone
+  // microbenchmark is misleading here: its operands sit in the 256 MB Infinity Cache): the 8x16 tile beats the 16x16
+  // tile on every layer with 64+ output channels -- 3 instead of 2 workgroups per CU, double-buffered halo, finer
+  // tail -- and on the large maps (M >= 150k positions: HBM-bound 1x1 layers, the 80x80 head) 32-channel chunks
+  // beat 64 (3x3 128->128 @80x80: 82.7 -> 79.2 us, 1x1 128->128 @80x80: 43.5 -> 37.0 us, 1x1 64->64 @160x160:
+  // 76 -> 56 us).  Only the 32-output-channel layers (160x160 / 320x320 maps) keep the 16-row tile.
+  const double Mpos = (double)p.N * p.OHt * p.OWt;
+  int th = (p.OHt > 8 && bn == 32) ? 16 : 8;
   if (p.si == 2) th = 8;  // stride-2 halo tile: 17 x 33 pixels
   if (p.si == 2 && ext_y > 1 && ck > 32) ck = 32;
-  // few tiles: prefer the small tile so that the launch still spreads over the CUs
-  const long tiles16 = (long)p.N * ((p.OHt + 15) / 16) * ((p.OWt + TW - 1) / TW) * ((p.Cout + bn - 1) / bn);
-  if (th == 16 && tiles16 < 384) th = 8;
-  if (th == 8 && p.si == 1 && p.Cin == 128 && !out_f32 && bn >= 64 && getenv("PLYOLO_NO_CK128") == nullptr) ck = 128;
+  // ... and 32-channel chunks everywhere: on the small maps 64/128-channel chunks are 1-3 us faster per launch when
+  // timed alone, but the whole step is 2-3 % faster with 32 -- the backward runs the weight-gradient lane beside
+  // this kernel, and the lighter workgroup (148 VGPRs, 20 KB of halo buffers) leaves it more of each CU
+  static const int ck_mode = getenv("PLYOLO_CK_MODE") ? atoi(getenv("PLYOLO_CK_MODE")) : 0;  // 1: 64/128 on small maps
+  if (p.si == 1 && ck > 32 && (ck_mode == 0 || (bn >= 64 && Mpos >= 150.0e3))) ck = 32;
+  if (ck_mode == 1 && th == 8 && p.si == 1 && p.Cin == 128 && !out_f32 && bn >= 64 && ck == 64) ck = 128;
   // the 16-row tile double-buffers its halo only with 32-channel chunks (two 64-channel buffers leave no LDS for a second workgroup)
   if (th == 16 && p.si == 1 && ck == 64 && !out_f32 && p.db >= 2) ck = 32;
   if (const char* e = getenv("PLYOLO_FORCE_CK")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) ck = v < ck ? v : ck; }
