@@ -137,7 +137,10 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
   const bf16_t* wlane = p.w + ((size_t)(nb_ok ? nb : p.nnb - 1) * p.nkb) * 512 + lane * 8;
   const size_t wtap = (size_t)p.nnb * p.nkb * 512;
 
-  u32x4 bcur[KS], bnext[KS];
+  // weight fragments in flight: PD taps ahead.  PD = 2 on the 32-channel double-buffered variant (a tap there is only
+  // 256 cycles of MFMA) measured 1.5 % SLOWER on the whole step (+8 VGPRs, same occupancy), so one tap it stays
+  constexpr int PD = 1;
+  u32x4 bq[PD + 1][KS];
   // Branch-free: the loads are ALWAYS issued (from a clamped, valid fragment).  With the loads inside `if`s the
   // compiler cannot count the outstanding ones and emits s_waitcnt vmcnt(0) at the top of every tap -- which
   // also waits for the prefetch it has just issued.
@@ -155,7 +158,8 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
   };
 
   constexpr int abl = ABL;  // compile-time diagnostics switch (see ConvP::ablate)
-  load_b(0, bcur);
+  load_b(0, bq[0]);
+  if (PD == 2) load_b(total > 1 ? 1 : 0, bq[1]);
 
   // ---- halo-tile loader.  The (pixel, channel-vector) -> (global offset, LDS offset) mapping of a thread's
   // vectors is the same for every Cin chunk, so it is computed ONCE per tile: in-kernel stamps showed the halo
@@ -233,7 +237,7 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
   auto run_tap = [&](const int t, const int boff, auto&& extra_loads) {
     // unconditional (the last tap re-loads its own fragments): a branch around the loads makes the waitcnt
     // insertion fall back to vmcnt(0) at the join
-    if (!(abl & 16)) load_b(phase + 1 < total ? phase + 1 : phase, bnext);
+    if (!(abl & 16)) load_b(phase + PD < total ? phase + PD : total - 1, bq[PD]);
     extra_loads();
     // keep the prefetch ABOVE the MFMA block: left alone, the scheduler sinks these loads to the end of the tap
     // (shorter live range) where the next tap's s_waitcnt vmcnt(0) exposes their full latency
@@ -248,7 +252,7 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
     for (int mt = 0; mt < MT; ++mt) a[mt] = *(const bf16x8*)(smem + arow[mt] + toff);
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
-      const bf16x8 b = *(const bf16x8*)&bcur[kk];
+      const bf16x8 b = *(const bf16x8*)&bq[0][kk];
       if (PIPE && kk + 1 < KS) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) an[PIPE ? mt : 0] = *(const bf16x8*)(smem + arow[mt] + toff + (kk + 1) * 32);
@@ -270,7 +274,10 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
       }
     }
 #pragma unroll
-    for (int kk = 0; kk < KS; ++kk) bcur[kk] = bnext[kk];
+    for (int kk = 0; kk < KS; ++kk) {
+#pragma unroll
+      for (int d = 0; d < PD; ++d) bq[d][kk] = bq[d + 1][kk];
+    }
     ++phase;
   };
 
