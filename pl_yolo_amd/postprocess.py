@@ -55,3 +55,52 @@ def postprocess(predictions, conf_thre=0.7, nms_thre=0.45, class_agnostic=False)
     det, count = postprocess_device(predictions, conf_thre, nms_thre, class_agnostic)
     counts = count.tolist()  # the only host sync
     return [det[i, :n] if n > 0 else None for i, n in enumerate(counts)]
+
+
+def format_outputs(outputs, ids, hws, val_size, class_ids, labels=None):
+    """Detections -> (COCO json records, per-image per-class VOC arrays), the reference's
+    `format_outputs(outputs, ids, hws, val_size, class_ids, labels)`
+    (reference models/evaluators/postprocess.py:95-138, models/utils/bbox.py:58-63; called from
+    PL_Modules/pl_detection.py:78,132 right after `postprocess`).
+
+    Same results and the same side effect (the boxes of `outputs[i]` are rescaled IN PLACE to the original
+    image, postprocess.py:112-113), but the device is touched once per image for the rescale (asynchronous) and
+    ONCE per batch for the device->host copy; the reference copies every box, score and class mask to the host
+    separately (postprocess.py:125-126,136), i.e. thousands of blocking copies per validation batch.
+    """
+    import numpy as np
+    n_cls = len(class_ids)
+    det_list = [[np.empty(shape=[0, 5]) for _ in range(n_cls)] for _ in range(len(outputs))]
+    live = []
+    for i, (output, img_h, img_w, img_id) in enumerate(zip(outputs, hws[0], hws[1], ids)):
+        if output is None:
+            continue
+        scale = min(val_size[0] / float(img_w), val_size[1] / float(img_h))
+        output[:, 0:4] /= scale  # in place, like the reference (fp32 tensor / python float)
+        live.append((i, int(img_id), output))
+    if not live:
+        return [], det_list
+    host = torch.cat([o for _, _, o in live], 0).detach().to("cpu", torch.float32).numpy()  # the only device->host copy
+    json_list = []
+    row = 0
+    for i, img_id, output in live:
+        n = output.shape[0]
+        d = host[row:row + n]
+        row += n
+        xywh = d[:, 0:4].copy()
+        xywh[:, 2] = d[:, 2] - d[:, 0]
+        xywh[:, 3] = d[:, 3] - d[:, 1]
+        clses = d[:, 5]
+        boxes = xywh.tolist()
+        scores = d[:, 4].tolist()
+        for k in range(n):
+            json_list.append({
+                "image_id": img_id,
+                "category_id": class_ids[int(clses[k])],
+                "bbox": boxes[k],
+                "score": scores[k],
+                "segmentation": [],
+            })
+        for c in range(n_cls):
+            det_list[i][c] = d[clses == c, 0:5].copy()
+    return json_list, det_list

@@ -234,3 +234,63 @@ def test_batched_nms_entry():
         keep = onms.batched_nms(bb[:, :4], bb[:, 4], bb[:, 5], 0.65)[:300]
         assert int(cnt[b]) == len(keep)
         np.testing.assert_array_equal(det[b, :len(keep)].cpu().numpy(), bb[keep])
+
+
+def test_format_outputs_device_vs_oracle():
+    """format_outputs on device detections (one D2H copy) == the box-by-box restatement of
+    postprocess.py:95-138 on the same numbers, including the in-place rescale of the caller's tensors."""
+    import copy, time
+    from oracle import formatting as ofmt
+    from pl_yolo_amd.postprocess import format_outputs
+    gen = torch.Generator().manual_seed(31)
+    n_cls, B = 80, 16
+    outs = []
+    for b in range(B):
+        n = [300, 0, 57, 1][b % 4]
+        if n == 0:
+            outs.append(None)
+            continue
+        xy = torch.rand(n, 2, generator=gen) * 500
+        wh = torch.rand(n, 2, generator=gen) * 120 + 1
+        outs.append(torch.cat([xy, xy + wh, torch.rand(n, 1, generator=gen), torch.randint(0, n_cls, (n, 1), generator=gen).float()], 1))
+    ids = list(range(100, 100 + B))
+    hws = ([480 + 10 * b for b in range(B)], [640 - 7 * b for b in range(B)])
+    class_ids = list(range(1, n_cls + 1))
+    ref_in = copy.deepcopy(outs)
+    dev_in = [o.to(hu.DEV) if o is not None else None for o in outs]
+    t0 = time.perf_counter()
+    js_a, det_a = ofmt.format_outputs(ref_in, ids, hws, (640, 640), class_ids, None)
+    t1 = time.perf_counter()
+    js_b, det_b = format_outputs(dev_in, ids, hws, (640, 640), class_ids, None)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    # for the record: the reference's access pattern on DEVICE tensors (one blocking copy per box and per score,
+    # postprocess.py:125-126) against the batched copy, both warm
+    dev2 = [o.to(hu.DEV) if o is not None else None for o in outs]
+    dev3 = [o.to(hu.DEV) if o is not None else None for o in outs]
+    torch.cuda.synchronize()
+    t3 = time.perf_counter()
+    format_outputs(dev2, ids, hws, (640, 640), class_ids, None)
+    t4 = time.perf_counter()
+    nbox = 0
+    for o in dev3:
+        if o is None:
+            continue
+        for k in range(o.shape[0]):
+            o[k, 0:4].cpu().numpy().tolist(); o[k, 4].cpu().numpy().item(); nbox += 1
+    t5 = time.perf_counter()
+    print("format_outputs, %d boxes on the device: batched copy %.2f ms, box-by-box copies (reference pattern) %.1f ms"
+          % (nbox, (t4 - t3) * 1e3, (t5 - t4) * 1e3))
+    # torch divides a device tensor by a python scalar as a multiplication by its reciprocal, the CPU kernel divides:
+    # the rescaled corners may differ in the last fp32 bit (the reference inherits the same torch behaviour on
+    # whichever device its detections live).  Everything else is exact.
+    assert len(js_a) == len(js_b)
+    for a, b in zip(js_a, js_b):
+        assert {k: v for k, v in a.items() if k != "bbox"} == {k: v for k, v in b.items() if k != "bbox"}
+        np.testing.assert_allclose(np.array(b["bbox"]), np.array(a["bbox"]), rtol=0, atol=2e-4)
+    for ra, rb in zip(det_a, det_b):
+        for x, y in zip(ra, rb):
+            assert x.dtype == y.dtype and x.shape == y.shape
+            np.testing.assert_allclose(y, x, rtol=3e-7, atol=0)
+    for x, y in zip(ref_in, dev_in):
+        assert (x is None and y is None) or bool(torch.allclose(x, y.cpu(), rtol=3e-7, atol=0))

@@ -81,3 +81,66 @@ def test_postprocess_contract():
     # max_det cap
     out = onms.postprocess(p, 0.0, 1.0, max_det=10)
     assert out[0].shape[0] == 10
+
+
+def _rand_dets(seed, counts, n_cls):
+    import torch
+    gen = torch.Generator().manual_seed(seed)
+    outs = []
+    for n in counts:
+        if n is None:
+            outs.append(None)
+            continue
+        xy = torch.rand(n, 2, generator=gen) * 500
+        wh = torch.rand(n, 2, generator=gen) * 120 + 1
+        conf = torch.rand(n, 1, generator=gen)
+        cls = torch.randint(0, n_cls, (n, 1), generator=gen).float()
+        outs.append(torch.cat([xy, xy + wh, conf, cls], 1))
+    return outs
+
+
+def test_format_outputs_hand_case():
+    """postprocess.py:95-138 on numbers worked out by hand: a 480x640 (h x w) image letterboxed into 640x640
+    has scale min(640/640, 640/480) = 1.0; a 960x1280 image has scale 0.5."""
+    import torch
+    from oracle import formatting as ofmt
+    outs = [torch.tensor([[10.0, 20.0, 110.0, 220.0, 0.9, 2.0], [0.0, 0.0, 50.0, 40.0, 0.25, 0.0]]),
+            None,
+            torch.tensor([[100.0, 50.0, 300.0, 250.0, 0.5, 1.0]])]
+    ids, hws = [7, 8, 9], ([480, 480, 960], [640, 640, 1280])
+    class_ids = [1, 2, 3]
+    js, det = ofmt.format_outputs(outs, ids, hws, (640, 640), class_ids, None)
+    assert js == [
+        {"image_id": 7, "category_id": 3, "bbox": [10.0, 20.0, 100.0, 200.0], "score": 0.8999999761581421, "segmentation": []},
+        {"image_id": 7, "category_id": 1, "bbox": [0.0, 0.0, 50.0, 40.0], "score": 0.25, "segmentation": []},
+        {"image_id": 9, "category_id": 2, "bbox": [200.0, 100.0, 400.0, 400.0], "score": 0.5, "segmentation": []},
+    ]
+    assert det[1][0].shape == (0, 5) and det[1][0].dtype == np.float64      # untouched default (postprocess.py:103)
+    np.testing.assert_array_equal(det[0][2], np.array([[10.0, 20.0, 110.0, 220.0, 0.9]], dtype=np.float32))
+    np.testing.assert_array_equal(det[2][1], np.array([[200.0, 100.0, 600.0, 500.0, 0.5]], dtype=np.float32))
+    assert det[0][1].shape == (0, 5) and det[0][1].dtype == np.float32
+    # the reference rescales the caller's tensors in place (:112-113)
+    assert outs[2][0, :4].tolist() == [200.0, 100.0, 600.0, 500.0]
+
+
+def test_format_outputs_product_vs_oracle_cpu():
+    """pl_yolo_amd.postprocess.format_outputs (one batched device->host copy) == the box-by-box restatement."""
+    import copy
+    from oracle import formatting as ofmt
+    from pl_yolo_amd.postprocess import format_outputs
+    n_cls = 6
+    outs = _rand_dets(3, [17, None, 1, 300, 0], n_cls)
+    outs = [o if o is None or o.shape[0] else None for o in outs]  # postprocess returns None for empty images
+    ids = [11, 12, 13, 14, 15]
+    hws = ([480, 333, 1000, 640, 20], [640, 500, 700, 640, 20])
+    class_ids = [1, 2, 3, 5, 8, 13]
+    a_in, b_in = copy.deepcopy(outs), copy.deepcopy(outs)
+    js_a, det_a = ofmt.format_outputs(a_in, ids, hws, (640, 640), class_ids, None)
+    js_b, det_b = format_outputs(b_in, ids, hws, (640, 640), class_ids, None)
+    assert js_a == js_b
+    for ra, rb in zip(det_a, det_b):
+        for x, y in zip(ra, rb):
+            assert x.dtype == y.dtype and x.shape == y.shape
+            np.testing.assert_array_equal(x, y)
+    for x, y in zip(a_in, b_in):
+        assert (x is None and y is None) or bool((x == y).all())
