@@ -554,6 +554,64 @@ __global__ void k_bwd(const plyolo_yolox_desc d, const float* raw, const float* 
   }
 }
 
+// bf16 gradient matrices, one 16-byte vector per thread: vector 0 of a row = (d tx, d ty, d tw, d th, d obj, 0, 0, 0)
+// of the [rows,16] reg+obj matrix, vectors 1.. = 8 class channels of the [rows,cls_ld] matrix.  Same arithmetic as
+// k_bwd<true> (which stores one bf16 per thread); the row bookkeeping is done once per 8 channels.
+__global__ __launch_bounds__(256) void k_bwd_vec(const plyolo_yolox_desc d, const float* __restrict__ raw, const float* labels,
+                                                 const uint8_t* fg, const int32_t* mgt, const float* miou, const float* losses,
+                                                 const float* gout, bf16_t* d_regobj, bf16_t* d_cls, int cls_ld) {
+  const int nch = 5 + d.C;
+  const unsigned vpr = 1u + (unsigned)cls_ld / 8u;
+  const unsigned total = (unsigned)d.B * (unsigned)d.A * vpr;
+  const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const unsigned row = idx / vpr;
+  const int v = (int)(idx - row * vpr);
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < 8; ++i)
+    if (i < d.nlevels && row >= (unsigned)d.lvl_row[i]) l = i;
+  const int hw = d.lvl_h[l] * d.lvl_w[l];
+  const int rr = (int)(row - (unsigned)d.lvl_row[l]);
+  const int b = (int)((unsigned)rr / (unsigned)hw);
+  const int a = d.lvl_off[l] + (rr - b * hw);
+  const size_t ba = (size_t)b * d.A + a;
+  const float g0 = gout ? gout[0] : 1.0f;
+  const float w_iou = gout ? 5.0f * g0 + gout[1] : 5.0f, w_obj = gout ? g0 + gout[2] : 1.0f, w_cls = gout ? g0 + gout[3] : 1.0f;
+  const float nfg = losses[4];
+  const float invN = 1.0f / (nfg > 1.0f ? nfg : 1.0f);
+  const float* r = raw + (size_t)row * nch;
+  const bool f = fg[ba] != 0;
+  float g[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) g[j] = 0.f;
+  if (v == 0) {
+    g[4] = (sig_fast(r[4]) - (f ? 1.0f : 0.0f)) * invN * w_obj;
+    if (f) {
+      const float* lg = labels + ((size_t)b * d.M + mgt[ba]) * 5;
+      float xs, ys, st;
+      anchor_geom(d, a, &xs, &ys, &st);
+      float p[4] = {(r[0] + xs) * st, (r[1] + ys) * st, expf(r[2]) * st, expf(r[3]) * st};
+      float gr[4];
+      giou_loss(p, lg + 1, gr);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) g[c] = w_iou * gr[c] * ((c < 2) ? st : p[c]) * invN;
+    }
+  } else if (f) {
+    const float* lg = labels + ((size_t)b * d.M + mgt[ba]) * 5;
+    const int cls = (int)lg[0], c0 = (v - 1) * 8;
+    const float t_iou = miou[ba];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (c0 + j < d.C) g[j] = (sig_fast(r[5 + c0 + j]) - ((c0 + j == cls) ? t_iou : 0.0f)) * invN * w_cls;
+  }
+  u32x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = pack2bf(g[2 * j], g[2 * j + 1]);
+  if (v == 0) *(u32x4*)(d_regobj + (size_t)row * 16) = o;
+  else *(u32x4*)(d_cls + (size_t)row * cls_ld + (v - 1) * 8) = o;
+}
+
 // eval branch: out is BATCH-major [B,A,5+C] (the reference's return layout)
 __global__ void k_eval_decode(const plyolo_yolox_desc d, const float* raw, float* out) {
   const int nch = 5 + d.C;
@@ -685,7 +743,11 @@ int plyolo_yolox_loss_bwd(const plyolo_yolox_desc* dp, const float* raw, const f
     if (draw_f32)
       hipLaunchKernelGGL(k_bwd<false>, dim3(grid), dim3(256), 0, s, d, raw, labels, fg, matched_gt, matched_iou, losses, gout, draw_f32,
                          (bf16_t*)nullptr, (bf16_t*)nullptr, 0);
-    else
+    else if (cls_ld % 8 == 0 && cls_ld >= d.C && ((uintptr_t)d_cls & 15) == 0 && ((uintptr_t)d_regobj & 15) == 0) {
+      const size_t nvec = (size_t)d.B * d.A * (1 + cls_ld / 8);
+      hipLaunchKernelGGL(k_bwd_vec, dim3((unsigned)cdivz(nvec, 256)), dim3(256), 0, s, d, raw, labels, fg, matched_gt, matched_iou, losses,
+                         gout, (bf16_t*)d_regobj, (bf16_t*)d_cls, cls_ld);
+    } else
       hipLaunchKernelGGL(k_bwd<true>, dim3(grid), dim3(256), 0, s, d, raw, labels, fg, matched_gt, matched_iou, losses, gout,
                          (float*)nullptr, (bf16_t*)d_regobj, (bf16_t*)d_cls, cls_ld);
     return hipGetLastError();
