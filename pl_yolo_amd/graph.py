@@ -348,7 +348,7 @@ class _Branch:
         return False
 
 
-def record_ops(g, plan, ops, method):
+def record_ops(g, plan, ops, method, lanes=True):
     """Record `op.<method>()` for every op in `ops` (forward order, or reversed for the backward plan)
     with the fork / join events of the regions they belong to.  Inside a region the branches are issued
     round-robin (lane 0 first): the branches are independent, so any interleaving that keeps each lane's
@@ -356,7 +356,7 @@ def record_ops(g, plan, ops, method):
     i, n = 0, len(ops)
     while i < n:
         op = ops[i]
-        r = op.region
+        r = op.region if lanes else None
         if r is None:
             plan.lane(0)
             getattr(op, method)()

@@ -163,7 +163,11 @@ class DetectorRunner:
             g.plan = s.fwd
             call("plyolo_pack_weights", g.pack_table.data_ptr(), g.n_pack, g.dtype, g.max_pack_elems, None)
             g.zero_fwd_stats()
-            G.record_ops(g, s.fwd, g.ops, "fwd")
+            # PLYOLO_FWD_LANES=0 records the forward on one lane, which then replays as ONE hipGraph: measured 2 %
+            # slower than the eager replay with the head levels side by side (a dependent launch costs ~1.8 us in a
+            # graph against ~5 us eagerly for EMPTY kernels, tools/micro/graph_floor.hip, but behind real kernels the
+            # command processor has the next dispatch ready either way)
+            G.record_ops(g, s.fwd, g.ops, "fwd", lanes=os.environ.get("PLYOLO_FWD_LANES", "1") != "0")
         s.bwd = None
         s.used_params = []
         if mode in ("train", "maps_grad"):
