@@ -56,6 +56,10 @@ static int check_conv(const plyolo_conv_desc* d, const char* who, bool fwd) {
     PLY_CHECK_ARG(d->Cin % 8 == 0 && d->x_ld % 8 == 0, "%s: bf16 path needs Cin and x_ld multiples of 8 (Cin %d, x_ld %d)", who, d->Cin, d->x_ld);
     if (fwd && !d->y_f32) PLY_CHECK_ARG(d->Cout % 8 == 0 && d->y_ld % 8 == 0, "%s: bf16 output needs Cout and y_ld multiples of 8 (Cout %d, y_ld %d)", who, d->Cout, d->y_ld);
     if (!fwd) PLY_CHECK_ARG(d->y_ld % 8 == 0 && d->y_ld >= ((d->Cout + 7) & ~7), "%s: bf16 dy rows must hold Cout rounded up to 8 channels (Cout %d, y_ld %d)", who, d->Cout, d->y_ld);
+    // the MFMA kernels keep 32-bit offsets: elements within one image, bytes within one weight pack
+    const double img = (double)d->H * d->W * (d->x_ld > d->y_ld ? d->x_ld : d->y_ld);
+    const double pack = 2.0 * d->ksize * d->ksize * (double)((d->Cout + 31) / 32 * 32) * ((d->Cin + 31) / 32 * 32);
+    PLY_CHECK_ARG(img < 2147483000.0 && pack < 2147483000.0, "%s: image plane or weight pack beyond the 32-bit offsets of the bf16 kernels", who);
   }
   return 0;
 }

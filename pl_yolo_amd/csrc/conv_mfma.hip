@@ -133,33 +133,38 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
   const int nchunks = (p.Cin + CK - 1) / CK;
   const int total = nchunks * p.ntaps;
   const bool nb_ok = nb < p.nnb;
-  // fragment (tap, nb, kb): 64 lanes x 8 bf16, contiguous
-  const bf16_t* wlane = p.w + ((size_t)(nb_ok ? nb : p.nnb - 1) * p.nkb) * 512 + lane * 8;
-  const size_t wtap = (size_t)p.nnb * p.nkb * 512;
+  // fragment (tap, nb, kb): 64 lanes x 8 bf16, contiguous.  Addressing = uniform 64-bit base (SGPR pair: pack base +
+  // tap + k-block, scalar arithmetic) + a per-lane 32-bit byte offset that never changes (n-block + lane): the
+  // loads take the saddr + voffset form and cost no vector ALU work (the pack is < 2^31 bytes, checked on the host)
+  const char* wbase = (const char*)p.w;
+  const unsigned wvoff = (unsigned)((nb_ok ? nb : p.nnb - 1) * p.nkb) * 1024u + (unsigned)lane * 16u;
+  const unsigned wtapB = (unsigned)p.nnb * (unsigned)p.nkb * 1024u;
 
   // weight fragments in flight: PD taps ahead.  PD = 2 on the 32-channel double-buffered variant (a tap there is only
   // 256 cycles of MFMA) measured 1.5 % SLOWER on the whole step (+8 VGPRs, same occupancy), so one tap it stays
   constexpr int PD = 1;
   u32x4 bq[PD + 1][KS];
-  // Branch-free: the loads are ALWAYS issued (from a clamped, valid fragment).  With the loads inside `if`s the
-  // compiler cannot count the outstanding ones and emits s_waitcnt vmcnt(0) at the top of every tap -- which
-  // also waits for the prefetch it has just issued.
-  auto load_b = [&](int phase, u32x4* dst) {
-    const int chunk = phase / p.ntaps, t = phase - chunk * p.ntaps;
-    const bf16_t* wt = wlane + (size_t)(tap_code(p, t) >> 4) * wtap;
+  // The (chunk, tap) of the next prefetch is tracked incrementally (deriving it from the phase counter cost a scalar
+  // integer division -- ~20 SALU instructions -- per tap).  Past the last tap the stream parks on the last fragments:
+  // the loads stay unconditional, a branch around them makes the waitcnt insertion fall back to vmcnt(0).
+  int pf_chunk = 0, pf_t = 0;
+  auto load_b = [&](u32x4* dst) {
+    const char* wt = wbase + (size_t)((tap_code(p, pf_t) >> 4) * wtapB);
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
-      const int kb = chunk * KS + kk;
+      const int kb = pf_chunk * KS + kk;
       // No masking is needed: a k-block beyond Cin meets zero-filled halo columns (finite weights x 0 = 0), and a
       // wave whose 32-channel block lies beyond Cout only produces accumulators that the epilogue never stores.
-      const int kbc = kb < p.nkb ? kb : p.nkb - 1;
-      dst[kk] = *(const u32x4*)(wt + (size_t)kbc * 512);
+      const unsigned kbc = (unsigned)(kb < p.nkb ? kb : p.nkb - 1);
+      dst[kk] = *(const u32x4*)(wt + (size_t)(kbc * 1024u) + wvoff);
     }
+    if (pf_t + 1 < p.ntaps) ++pf_t;
+    else if (pf_chunk + 1 < nchunks) { pf_t = 0; ++pf_chunk; }
   };
 
   constexpr int abl = ABL;  // compile-time diagnostics switch (see ConvP::ablate)
-  load_b(0, bq[0]);
-  if (PD == 2) load_b(total > 1 ? 1 : 0, bq[1]);
+  load_b(bq[0]);
+  if (PD == 2) load_b(bq[1]);
 
   // ---- halo-tile loader.  The (pixel, channel-vector) -> (global offset, LDS offset) mapping of a thread's
   // vectors is the same for every Cin chunk, so it is computed ONCE per tile: in-kernel stamps showed the halo
@@ -237,7 +242,7 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
   auto run_tap = [&](const int t, const int boff, auto&& extra_loads) {
     // unconditional (the last tap re-loads its own fragments): a branch around the loads makes the waitcnt
     // insertion fall back to vmcnt(0) at the join
-    if (!(abl & 16)) load_b(phase + PD < total ? phase + PD : total - 1, bq[PD]);
+    if (!(abl & 16)) load_b(bq[PD]);
     extra_loads();
     // keep the prefetch ABOVE the MFMA block: left alone, the scheduler sinks these loads to the end of the tap
     // (shorter live range) where the next tap's s_waitcnt vmcnt(0) exposes their full latency
@@ -616,10 +621,8 @@ void set_taps(ConvP& p) {
   }
 }
 
-// choose the tiles, then derive the grid; ext = halo extent beyond (T-1)*si (per axis)
-// the halo loader keeps 32-bit element offsets per image
-bool offsets_fit(const ConvP& p) { return (double)p.H * p.W * p.x_ld < 2147483000.0; }
-
+// choose the tiles, then derive the grid; ext = halo extent beyond (T-1)*si (per axis); the 32-bit offset limits of the
+// loaders are checked at the C ABI (api.hip: check_conv)
 void apply_tiles(ConvP& p, int ext_y, int ext_x, int TH) {
   p.ITH = (TH - 1) * p.si + ext_y;
   p.ITW = (TW - 1) * p.si + ext_x;
