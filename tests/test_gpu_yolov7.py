@@ -250,3 +250,27 @@ def test_v7_with_repconv_neck_trains():
     assert torch.isfinite(out["loss"]).all()
     for n, p in model.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all(), n
+
+
+@pytest.mark.parametrize("repconv", [False, True])
+def test_v7_overfit_one_batch(repconv):
+    """60 SGD steps (Trainer: flat SGD-momentum + EMA launches) on one fixed batch drive the YOLOv7 loss down,
+    with the reference's BaseConv neck and with the optional RepConv n3/n4/n5 blocks."""
+    from pl_yolo_amd.trainer import Trainer
+    with open(os.path.join(ROOT, "configs", "model", "yolov7", "yolov7_test.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    cfg["neck"]["repconv"] = repconv
+    torch.manual_seed(3)
+    model = pl_yolo_amd.build_model(cfg, 3)
+    model.compute_dtype = "bf16"
+    model = model.to(hu.DEV)
+    x = (torch.rand(2, 3, 128, 128, generator=torch.Generator().manual_seed(2)) * 255).to(hu.DEV)
+    labels = torch.zeros(2, 6, 5)
+    labels[0, :2] = torch.tensor([[1, 40.0, 50.0, 30.0, 36.0], [0, 90.0, 70.0, 50.0, 44.0]])
+    labels[1, :1] = torch.tensor([[2, 64.0, 64.0, 80.0, 60.0]])
+    labels = labels.to(hu.DEV)
+    tr = Trainer(model, learning_rate=0.02, momentum=0.9, warmup=0.1, total_steps=400, ema=True)
+    losses = [float(tr.train_step(x, labels)["loss"].detach()) for _ in range(60)]
+    head, tail = sum(losses[:5]) / 5, sum(losses[-5:]) / 5
+    print("yolov7 overfit (repconv=%s): loss %.4f -> %.4f" % (repconv, head, tail))
+    assert all(np.isfinite(losses)) and tail < 0.8 * head
