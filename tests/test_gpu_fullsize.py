@@ -182,3 +182,39 @@ def test_nms_16x1000_properties():
     dets2 = postprocess(again, conf_thre=0.01, nms_thre=0.65)
     for d, d2 in zip(dets, dets2):
         assert torch.equal(d.cpu(), d2.cpu())
+
+
+@pytest.mark.parametrize("family,name", [("yolox", "yolox_nano"), ("yolox", "yolox_tiny"), ("yolox", "yolox_m"), ("yolox", "yolox_l"),
+                                         ("yolox", "yolox_x"), ("yolov7", "yolov7")])
+def test_every_shipped_config_steps(family, name):
+    """Every YAML of configs/model builds through build_model and runs one bf16 training step and one eval
+    forward (+ postprocess) at 256x256, batch 2: finite loss, a finite gradient for every parameter that the
+    reference trains, the reference's output shapes."""
+    from pl_yolo_amd.postprocess import postprocess
+    with open(os.path.join(ROOT, "configs", "model", family, name + ".yaml")) as f:
+        cfg = yaml.safe_load(f)
+    torch.manual_seed(96)
+    model = pl_yolo_amd.build_model(cfg, NC)
+    model.compute_dtype = "bf16"
+    model = model.to(hu.DEV).train()
+    gen = torch.Generator().manual_seed(5)
+    x = (torch.rand(2, 3, 256, 256, generator=gen) * 255).to(hu.DEV)
+    labels = torch.zeros(2, 20, 5)
+    labels[:, :6, 0] = torch.randint(0, NC, (2, 6), generator=gen).float()
+    labels[:, :6, 1:3] = 40 + torch.rand(2, 6, 2, generator=gen) * 170
+    labels[:, :6, 3:5] = 16 + torch.rand(2, 6, 2, generator=gen) * 90
+    out = model(x, labels.to(hu.DEV))
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out["loss"]).all())
+    missing = [n for n, p in model.named_parameters() if p.grad is None and ".m." not in n and not n.endswith("bn.weight") and not n.endswith("bn.bias")]
+    assert all(bool(torch.isfinite(p.grad).all()) for p in model.parameters() if p.grad is not None)
+    print(name, "loss %.4f, parameters without gradient: %d" % (float(out["loss"].detach()), sum(1 for p in model.parameters() if p.grad is None)))
+    assert not missing, missing[:5]
+    model.eval()
+    with torch.no_grad():
+        pred = model(x, torch.zeros(2, 1, 5, device=hu.DEV))
+    na = 3 if family == "yolov7" else 1
+    assert tuple(pred.shape) == (2, na * (32 * 32 + 16 * 16 + 8 * 8), 5 + NC)
+    dets = postprocess(pred, conf_thre=0.001, nms_thre=0.65)
+    assert len(dets) == 2
