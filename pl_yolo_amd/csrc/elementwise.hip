@@ -337,16 +337,43 @@ __global__ void implicit_bwd_kernel(const float* dy, const float* u, const float
 __global__ void implicit_param_grads_kernel(const float* partial, int nblk, const float* W, const float* a, const float* sdu, float* dm,
                                             float* da, float* dW, float* db, int Cout, int Cin) {
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid < Cout) {
-    float s = 0.f;
-    for (int k = 0; k < nblk; ++k) s += partial[(size_t)k * Cout + tid];
-    dm[tid] = s;
-    db[tid] = sdu[tid];
+  {
+    // dm: 8 channels x 32 partial groups per workgroup pass, folded through LDS in a fixed order (one thread per
+    // channel walking all nblk partials was a 2048-deep chain of dependent loads: 0.3 ms per head level)
+    __shared__ float red[256];
+    const int cl = threadIdx.x & 7, part = threadIdx.x >> 3;
+    for (int c0 = blockIdx.x * 8; c0 < Cout; c0 += gridDim.x * 8) {
+      const int c = c0 + cl;
+      float s = 0.f;
+      if (c < Cout)
+        for (int k = part; k < nblk; k += 32) s += partial[(size_t)k * Cout + c];
+      red[threadIdx.x] = s;
+      __syncthreads();
+      if (part == 0 && c < Cout) {
+        for (int q = 1; q < 32; ++q) s += red[q * 8 + cl];
+        dm[c] = s;
+        db[c] = sdu[c];
+      }
+      __syncthreads();
+    }
   }
-  if (tid < Cin) {
-    float s = 0.f;
-    for (int co = 0; co < Cout; ++co) s += W[(size_t)co * Cin + tid] * sdu[co];
-    da[tid] = s;
+  {
+    // da[ci] = sum_co W[co][ci] * sdu[co]: 32 input channels x 8 co-groups per workgroup pass (same reason)
+    __shared__ float red2[256];
+    const int il = threadIdx.x & 31, part = threadIdx.x >> 5;
+    for (int i0 = blockIdx.x * 32; i0 < Cin; i0 += gridDim.x * 32) {
+      const int ci = i0 + il;
+      float s = 0.f;
+      if (ci < Cin)
+        for (int co = part; co < Cout; co += 8) s += W[(size_t)co * Cin + ci] * sdu[co];
+      red2[threadIdx.x] = s;
+      __syncthreads();
+      if (part == 0 && ci < Cin) {
+        for (int q = 1; q < 8; ++q) s += red2[q * 32 + il];
+        da[ci] = s;
+      }
+      __syncthreads();
+    }
   }
   for (int idx = tid; idx < Cout * Cin; idx += gridDim.x * blockDim.x) dW[idx] += sdu[idx / Cin] * a[idx % Cin];
 }
