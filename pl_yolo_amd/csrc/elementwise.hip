@@ -6,6 +6,8 @@
 // Reference semantics: BaseConv = act(bn(conv(x))) models/layers/network_blocks.py:30-37,
 // BatchNorm2d(eps 1e-3, momentum 0.03) models/layers/normalization.py:8, Focus
 // network_blocks.py:50-65, SPP pools :144, nn.Upsample(nearest x2) necks/pafpn_csp.py:22.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -190,6 +192,66 @@ __global__ __launch_bounds__(256) void spp_pools_bwd_kernel(int H, int W, int C,
     const int dl = j == 0 ? dl0 : (j == 1 ? dl1 : dl2);
     if (dout == nullptr) continue;
     const int rad = k / 2;
+    // Window scans with a compile-time trip count (5 / 9 / 13, the SPP kernels of every shipped config): all LDS
+    // reads of a window are issued before the first compare (a data-dependent loop serialised read -> compare ->
+    // read: ~100 cycles of LDS latency x 54 reads per element).  Out-of-range taps are clamped onto the border
+    // element: a duplicate of an element already seen never wins a strict '>' -- the first maximum is unchanged.
+    // One thread = one pixel, all 8 channels of the plane in registers: 16-byte LDS vectors instead of one 2-byte
+    // read per (pixel, channel, tap) -- the element-wise form issued ~1000 LDS instructions per thread and was bound
+    // by the LDS instruction rate.
+    auto ld8 = [&](const T* q, float* f) {
+      if constexpr (sizeof(T) == 2) { Vec<T>::load(q, f); } else { Vec<T>::load(q, f); Vec<T>::load(q + 4, f + 4); }
+    };
+    auto st8 = [&](T* q, const float* f) {
+      if constexpr (sizeof(T) == 2) { Vec<T>::store(q, f); } else { Vec<T>::store(q, f); Vec<T>::store(q + 4, f + 4); }
+    };
+    auto pool = [&](auto KC) {
+      constexpr int K = decltype(KC)::value;
+      for (int p = threadIdx.x; p < HW; p += 256) {
+        const int y = p / W, x = p - y * W;
+        float best[SPP_CG];
+        int ax[SPP_CG];
+#pragma unroll
+        for (int d = 0; d < K; ++d) {
+          const int xi = min(max(x + d - K / 2, 0), W - 1);
+          float v[SPP_CG];
+          ld8(xs + (y * W + xi) * SPP_CG, v);
+#pragma unroll
+          for (int ch = 0; ch < SPP_CG; ++ch)
+            if (d == 0 || v[ch] > best[ch]) { best[ch] = v[ch]; ax[ch] = xi; }
+        }
+        st8(rv + p * SPP_CG, best);
+#pragma unroll
+        for (int ch = 0; ch < SPP_CG; ++ch) ra[p * SPP_CG + ch] = (unsigned short)ax[ch];
+      }
+      __syncthreads();
+      for (int p = threadIdx.x; p < HW; p += 256) {
+        const int y = p / W, x = p - y * W;
+        float best[SPP_CG];
+        int ay[SPP_CG];
+#pragma unroll
+        for (int d = 0; d < K; ++d) {
+          const int yi = min(max(y + d - K / 2, 0), H - 1);
+          float v[SPP_CG];
+          ld8(rv + (yi * W + x) * SPP_CG, v);
+#pragma unroll
+          for (int ch = 0; ch < SPP_CG; ++ch)
+            if (d == 0 || v[ch] > best[ch]) { best[ch] = v[ch]; ay[ch] = yi; }
+        }
+        float g[SPP_CG];
+        ld8(dout + ((size_t)n * HW + p) * dl + c0, g);
+#pragma unroll
+        for (int ch = 0; ch < SPP_CG; ++ch) {
+          const int arg = ay[ch] * W + ra[(ay[ch] * W + x) * SPP_CG + ch];
+          atomicAdd(gs + arg * SPP_CG + ch, g[ch]);
+        }
+      }
+      __syncthreads();
+    };
+    const bool vec_ok = c0 + SPP_CG <= C && dl % SPP_CG == 0 && ((size_t)dout & 15) == 0;
+    if (vec_ok && k == 5) { pool(std::integral_constant<int, 5>{}); continue; }
+    if (vec_ok && k == 9) { pool(std::integral_constant<int, 9>{}); continue; }
+    if (vec_ok && k == 13) { pool(std::integral_constant<int, 13>{}); continue; }
     for (int it = threadIdx.x; it < items; it += 256) {
       const int p = it / SPP_CG, ch = it % SPP_CG;
       const int y = p / W, x = p - y * W;
