@@ -228,7 +228,9 @@ def main():
                 "bound": "mfma" if mfma_bound else "hbm",
                 "achieved": tf if mfma_bound else gbs, "peak": PEAK_MFMA if mfma_bound else PEAK_HBM,
                 "unit": "TFLOP/s" if mfma_bound else "GB/s",
-                "frac": (tf / PEAK_MFMA) if mfma_bound else (gbs / PEAK_HBM), "traffic": traffic,
+                "frac": (tf / PEAK_MFMA) if mfma_bound else (gbs / PEAK_HBM),
+                # HBM bytes per launch from the PMC passes (a number, like `achieved` per launch), or null
+                "traffic": traffic["bytes_per_launch"] if traffic else None, "traffic_detail": traffic,
                 "achieved_tflops": tf, "achieved_gbs": gbs}
         a = ALGO.get(args.model, ALGO["yolox_s"])
         scale = (args.size / 640.0) ** 2 if args.model != "yolox_nano" else (args.size / 640.0) ** 2
