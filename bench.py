@@ -132,7 +132,10 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    # PLYOLO_BENCH_FORCE_DDP=1 (under torchrun with one rank) runs the multi-GPU code path -- RCCL init, weight
+    # broadcast, gradient all-reduce, barriers -- on a single GPU: a self-test of that path on a 1-GPU box
+    ddp_on = world > 1 or (os.environ.get("PLYOLO_BENCH_FORCE_DDP", "0") == "1" and "RANK" in os.environ)
+    if ddp_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
@@ -148,8 +151,9 @@ def main():
     model = model.to(dev).train()
     runner = model.runner()
     runner.use_graph = True if args.graph else (False if args.no_graph else "auto")
-    if world > 1:
+    if ddp_on:
         from pl_yolo_amd import ddp
+        ddp.FORCE_COLLECTIVE = world == 1
         ddp.attach(model)
     imgs, labels = synthetic(args.batch, args.size, nc, 1234 + rank)
     imgs, labels = imgs.to(dev), labels.to(dev)

@@ -8,6 +8,9 @@ import torch
 import torch.distributed as dist
 
 
+FORCE_COLLECTIVE = False   # self-test: issue the collective even in a one-rank group (bench.py PLYOLO_BENCH_FORCE_DDP)
+
+
 class GradAllReduce:
     """Averages a flat gradient buffer across ranks.  The whole model is ONE bucket
     (YOLOX-s: 36 MB): xGMI is point-to-point, so few large collectives beat many small
@@ -18,7 +21,7 @@ class GradAllReduce:
         self.world = dist.get_world_size(group)
 
     def all_reduce_(self, flat):
-        if self.world == 1:
+        if self.world == 1 and not FORCE_COLLECTIVE:
             return flat
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         flat.mul_(1.0 / self.world)

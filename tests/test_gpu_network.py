@@ -300,3 +300,19 @@ def test_overfit_one_batch(dtype):
     with torch.no_grad():
         pred = ema(x, torch.zeros(x.shape[0], 1, 5, device=hu.DEV))
     assert not bool(torch.isnan(pred[..., 4:]).any())
+
+
+def test_bench_rccl_path_single_rank():
+    """bench.py under torchrun with one rank and PLYOLO_BENCH_FORCE_DDP=1: RCCL process-group init, weight
+    broadcast, the gradient all-reduce after every backward and the barriers of the timing protocol all execute
+    on this GPU (the multi-GPU runs are the driver's; this keeps their code path from rotting)."""
+    import json, subprocess, sys
+    env = dict(os.environ, PLYOLO_BENCH_FORCE_DDP="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29531", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--batch", "4", "--size", "320", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 1 and out["value"] > 0 and np.isfinite(out["config"]["loss"])
