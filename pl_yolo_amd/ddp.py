@@ -23,8 +23,11 @@ class GradAllReduce:
     def all_reduce_(self, flat):
         if self.world == 1 and not FORCE_COLLECTIVE:
             return flat
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-        flat.mul_(1.0 / self.world)
+        if dist.get_backend(self.group) == "nccl":   # RCCL averages inside the collective: no second pass over the buffer
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
+        else:                                        # gloo (CPU tests) has no AVG
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            flat.mul_(1.0 / self.world)
         return flat
 
 
