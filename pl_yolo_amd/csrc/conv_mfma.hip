@@ -3,8 +3,9 @@
 // Replaces nn.Conv2d inside BaseConv (reference models/layers/network_blocks.py:18-26)
 // and what ATen's convolution_backward computes for its input.
 //
-// Formulation (im2col-free): one workgroup (4 waves) owns a TH x 16 tile (TH = 16 or 8) of
-// output positions x BN output channels.  Per Cin-chunk (CK channels) the input HALO tile
+// Formulation (im2col-free): one workgroup (4 waves) owns a TH x 16 tile (TH = 8, or 16 for the
+// 32-output-channel layers) of output positions x BN output channels.  Per Cin-chunk (CK = 32 channels;
+// stride-1 tiles double-buffer the chunk in LDS) the input HALO tile
 // ((TH-1)*si+ext_y) x ((16-1)*si+ext_x) pixels is staged ONCE into LDS from coalesced
 // NHWC rows; each filter tap is then a dense [TH*16 x CK] x [CK x BN] product on
 // v_mfma_f32_32x32x16_bf16 whose A fragments are the tap-shifted rows of the halo tile (no
@@ -15,7 +16,7 @@
 // global stores are whole 16-byte channel vectors; concat = strided store (y_ld).
 //
 // The same kernel serves dgrad: stride-1 dgrad is a forward conv with the tap table
-// mirrored; stride-2 dgrad is four launches, one per output parity class, each with
+// mirrored; stride-2 dgrad is four jobs of ONE launch, one per output parity class, each with
 // the 1/2/2/4 taps that reach that class (so no zero-stuffing and no atomics).
 #include <stdlib.h>
 

@@ -12,8 +12,11 @@
 // One workgroup (4 waves) owns a CO_T x CI_T slab of dW for ALL taps (9*16 fp32
 // accumulator registers per wave) and streams a strided share of the 8x16 output
 // tiles: per tile the dY tile and the X halo tile are staged once in LDS and used
-// for 8 k-steps x ntaps MFMAs.  Partial slabs from the spatial splits are combined
-// with fp32 atomics shaped as full 128-byte row segments.
+// for 8 k-steps x ntaps MFMAs.  Every spatial split writes its own PRIVATE fp32 slab (plain 128-byte
+// row stores, no atomics); plyolo_reduce_slabs folds the slabs in a fixed order right behind this launch.
+// The 3x3 variants run ONE workgroup per CU (168 VGPRs + 144 accumulator AGPRs): measured better for the
+// whole step than two register-capped workgroups, the launches are deliberately under-filled
+// (~20 MB of slabs per layer) and share the chip with the data-gradient lane.
 #include <stdlib.h>
 
 #include "common.h"
