@@ -273,6 +273,10 @@ static WgPlan plan_wgrad(const plyolo_conv_desc* d) {
   int S = target / (nco * p.nci * w.WK);
   if (S * w.WK > 1024) S = 1024 / w.WK;
   double budget = 20.0e6;  // measured on the whole step (8 / 12 / 16 / 20 / 24 / 32 / 64 MB): slab stores + folds compete with the main lane for HBM
+  // wide layers (FLOPs per operand byte k*k*Cin*Cout/(Cin+Cout) >= 1300: 320+ channels at 3x3) are MFMA-bound and sit
+  // on the critical lane of the large models (YOLOX-x: the weight-gradient lane is the longer one): they get twice
+  // the slabs so that their launches fill the chip (+3 % on YOLOX-x 1280, nothing on YOLOX-s whose widest 3x3 is 256)
+  if ((double)d->ksize * d->ksize * d->Cin * d->Cout / (double)(d->Cin + d->Cout) >= 1300.0) budget = 40.0e6;
   if (const char* e = getenv("PLYOLO_WG_BUDGET_MB")) { const double v = atof(e); if (v >= 1.0) budget = v * 1.0e6; }
   const int s_budget = (int)(budget / (dw_bytes * w.WK));
   if (S > s_budget) S = s_budget;
