@@ -463,12 +463,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvP p) {
   conv_mfma_body<BN, CK, TH, OUT_F32, ABL, DB>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 
-template <int BN, int CK, int TH>
+template <int BN, int CK, int TH, bool DB = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_jobs_kernel(const ConvJobs jobs) {
   int j = 0;
   for (int k = 1; k < 4; ++k)
     if (k < jobs.n && (int)blockIdx.x >= jobs.start[k]) j = k;
-  conv_mfma_body<BN, CK, TH, false, 0>(jobs.c[j], (int)blockIdx.x - jobs.start[j], jobs.start[j + 1] - jobs.start[j]);
+  conv_mfma_body<BN, CK, TH, false, 0, DB>(jobs.c[j], (int)blockIdx.x - jobs.start[j], jobs.start[j + 1] - jobs.start[j]);
 }
 
 template <int BN, int CK, int TH, bool OUT_F32>
@@ -558,6 +558,21 @@ hipError_t launch_jobs_inst(ConvJobs jobs, hipStream_t s) {
   }
   jobs.start[jobs.n] = total;
   auto kern = conv_mfma_jobs_kernel<BN, CK, TH>;
+  // the parity classes of a stride-2 data gradient are stride-1 tiles: same double-buffered halo as the plain launches
+  constexpr bool HAS_DB = (TH == 8 && (CK == 32 || CK == 64)) || (TH == 16 && CK == 32);
+  if constexpr (HAS_DB) {
+    bool db = true;
+    for (int j = 0; j < jobs.n; ++j) db = db && jobs.c[j].db && jobs.c[j].si == 1 && jobs.c[j].Cin > CK && !jobs.c[j].ablate;
+    if (db) {
+      for (int j = 0; j < jobs.n; ++j) {
+        ConvP& p = jobs.c[j];
+        p.bufsz = p.ITH * p.rowp;
+        const size_t m2 = 2 * (size_t)p.bufsz;
+        lds = m2 > lds ? m2 : lds;
+      }
+      kern = conv_mfma_jobs_kernel<BN, CK, TH, true>;
+    }
+  }
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
