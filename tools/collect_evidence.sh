@@ -7,7 +7,10 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace -d $R/gpurun_out/${tag}_trace -o t -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/${tag}_trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/${tag}_pmc_fetch -o p -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline > $R/gpurun_out/${tag}_pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/${tag}_pmc_write -o p -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline > $R/gpurun_out/${tag}_pmc_write.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $R/gpurun_out/${tag}_pmc_mfma -o p -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline > $R/gpurun_out/${tag}_pmc_mfma.log 2>&1
 cd $R
+python tools/rocpd_mfma_busy.py $(find gpurun_out/${tag}_pmc_mfma -name "*.db" | head -1) gpurun_out/${tag}_mfma_busy.json | head -4
+rm -rf gpurun_out/${tag}_pmc_mfma
 python tools/rocpd_stats.py $(find gpurun_out/${tag}_trace -name "*.db" | head -1) --csv gpurun_out/${tag}_kstats.csv | tail -3
 python tools/rocpd_pmc.py $(find gpurun_out/${tag}_pmc_fetch -name "*.db" | head -1) $(find gpurun_out/${tag}_pmc_write -name "*.db" | head -1) gpurun_out/${tag}_pmc.json | tail -3
 rm -rf gpurun_out/${tag}_trace gpurun_out/${tag}_pmc_fetch gpurun_out/${tag}_pmc_write
