@@ -50,40 +50,58 @@ def _fresh_state(cfg, nc):
     return onet.build_state(cfg, nc)
 
 
-def cpu_baseline(cfg, nc, size, budget_s=25.0):
-    """The oracle (port of the reference path) on the host cores, bounded sample."""
+def _thread_counts(spec):
+    """Thread counts of the CPU-baseline sweep: the oracle at batch 4 does not scale to 128 threads (oversubscribed
+    it is SLOWER than the reference on 8 cores), so the baseline reports the best of a short sweep."""
+    if spec:
+        return [int(v) for v in spec.split(",") if v]
+    n = os.cpu_count() or 1
+    return sorted({t for t in (8, 16, 32, 64) if t <= n} | {min(n, 8)})
+
+
+def cpu_baseline(cfg, nc, size, b=4, budget_s=25.0, threads=""):
+    """The oracle (port of the reference path) on the host cores, bounded sample; thread count = best of a sweep."""
     from oracle import net as onet, detector as odet
     torch.manual_seed(96)
     state = onet.build_state(cfg, nc)
-    b = 4
     imgs, labels = synthetic(b, size, nc, 1234)
-    t0 = time.time()
-    odet.train_step_grads(state, cfg, nc, imgs, labels)  # warm-up
-    warm = time.time() - t0
-    steps = max(1, min(5, int((budget_s - warm) / max(warm, 1e-3))))
-    t0 = time.time()
-    for _ in range(steps):
+    t_start = time.time()
+    odet.train_step_grads(state, cfg, nc, imgs, labels)  # warm-up (allocator, thread pool)
+    sweep, best = {}, None
+    n0 = torch.get_num_threads()
+    counts = _thread_counts(threads)
+    for i, t in enumerate(counts):
+        if time.time() - t_start > budget_s and best is not None:
+            break
+        torch.set_num_threads(t)
         odet.train_step_grads(state, cfg, nc, imgs, labels)
-    dt = (time.time() - t0) / steps
-    ref_loss = float(odet.train_step_grads(onet.build_state(cfg, nc) if False else _fresh_state(cfg, nc), cfg, nc, imgs, labels)[0]["loss"].detach())
-    return {"value": b / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port", "loss_b4": ref_loss,
-            "sample": "oracle (pure-PyTorch fp32 port of OneStageD fwd+loss+bwd), %s %dx%d, batch %d, %d timed steps after 1 warm-up"
-                      % (cfg.get("_name", "model"), size, size, b, steps)}
+        t0 = time.time()
+        out = odet.train_step_grads(state, cfg, nc, imgs, labels)
+        dt = time.time() - t0
+        sweep[t] = b / dt
+        if best is None or b / dt > best[1]:
+            best = (t, b / dt)
+    # a few more timed steps at the best count if the budget allows
+    torch.set_num_threads(best[0])
+    steps, t0 = 0, time.time()
+    while steps < 3 and (time.time() - t_start) < budget_s:
+        out = odet.train_step_grads(state, cfg, nc, imgs, labels)
+        steps += 1
+    if steps:
+        best = (best[0], max(best[1], b * steps / (time.time() - t0)))
+    ref_loss = float(odet.train_step_grads(_fresh_state(cfg, nc), cfg, nc, imgs, labels)[0]["loss"].detach())
+    torch.set_num_threads(n0)
+    return {"value": best[1], "unit": "images/sec", "cores": best[0], "kind": "port", "loss_b4": ref_loss,
+            "host_cpus": os.cpu_count(), "thread_sweep_img_per_s": {str(k): v for k, v in sweep.items()},
+            "sample": "oracle (pure-PyTorch fp32 port of OneStageD fwd+loss+bwd), %s %dx%d, batch %d, best of a %s-thread sweep "
+                      "(1 warm-up + 1 timed step each) + %d more timed steps" % (cfg.get("_name", "model"), size, size, b,
+                                                                             "/".join(str(c) for c in sweep), steps)}
 
 
-def nms_bench(device, B=16, n=1000, reps=20):
-    import ctypes as C
+def nms_boxes(B, n):
+    """SURVEY 8d set (ii): 200 cluster centres x 5 jittered copies per image -> [B, n, 6] (x1,y1,x2,y2,score,class)."""
     import numpy as np
-    from pl_yolo_amd import _lib
-    from pl_yolo_amd._lib import NmsDesc, call
-    rng = np.random.default_rng(0)
-    boxes = np.zeros((B, n, 6), np.float32)
-    for b in range(B):
-        c = np.repeat(rng.uniform(50, 1230, (n // 5, 2)), 5, 0) + rng.normal(0, 4, (n, 2))
-        wh = np.exp(rng.uniform(np.log(16), np.log(256), (n, 2)))
-        boxes[b, :, 0:2], boxes[b, :, 2:4] = c - wh / 2, c + wh / 2
-        boxes[b, :, 4] = rng.uniform(0.01, 1, n)
-        boxes[b, :, 5] = rng.integers(0, 80, n)
+    boxes = nms_boxes(B, n)
     d = NmsDesc()
     d.B, d.A, d.C, d.conf_thre, d.nms_thre, d.class_agnostic, d.max_nms, d.max_det, d.numel_threshold = B, n, 80, 0.01, 0.65, 0, 10000, 300, 20000
     wsb = _lib.lib().plyolo_postprocess_workspace(C.byref(d))
@@ -104,7 +122,75 @@ def nms_bench(device, B=16, n=1000, reps=20):
         run()
     torch.cuda.synchronize()
     ms = (time.time() - t0) * 1e3 / reps
-    return {"boxes_per_ms": B * n / ms, "ms_per_batch": ms, "batch": B, "boxes_per_image": n, "kept_mean": float(cnt.float().mean())}
+    out = {"boxes_per_ms": B * n / ms, "ms_per_batch": ms, "batch": B, "boxes_per_image": n, "kept_mean": float(cnt.float().mean())}
+    if cpu:
+        out["cpu_baseline"] = nms_cpu_baseline(boxes)
+        out["speedup_vs_cpu"] = out["boxes_per_ms"] / out["cpu_baseline"]["boxes_per_ms"]
+    return out
+
+
+# plan-profile label -> the __global__ function that launch runs (csrc/*.hip); forward, data-gradient and the
+# stride-2 parity-class jobs are all instances of conv_mfma_kernel / conv_mfma_jobs_kernel
+_KERNEL_OF = {"conv_mfma_fwd": "conv_mfma_kernel", "conv_mfma_dgrad": "conv_mfma_kernel", "conv_mfma_dgrad_s2": "conv_mfma_kernel",
+              "conv_wgrad": "conv_wgrad_kernel", "conv_pw_fwd": "conv_pw_kernel", "conv_pw_dgrad": "conv_pw_kernel"}
+
+
+def kernel_of(label):
+    base = label.split("<")[0]
+    return _KERNEL_OF.get(base, base)
+
+
+def load_pmc_traffic(args):
+    """HBM traffic per launch (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md section HBM) is collected by separate
+    rocprofv3 --pmc passes (tools/collect_evidence.sh) and committed under profiles/; it is NOT measured in this run,
+    and the entry says which build it belongs to."""
+    if (args.model, args.size, args.batch) != ("yolox_s", 640, 32):
+        return None
+    for tag in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", "%s_pmc_hbm_traffic.json" % tag)
+        try:
+            with open(path) as f:
+                pm = json.load(f)
+        except OSError:
+            continue
+        kernels = {}
+        for k, v in pm.items():
+            if isinstance(v, dict) and "read_MB_per_launch" in v:
+                kernels[{"conv_mfma": "conv_mfma_kernel", "conv_wgrad": "conv_wgrad_kernel"}.get(k, k)] = v
+        return {"kernels": kernels, "source": "profiles/%s_pmc_hbm_traffic.json" % tag, "build": pm.get("build", tag)}
+    return None
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: run torch.distributed.run as a CHILD process (one rank per
+    GPU, RCCL over xGMI), relay its output and return its exit code.  Nothing in this process touches the GPU."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()   # counting devices does not initialise HIP
+    if have < n:
+        sys.stderr.write("bench.py: --gpus %d but this node exposes %d GPU(s)\n" % (n, have))
+        return 2
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+    for l in proc.stdout.splitlines():
+        if not l.startswith("{"):
+            sys.stderr.write(l + "\n")
+    if proc.returncode != 0 or not lines:
+        sys.stderr.write("bench.py: the %d-rank run failed (exit code %d)\n" % (n, proc.returncode))
+        return proc.returncode or 1
+    out = json.loads(lines[-1])
+    if out.get("n_gpus") != n:
+        sys.stderr.write("bench.py: asked for %d GPUs, the ranks report n_gpus=%r\n" % (n, out.get("n_gpus")))
+        return 1
+    print(lines[-1])
+    return 0
 
 
 def main():
@@ -119,7 +205,13 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="replay every plan eagerly (default: single-lane plans as hipGraphs, multi-lane plans eagerly)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-out", default=None, help="write the per-launch plan profile (JSON) here")
+    ap.add_argument("--cpu-threads", default="", help="comma-separated thread counts of the CPU-baseline sweep (default: a bounded sweep up to the host's cores)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # Not under a launcher: start the N ranks ourselves.  This happens BEFORE anything touches the GPU (a process
+        # that has initialised HIP must never exec or fork GPU work), as child processes; rank 0's JSON line is relayed.
+        raise SystemExit(self_launch(args.gpus))
 
     import yaml
     import pl_yolo_amd
@@ -127,8 +219,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d is running with WORLD_SIZE=%d: launch it as\n  python -m torch.distributed.run --nnodes=1 "
+                         "--nproc-per-node %d --master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d ...\n(or plain "
+                         "`python bench.py --gpus %d`, which starts those ranks itself)" % (args.gpus, world, args.gpus, args.gpus, args.gpus))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -206,36 +300,37 @@ def main():
         nrep = len(prof)
         table = sorted(((k, v[0] / nrep, v[1] / nrep, v[2] / nrep, v[3] / nrep) for k, v in agg.items()), key=lambda r: -r[2])
         total_ms = sum(r[2] for r in table)
-        # dominant kernel = the kernel FAMILY (all template instances of one __global__ function) with the
-        # largest share of the step; roofline figures are per launch, averaged over the family's launches
+        # dominant kernel = the __global__ FUNCTION (all template instances, every role it is launched in) with the
+        # largest share of the step; roofline figures are per launch, averaged over that function's launches
         fam = {}
         for (label, cnt, ms_tot, fl_tot, by_tot) in table:
-            f = fam.setdefault(label.split("<")[0], [0.0, 0.0, 0.0, 0.0])
+            f = fam.setdefault(kernel_of(label), [0.0, 0.0, 0.0, 0.0])
             f[0] += cnt; f[1] += ms_tot; f[2] += fl_tot; f[3] += by_tot
-        label, (cnt, ms_tot, fl_tot, by_tot) = max(fam.items(), key=lambda kv: kv[1][1])
-        avg_ms = ms_tot / cnt
-        tf = fl_tot / cnt / (avg_ms * 1e-3) / 1e12
-        gbs = by_tot / cnt / (avg_ms * 1e-3) / 1e9
-        mfma_bound = (fl_tot / PEAK_MFMA / 1e12) >= (by_tot / PEAK_HBM / 1e9)
-        traffic = None
-        try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, tools/rocpd_pmc.py)
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as f:
-                pm = json.load(f)
-            key = {"conv_mfma_fwd": "conv_mfma", "conv_mfma_dgrad": "conv_mfma", "conv_mfma_dgrad_s2": "conv_mfma"}.get(label, label)
-            if args.model == "yolox_s" and args.size == 640 and args.batch == 32 and key in pm:
-                traffic = {"bytes_per_launch": (pm[key]["read_MB_per_launch"] + pm[key]["write_MB_per_launch"]) * 1e6,
-                           "algorithmic_bytes_per_launch": by_tot / cnt,
-                           "source": "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, family %s)" % key}
-        except OSError:
-            pass
-        roof = {"kernel": label, "launches_per_step": cnt, "avg_ms": avg_ms, "share_of_step": ms_tot / total_ms,
-                "bound": "mfma" if mfma_bound else "hbm",
-                "achieved": tf if mfma_bound else gbs, "peak": PEAK_MFMA if mfma_bound else PEAK_HBM,
-                "unit": "TFLOP/s" if mfma_bound else "GB/s",
-                "frac": (tf / PEAK_MFMA) if mfma_bound else (gbs / PEAK_HBM),
-                # HBM bytes per launch from the PMC passes (a number, like `achieved` per launch), or null
-                "traffic": traffic["bytes_per_launch"] if traffic else None, "traffic_detail": traffic,
-                "achieved_tflops": tf, "achieved_gbs": gbs}
+        pmc = load_pmc_traffic(args)
+
+        def fam_entry(name, v):
+            cnt, ms_tot, fl_tot, by_tot = v
+            avg_ms = ms_tot / cnt
+            tf = fl_tot / cnt / (avg_ms * 1e-3) / 1e12
+            gbs = by_tot / cnt / (avg_ms * 1e-3) / 1e9
+            mfma_bound = (fl_tot / PEAK_MFMA / 1e12) >= (by_tot / PEAK_HBM / 1e9)
+            e = {"kernel": name, "launches_per_step": cnt, "avg_ms": avg_ms, "share_of_step": ms_tot / total_ms,
+                 "bound": "mfma" if mfma_bound else "hbm",
+                 "achieved": tf if mfma_bound else gbs, "peak": PEAK_MFMA if mfma_bound else PEAK_HBM,
+                 "unit": "TFLOP/s" if mfma_bound else "GB/s",
+                 "frac": (tf / PEAK_MFMA) if mfma_bound else (gbs / PEAK_HBM),
+                 "achieved_tflops": tf, "achieved_gbs": gbs, "algorithmic_bytes_per_launch": by_tot / cnt,
+                 "traffic": None}
+            t = pmc.get("kernels", {}).get(name) if pmc else None
+            if t:  # HBM bytes per launch of this function from the rocprofv3 --pmc passes of the SAME build
+                e["traffic"] = (t["read_MB_per_launch"] + t["write_MB_per_launch"]) * 1e6
+                e["traffic_detail"] = {"read_bytes": t["read_MB_per_launch"] * 1e6, "write_bytes": t["write_MB_per_launch"] * 1e6,
+                                       "measured_in_run": False, "source": pmc.get("source"), "build": pmc.get("build")}
+            return e
+        fams = sorted((fam_entry(k, v) for k, v in fam.items()), key=lambda e: -e["share_of_step"])
+        roof = dict(fams[0])
+        roof["families"] = [{k: e[k] for k in ("kernel", "launches_per_step", "avg_ms", "share_of_step", "bound", "achieved", "unit", "frac", "traffic")}
+                            for e in fams[:8]]
         a = ALGO.get(args.model, ALGO["yolox_s"])
         scale = (args.size / 640.0) ** 2 if args.model != "yolox_nano" else (args.size / 640.0) ** 2
         t_roof = max(a["flops"] * scale * args.batch / (PEAK_MFMA * 1e12), a["bytes"] * scale * args.batch / (PEAK_HBM * 1e9))
@@ -252,7 +347,7 @@ def main():
             "metric": ("images/sec fwd+bwd YOLOX-s 640x640 bs32" if (args.model, args.size, args.batch) == ("yolox_s", 640, 32)
                        else "images/sec fwd+bwd %s %dx%d bs%d" % (args.model, args.size, args.size, args.batch)),
             "value": value, "unit": "images/sec",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "n_gpus": world, "rccl_world_size": (dist.get_world_size() if dist is not None else 1), "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "%s %dx%d, batch %d per GPU, 30 GT/img, fwd + SimOTA/loss + bwd%s" % (
                 args.model, args.size, args.size, args.batch, " + RCCL grad all-reduce" if world > 1 else ""),
@@ -262,11 +357,11 @@ def main():
             "roofline": roof,
         }
         try:
-            result["nms"] = nms_bench(dev)
+            result["nms"] = nms_bench(dev, cpu=(world == 1 and not args.no_cpu_baseline))
         except Exception as e:  # the headline number must still print
             result["nms"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(cfg, nc, args.size)
+            result["cpu_baseline"] = cpu_baseline(cfg, nc, args.size, threads=args.cpu_threads)
             # parity spot-check at the benchmark's own resolution: same weights (seed 96), same
             # synthetic batch of 4 -> HIP bf16 loss vs the oracle's fp32 loss
             torch.manual_seed(96)
@@ -278,6 +373,22 @@ def main():
             ref_loss = result["cpu_baseline"].pop("loss_b4")
             result["parity_check"] = {"batch": 4, "hip_bf16_loss": hip_loss, "oracle_fp32_loss": ref_loss,
                                       "rel_diff": abs(hip_loss - ref_loss) / abs(ref_loss)}
+            if args.model == "yolox_s":
+                # BASELINE.json configs[0] (the reference's CPU-runnable case): YOLOX-nano 416x416 batch 4 on the host
+                # cores, with the HIP fp32 parity mode on the same weights and batch beside it (loss contract 1e-4)
+                with open(os.path.join(ROOT, "configs", "model", "yolox", "yolox_nano.yaml")) as f:
+                    cfg1 = yaml.safe_load(f)
+                cfg1["_name"] = "yolox_nano"
+                c1 = cpu_baseline(cfg1, nc, 416, budget_s=10.0, threads=args.cpu_threads)
+                torch.manual_seed(96)
+                m1 = pl_yolo_amd.build_model(cfg1, nc)
+                m1.compute_dtype = "fp32"
+                m1 = m1.to(dev).train()
+                i1, l1 = synthetic(4, 416, nc, 1234)
+                hip1 = float(m1(i1.to(dev), l1.to(dev))["loss"].detach())
+                ref1 = c1.pop("loss_b4")
+                c1["hip_fp32_loss"], c1["oracle_fp32_loss"], c1["rel_diff"] = hip1, ref1, abs(hip1 - ref1) / abs(ref1)
+                result["cpu_baseline_cfg1"] = c1
         print(json.dumps(result))
     if dist is not None:
         dist.barrier()

@@ -23,11 +23,14 @@ import torch.nn.functional as F
 BN_EPS = 1e-3
 BN_MOMENTUM = 0.03
 
-# Optional emulation of the HIP bf16 pipeline's storage roundings (forward only, used to
-# check the bf16 MFMA path tightly): bf16 weights, bf16 raw conv output `z` (the batch
-# statistics are taken from the fp32 accumulators first), bf16 activations, bf16 image
-# after the Focus gather; BatchNorm / SiLU arithmetic stays fp32, prediction convs write
-# fp32.  Enabled with `with emulate_bf16(): ...`.
+# Optional emulation of the HIP bf16 pipeline's storage roundings (used to check the bf16
+# MFMA path tightly): bf16 weights, bf16 raw conv output `z` (the batch statistics are taken
+# from the fp32 accumulators first), bf16 activations, bf16 image after the Focus gather;
+# BatchNorm / SiLU arithmetic stays fp32, prediction convs write fp32.  Under autograd the
+# same points round the GRADIENT to bf16 on the way back (`_q`: the cast pair's backward is a
+# cast pair) -- the HIP backward stores d(activation) and dz as bf16 at exactly these places --
+# while weight gradients stay fp32 like the MFMA weight-gradient slabs (`_qw`).
+# Enabled with `with emulate_bf16(): ...`.
 _EMU = [False]
 
 
@@ -43,6 +46,11 @@ class emulate_bf16:
 
 def _q(t):
     return t.to(torch.bfloat16).to(torch.float32) if _EMU[0] else t
+
+
+def _qw(w):
+    """bf16-rounded weights in the forward, UNROUNDED (fp32) gradient in the backward."""
+    return w + (w.to(torch.bfloat16).to(torch.float32) - w).detach() if _EMU[0] else w
 
 
 def activation(x, name):
@@ -67,7 +75,7 @@ def conv_unit(state, prefix, x, stride, training, norm="bn", act="silu", residua
     training, running stats in eval; running buffers updated in place) -> act."""
     w = state[prefix + ".conv.weight"]
     k = w.shape[-1]
-    z = F.conv2d(x, _q(w), state.get(prefix + ".conv.bias"), stride, (k - 1) // 2)
+    z = F.conv2d(x, _qw(w), state.get(prefix + ".conv.bias"), stride, (k - 1) // 2)
     if norm is not None and _EMU[0]:
         if norm != "bn":
             raise AttributeError("Unsupported normalization function type: {}".format(norm))
@@ -188,7 +196,7 @@ def decoupled_head(state, cfg, inputs, training, prefix="head"):
             r = conv_unit(state, "%s.reg_convs.%d.%d" % (prefix, k, j), r, 1, training, norm, act)
 
         def pred(name, t):
-            return F.conv2d(t, _q(state["%s.%s.%d.weight" % (prefix, name, k)]), state["%s.%s.%d.bias" % (prefix, name, k)])
+            return F.conv2d(t, _qw(state["%s.%s.%d.weight" % (prefix, name, k)]), state["%s.%s.%d.bias" % (prefix, name, k)])
 
         outs.append(torch.cat([pred("reg_preds", r), pred("obj_preds", r), pred("cls_preds", c)], 1))
     return outs

@@ -11,7 +11,7 @@ Reference semantics restated (file:line into /root/reference):
 import torch
 import torch.nn.functional as F
 
-from .net import conv_unit, spp_bottleneck, _q
+from .net import conv_unit, spp_bottleneck, _q, _qw
 
 
 def _chain(state, prefix, x, n, training, norm, act):
@@ -97,7 +97,7 @@ def implicit_head(state, inputs, prefix="head"):
     outs = []
     for k, x in enumerate(inputs):
         x = state["%s.ia.%d.implicit" % (prefix, k)] + x
-        x = F.conv2d(x, _q(state["%s.conv.%d.weight" % (prefix, k)]), state["%s.conv.%d.bias" % (prefix, k)])
+        x = F.conv2d(x, _qw(state["%s.conv.%d.weight" % (prefix, k)]), state["%s.conv.%d.bias" % (prefix, k)])
         outs.append(state["%s.im.%d.implicit" % (prefix, k)] * x)
     return outs
 

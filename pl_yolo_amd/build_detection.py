@@ -49,6 +49,7 @@ class OneStageD(nn.Module):
         self.loss = loss
         self.compute_dtype = os.environ.get("PLYOLO_DTYPE", "bf16")
         self.__dict__['_runner'] = None
+        self.__dict__['_ddp'] = None
 
     def runner(self):
         r = self.__dict__.get('_runner')
@@ -58,6 +59,7 @@ class OneStageD(nn.Module):
                 raise PlyoloError("compute_dtype must be 'bf16' or 'fp32'")
             r = R.DetectorRunner(self, want)
             r.dtype_name = want
+            r.ddp = self.__dict__.get('_ddp')   # the gradient exchange belongs to the model (pl_yolo_amd.ddp.attach), not to one runner
             self.__dict__['_runner'] = r
         return r
 

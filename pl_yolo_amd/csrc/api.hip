@@ -2,6 +2,9 @@
 // dtype dispatch of the convolution entry points.
 #include <stdarg.h>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "common.h"
 
 namespace plyolo {
@@ -18,6 +21,18 @@ void set_error(const char* fmt, ...) {
   g_err = buf;
 }
 Plan* recording_plan() { return g_rec; }
+
+hipError_t ensure_dynamic_lds(const void* kernel, size_t bytes) {
+  if (bytes <= 64 * 1024) return hipSuccess;
+  static std::mutex mu;
+  static std::unordered_map<const void*, size_t> granted;
+  std::lock_guard<std::mutex> lock(mu);
+  size_t& have = granted[kernel];
+  if (bytes <= have) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) have = bytes;
+  return e;
+}
 
 static thread_local std::string g_ann_label;
 static thread_local double g_ann_flops = 0.0, g_ann_bytes = 0.0;

@@ -156,6 +156,10 @@ template <typename F> int submit(void* stream, F&& fn) {
 
 inline hipError_t launch_status() { return hipGetLastError(); }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize, set ONCE per kernel and size: the attribute call costs host time on
+// every launch of the eager replay (~1300 convolution launches per step) and never changes after the first.
+hipError_t ensure_dynamic_lds(const void* kernel, size_t bytes);
+
 // Byte fill as an ordinary kernel launch.  (hipMemsetAsync nodes inside a captured hipGraph were
 // observed to misbehave on re-launch for small sizes on ROCm 7.2; a kernel node is always safe.)
 __global__ void fill_bytes_kernel(unsigned char* p, unsigned value, size_t bytes);

@@ -492,6 +492,7 @@ hipError_t launch_inst(ConvP p, hipStream_t s) {
       kern = conv_mfma_kernel<BN, CK, TH, OUT_F32, 0, true>;
     }
   }
+#ifdef PLYOLO_DIAG_ABLATE   // diagnostic instantiations (results are wrong by design): make DIAG=1
   if (BN == 128 && CK == 64 && TH == 16 && !OUT_F32 && p.ablate) {  // diagnostic instantiations of the main shape only
     switch (p.ablate) {
       case 1: kern = conv_mfma_kernel<128, 64, 16, false, 1>; break;
@@ -512,10 +513,8 @@ hipError_t launch_inst(ConvP p, hipStream_t s) {
       default: break;
     }
   }
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-  }
+#endif
+  if (hipError_t e = plyolo::ensure_dynamic_lds((const void*)kern, lds); e != hipSuccess) return e;
   dim3 grid(p.nmb, (p.Cout + BN - 1) / BN);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
   return hipGetLastError();
@@ -573,10 +572,7 @@ hipError_t launch_jobs_inst(ConvJobs jobs, hipStream_t s) {
       kern = conv_mfma_jobs_kernel<BN, CK, TH, true>;
     }
   }
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-  }
+  if (hipError_t e = plyolo::ensure_dynamic_lds((const void*)kern, lds); e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(total, ny), dim3(256), lds, s, jobs);
   return hipGetLastError();
 }

@@ -800,10 +800,7 @@ int plyolo_spp_pools_bwd(int dtype, int N, int H, int W, int C, int nk, const in
   return submit(stream, [=](hipStream_t s) -> hipError_t {
     DISPATCH_T(dtype, {
       auto kern = spp_pools_bwd_kernel<T>;
-      if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-      }
+      if (hipError_t e = plyolo::ensure_dynamic_lds((const void*)kern, lds); e != hipSuccess) return e;
       hipLaunchKernelGGL(kern, dim3(N, cdiv(C, SPP_CG)), dim3(256), lds, s, H, W, C, nk, k[0], k[1], k[2], (const T*)in, i_ld,
                          (const T*)d[0], (const T*)d[1], (const T*)d[2], dl[0], dl[1], dl[2], (T*)din, di_ld, accumulate);
     })

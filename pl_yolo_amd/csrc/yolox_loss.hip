@@ -717,10 +717,7 @@ int plyolo_yolox_loss_fwd(const plyolo_yolox_desc* dp, const float* raw, const f
     int nchunk = 0;
     for (int l = 0; l < d.nlevels; ++l) nchunk += cdiv(d.lvl_h[l] * d.lvl_w[l], PREP_T);
     const size_t prep_lds = ((size_t)PREP_T * (5 + d.C) + (size_t)d.M * 5) * 4;
-    if (prep_lds > 64 * 1024) {
-      hipError_t ea = hipFuncSetAttribute((const void*)k_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds);
-      if (ea != hipSuccess) return ea;
-    }
+    if (hipError_t ea = plyolo::ensure_dynamic_lds((const void*)k_prep, prep_lds); ea != hipSuccess) return ea;
     hipLaunchKernelGGL(k_prep, dim3(nchunk, d.B), dim3(PREP_T), prep_lds, s, d, raw, labels, ws);
     hipLaunchKernelGGL(k_topk, dim3(d.M, d.B), dim3(256), 0, s, d, raw, labels, ws);
     hipLaunchKernelGGL(k_resolve, dim3(cdiv(d.A, 256), d.B), dim3(256), 0, s, d, raw, labels, ws, fg, matched_gt, matched_iou);

@@ -37,7 +37,11 @@ def attach(model, group=None):
     if not dist.is_initialized():
         raise RuntimeError("torch.distributed is not initialised")
     r = model.runner()
-    r.ddp = GradAllReduce(group)
-    for t in list(model.parameters()) + list(model.buffers()):
-        dist.broadcast(t.data, src=0, group=group)
+    dev = next(model.parameters()).device
+    if not r._adopted_ok(dev):
+        r.adopt(dev)            # parameters / buffers become views of three flat buffers ...
+    for key in ("w", "fbuf", "ibuf"):
+        dist.broadcast(r.flat[key], src=0, group=group)   # ... so the start state is three collectives, not one per tensor
+    model.__dict__['_ddp'] = GradAllReduce(group)         # kept on the model: a runner rebuilt later (compute_dtype change) re-attaches it
+    r.ddp = model.__dict__['_ddp']
     return model

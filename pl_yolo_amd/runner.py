@@ -120,6 +120,8 @@ class DetectorRunner:
         g.grad_ptr_of = self.grad_ptr_of
         s = _Session()
         s.g, s.mode, s.B, s.H, s.W, s.M = g, mode, B, H, W, M
+        s.generation = 0          # bumped by every forward of this session (see _check_generation)
+        s.published_version = None
         s.stem_kind = getattr(model.backbone, "stem_kind", "focus")
         if s.stem_kind == "focus":   # CSPDarkNet: space-to-depth gather (12 real channels)
             image = g.new_act(B, H // 2, W // 2, 16 if self.dtype == BF16 else 12, "focus")
@@ -257,6 +259,7 @@ class DetectorRunner:
         s.head.labels.view(labels.shape).copy_(labels)
         self._focus(s, x)
         self._run_plan(s.fwd)
+        s.generation += 1
         return s
 
     def backward_train(self, s, gout):
@@ -280,6 +283,7 @@ class DetectorRunner:
         s = self._session(B, H, W, 1, "maps_grad" if want_grad else "maps", x.device)
         self._focus(s, x)
         self._run_plan(s.fwd)
+        s.generation += 1
         hd = s.head
         outs = []
         for (h, w), r0 in zip(hd.sizes, hd.lvl_row):
@@ -294,18 +298,44 @@ class DetectorRunner:
             self.ddp.all_reduce_(self.flat["g"])
 
 
+def _check_generation(ctx, s):
+    """A session's activation / z / statistics / head buffers are shared by every forward of that shape, so a
+    backward is only valid for the LAST forward of its session: gradient accumulation over micro-batches (two
+    forwards, then two backwards) or a `model(x)` call between forward and backward would silently back-propagate
+    through the wrong activations.  Refused loudly instead."""
+    if ctx.generation != s.generation:
+        raise PlyoloError("backward of a stale forward: another forward with the same (batch, size, label rows, mode) ran after "
+                          "the one this loss came from, and the HIP launch plan keeps ONE set of activation buffers per shape; "
+                          "run forward -> backward pairs back to back (micro-batch accumulation is not supported)")
+
+
+def _check_not_accumulating(s):
+    """`.grad` still being the flat view AND untouched since the last backward means the caller neither dropped nor
+    zeroed the gradients: autograd would ADD the new gradient, the backward plan overwrites the flat buffer."""
+    if not s.used_params or s.published_version is None:
+        return
+    p, gv = s.used_params[0], s.grad_views[0]
+    g = p.grad
+    if g is not None and g.data_ptr() == gv.data_ptr() and g._version == s.published_version:
+        raise PlyoloError("gradient accumulation across backward() calls is not supported by the HIP launch plan (it writes the "
+                          "flat gradient buffer, it does not add to it): call optimizer.zero_grad() / model.zero_grad() between steps")
+
+
 def _publish_grads(s):
     """The backward plan has written every parameter gradient into the runner's flat
     buffer; expose them as `.grad` WITHOUT a copy (returning them through autograd would
     make AccumulateGrad clone all ~240 tensors every step).  Semantics match autograd
-    for the reference's loop (optimizer.zero_grad() -> .grad is None before backward); a
-    pre-existing foreign .grad tensor is accumulated into, like autograd would."""
+    for the reference's loop (optimizer.zero_grad() -> .grad is None, or zeroed in place, before
+    backward); a pre-existing foreign .grad tensor is accumulated into, like autograd would;
+    a second backward without zero_grad is refused (_check_not_accumulating)."""
     for p, gv in zip(s.used_params, s.grad_views):
         g = p.grad
         if g is None or g.data_ptr() == gv.data_ptr():
             p.grad = gv
         else:
             g.add_(gv)
+    if s.used_params and s.used_params[0].grad is not None:
+        s.published_version = s.used_params[0].grad._version
 
 
 class _TrainStep(torch.autograd.Function):
@@ -315,12 +345,14 @@ class _TrainStep(torch.autograd.Function):
     @staticmethod
     def forward(ctx, runner, x, labels, *params):
         s = runner.forward_train(x, labels)
-        ctx.runner, ctx.session = runner, s
+        ctx.runner, ctx.session, ctx.generation = runner, s, s.generation
         return s.head.losses.clone()
 
     @staticmethod
     def backward(ctx, gout):
         runner, s = ctx.runner, ctx.session
+        _check_generation(ctx, s)
+        _check_not_accumulating(s)
         runner.backward_train(s, gout.contiguous().float())
         _publish_grads(s)
         return (None, None, None) + (None,) * len(s.used_params)
@@ -332,12 +364,14 @@ class _MapsStep(torch.autograd.Function):
     @staticmethod
     def forward(ctx, runner, x, *params):
         s, outs = runner.forward_maps(x, want_grad=True)
-        ctx.runner, ctx.session = runner, s
+        ctx.runner, ctx.session, ctx.generation = runner, s, s.generation
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *grads):
         runner, s = ctx.runner, ctx.session
+        _check_generation(ctx, s)
+        _check_not_accumulating(s)
         runner.backward_maps(s, [g.contiguous().float() for g in grads])
         _publish_grads(s)
         return (None, None) + (None,) * len(s.used_params)

@@ -1,0 +1,305 @@
+"""-m gpu: every BASELINE.json configuration at its REAL size (the oracle needs minutes to hours there, so the
+checks are size-independent properties; the small-size fixture parity lives in test_gpu_network / test_gpu_yolov7):
+
+  cfg1  YOLOX-nano 416x416 batch 4     HIP fp32 parity mode vs the reference-generated fixture (loss 1e-4) --
+                                       the CPU side of this config is tests/test_oracle_cfg1.py
+  cfg3  YOLOv7 640x640 batch 32        with and without `neck.repconv`
+  cfg4  YOLOX-l 640x640 batch 16/GPU
+  cfg5  YOLOX-x 1280x1280 batch 16/GPU train step + eval decode + postprocess on the SURVEY 8d set-(i) head maps
+
+  * finite losses / a finite, non-zero gradient for every trained parameter
+  * repeatability          same state + batch -> same losses, same gradients (fixed-order or fp64 reductions)
+  * backward linearity     d(2*loss) == 2*d(loss)   (power-of-two scale commutes with every rounding)
+  * batch permutation      fp32 parity mode: bit-identical head maps, equal losses / gradients
+  * closed-form decode     model.eval() output == decode of the raw maps of the same weights
+
+These are also the launches that exercise the 32-bit offset guards of the conv loaders (api.hip: check_conv) and
+the weight-gradient slab planning at 1280x1280.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+pytestmark = pytest.mark.gpu
+
+import pl_yolo_amd  # noqa: E402
+from conftest import ROOT, load_golden  # noqa: E402
+import hiputil as hu  # noqa: E402
+
+NC = 80
+
+
+def _cfg(family, name, repconv=False):
+    with open(os.path.join(ROOT, "configs", "model", family, name + ".yaml")) as f:
+        cfg = yaml.safe_load(f)
+    if repconv:
+        cfg["neck"]["repconv"] = True
+    return cfg
+
+
+def _batch(B, size, seed, num_gt=30, max_gt=100):
+    gen = torch.Generator().manual_seed(seed)
+    imgs = torch.rand(B, 3, size, size, generator=gen) * 255
+    labels = torch.zeros(B, max_gt, 5)
+    labels[:, :num_gt, 0] = torch.randint(0, NC, (B, num_gt), generator=gen).float()
+    labels[:, :num_gt, 1:3] = (0.15 + 0.7 * torch.rand(B, num_gt, 2, generator=gen)) * size
+    labels[:, :num_gt, 3:5] = 8 + torch.rand(B, num_gt, 2, generator=gen) * 0.3 * size
+    return imgs.to(hu.DEV), labels.to(hu.DEV)
+
+
+def _build(cfg, dtype="bf16"):
+    torch.manual_seed(96)
+    model = pl_yolo_amd.build_model(cfg, NC)
+    model.compute_dtype = dtype
+    model = model.to(hu.DEV)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    return model, sd0
+
+
+def _step(model, sd0, imgs, labels, scale=1.0):
+    model.load_state_dict(sd0)
+    model.train()
+    model.zero_grad(set_to_none=True)
+    out = model(imgs, labels)
+    (out["loss"] * scale).backward()
+    torch.cuda.synchronize()
+    trained = [(n, p) for n, p in model.named_parameters() if p.grad is not None]
+    g = torch.cat([p.grad.flatten() for _, p in trained]).clone()
+    losses = {k: float(v.detach().reshape(-1)[0]) if torch.is_tensor(v) else float(v) for k, v in out.items()}
+    return losses, g, trained
+
+
+def _dead(name):
+    # the reference's unused Bottleneck.bn (network_blocks.py:81) never receives a gradient
+    return name.endswith(".bn.weight") or name.endswith(".bn.bias")
+
+
+def _check_step_properties(model, sd0, imgs, labels, tag):
+    l1, g1, trained = _step(model, sd0, imgs, labels)
+    print(tag, "losses", l1)
+    assert all(np.isfinite(v) for v in l1.values()), l1
+    assert bool(torch.isfinite(g1).all())
+    missing = [n for n, p in model.named_parameters() if p.grad is None and not _dead(n)]
+    assert not missing, missing[:5]
+    zero = [n for n, p in trained if float(p.grad.abs().max()) == 0.0]
+    assert not zero, zero[:5]
+    gmax = float(g1.abs().max())
+    l2, g2, _ = _step(model, sd0, imgs, labels)                 # repeatability
+    for k in l1:
+        assert abs(l1[k] - l2[k]) <= 1e-6 * max(1.0, abs(l1[k])), (k, l1[k], l2[k])
+    assert float((g1 - g2).abs().max()) <= 1e-5 * gmax
+    l3, g3, _ = _step(model, sd0, imgs, labels, scale=2.0)      # backward linearity
+    assert float((g3 - 2 * g1).abs().max()) <= 2e-5 * gmax
+    return l1, g1
+
+
+def _check_permutation_fp32(model, sd0, imgs, labels, tag):
+    B = imgs.shape[0]
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(8)).to(hu.DEV)
+    pimgs, plabels = imgs[perm].contiguous(), labels[perm].contiguous()
+    prev = model.compute_dtype
+    model.compute_dtype = "fp32"
+    try:
+        model.load_state_dict(sd0)
+        model.train()
+        with torch.no_grad():
+            m1 = [m.float().clone() for m in model(imgs, None)]
+            model.load_state_dict(sd0)
+            m2 = [m.float().clone() for m in model(pimgs, None)]
+        for a, b in zip(m1, m2):
+            assert torch.equal(a[perm], b)
+        l1, g1, _ = _step(model, sd0, imgs, labels)
+        l2, g2, _ = _step(model, sd0, pimgs, plabels)
+        for k in l1:
+            assert abs(l1[k] - l2[k]) <= 5e-6 * max(1.0, abs(l1[k])), (k, l1[k], l2[k])
+        cs = hu.cossim(g1, g2)
+        print(tag, "permuted batch (fp32): loss %.6f vs %.6f, gradient cosine %.7f" % (l1["loss"], l2["loss"], cs))
+        assert cs >= 0.99999 and float((g1 - g2).abs().max()) <= 2e-4 * float(g1.abs().max())
+    finally:
+        model.compute_dtype = prev
+
+
+def _decode_yolox(maps, strides):
+    rows = []
+    for m, s in zip(maps, strides):
+        b, c, h, w = m.shape
+        ys, xs = torch.meshgrid(torch.arange(h, device=m.device), torch.arange(w, device=m.device), indexing="ij")
+        t = m.float().permute(0, 2, 3, 1).reshape(b, h * w, c)
+        xy = (t[..., 0:2] + torch.stack([xs, ys], -1).reshape(1, h * w, 2)) * s
+        wh = torch.exp(t[..., 2:4]) * s
+        rows.append(torch.cat([xy - wh / 2, xy + wh / 2, torch.sigmoid(t[..., 4:])], -1))
+    return torch.cat(rows, 1)
+
+
+def _check_eval_decode_yolox(model, sd0, imgs, A):
+    model.load_state_dict(sd0)
+    model.eval()
+    with torch.no_grad():
+        pred = model(imgs, torch.zeros(imgs.shape[0], 1, 5, device=hu.DEV))
+        maps = model(imgs, None)
+    assert tuple(pred.shape) == (imgs.shape[0], A, 5 + NC)
+    want = _decode_yolox(maps, (8, 16, 32))
+    fin = torch.isfinite(want)
+    err = float(((pred - want)[fin]).abs().max() / want[fin].abs().max())
+    print("eval decode vs closed form: rel max err %.3g" % err)
+    assert err <= 1e-5
+    model.train()
+
+
+# ---------------------------------------------------------------------------------------------- cfg1
+def test_cfg1_nano416_b4_fp32_vs_reference_fixture():
+    """YOLOX-nano 416x416 batch 4 (the reference's CPU-runnable configuration) through the HIP fp32 parity mode:
+    same seeded weights and synthetic batch as the reference run that wrote tests/golden/cfg1_nano416.npz."""
+    g = load_golden("cfg1_nano416")
+    cfg = _cfg("yolox", "yolox_nano")
+    model, sd0 = _build(cfg, "fp32")
+    w = model.backbone.stem.conv.conv.weight.detach().cpu().numpy()
+    assert np.array_equal(w, g["stem_weight"]), "seed-96 initialisation differs from the reference's"
+    psum = float(sum(p.double().sum() for p in model.parameters()))
+    assert abs(psum - float(g["param_sum"])) <= 1e-6 * float(g["param_abs_sum"])
+    B, S = int(g["batch"]), int(g["size"])
+    gen = torch.Generator().manual_seed(int(g["seed_data"]))
+    imgs = torch.rand(B, 3, S, S, generator=gen) * 255
+    labels = torch.zeros(B, 100, 5)
+    labels[:, :30, 0] = torch.randint(0, NC, (B, 30), generator=gen).float()
+    labels[:, :30, 1:3] = (0.15 + 0.7 * torch.rand(B, 30, 2, generator=gen)) * S
+    labels[:, :30, 3:5] = 8 + torch.rand(B, 30, 2, generator=gen) * 0.3 * S
+    model.train()
+    out = model(imgs.to(hu.DEV), labels.to(hu.DEV))
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    for k in ("loss", "loss_iou", "loss_obj", "loss_cls"):
+        got, want = float(out[k]), float(g["out/" + k])
+        print("cfg1", k, got, want)
+        assert abs(got - want) <= 1e-4 * max(1.0, abs(want)), k
+    assert abs(float(out["proportion"]) - float(g["out/proportion"])) <= 1e-5
+    params = dict(model.named_parameters())
+    for k in [k for k in g if k.startswith("grad/")]:
+        ref = torch.from_numpy(g[k])
+        got = params[k[5:]].grad.cpu()
+        assert float((got - ref).abs().max()) <= 2e-4 * max(float(ref.abs().max()), 1e-6), k
+    gsq = float(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None))
+    assert abs(gsq - float(g["grad_sq_sum"])) <= 1e-3 * float(g["grad_sq_sum"])
+    # the bf16 MFMA path at this configuration: same batch, loss within the bf16 band
+    m16, _ = _build(cfg, "bf16")
+    m16.train()
+    l16 = float(m16(imgs.to(hu.DEV), labels.to(hu.DEV))["loss"])
+    print("cfg1 bf16 loss %.5f vs reference %.5f" % (l16, float(g["out/loss"])))
+    assert abs(l16 - float(g["out/loss"])) <= 3e-2 * float(g["out/loss"])
+
+
+# ---------------------------------------------------------------------------------------------- cfg3
+@pytest.mark.parametrize("repconv", [False, True])
+def test_cfg3_yolov7_640_b32(repconv):
+    cfg = _cfg("yolov7", "yolov7", repconv)
+    model, sd0 = _build(cfg)
+    imgs, labels = _batch(32, 640, 1234)
+    _check_step_properties(model, sd0, imgs, labels, "yolov7%s" % ("+repconv" if repconv else ""))
+    # eval: [B, 3*(80^2+40^2+20^2), 85], finite scores, closed-form decode of the raw maps (yolov7_loss.py:50-78)
+    model.load_state_dict(sd0)
+    model.eval()
+    with torch.no_grad():
+        pred = model(imgs, torch.zeros(32, 1, 5, device=hu.DEV))
+        maps = model(imgs, None)
+    A = 3 * (80 * 80 + 40 * 40 + 20 * 20)
+    assert tuple(pred.shape) == (32, A, 5 + NC)
+    anchors = torch.tensor(cfg["loss"]["anchors"], dtype=torch.float32, device=hu.DEV).reshape(3, 3, 2)
+    rows = []
+    for l, (m, s) in enumerate(zip(maps, (8, 16, 32))):
+        b, c, h, w = m.shape
+        t = torch.sigmoid(m.float().reshape(b, 3, 5 + NC, h, w).permute(0, 1, 3, 4, 2))
+        ys, xs = torch.meshgrid(torch.arange(h, device=hu.DEV), torch.arange(w, device=hu.DEV), indexing="ij")
+        grid = torch.stack([xs, ys], -1).reshape(1, 1, h, w, 2).float()
+        xy = (t[..., 0:2] * 2.0 - 0.5 + grid) * s
+        wh = (t[..., 2:4] * 2.0) ** 2 * anchors[l].reshape(1, 3, 1, 1, 2)
+        rows.append(torch.cat([xy - wh / 2, xy + wh / 2, t[..., 4:]], -1).reshape(b, 3 * h * w, 5 + NC))
+    want = torch.cat(rows, 1)
+    err = float((pred - want).abs().max() / want.abs().max())
+    print("yolov7 eval decode vs closed form: rel max err %.3g" % err)
+    assert err <= 1e-5
+
+
+def test_cfg3_yolov7_640_b32_permutation_fp32():
+    cfg = _cfg("yolov7", "yolov7")
+    model, sd0 = _build(cfg)
+    imgs, labels = _batch(32, 640, 4321)
+    _check_permutation_fp32(model, sd0, imgs, labels, "yolov7")
+
+
+# ---------------------------------------------------------------------------------------------- cfg4
+def test_cfg4_yolox_l_640_b16():
+    cfg = _cfg("yolox", "yolox_l")
+    model, sd0 = _build(cfg)
+    imgs, labels = _batch(16, 640, 1234)
+    _check_step_properties(model, sd0, imgs, labels, "yolox_l")
+    _check_eval_decode_yolox(model, sd0, imgs, 8400)
+    _check_permutation_fp32(model, sd0, imgs, labels, "yolox_l")
+
+
+# ---------------------------------------------------------------------------------------------- cfg5
+def test_cfg5_yolox_x_1280_b16_train_step():
+    cfg = _cfg("yolox", "yolox_x")
+    model, sd0 = _build(cfg)
+    imgs, labels = _batch(16, 1280, 1234)
+    _check_step_properties(model, sd0, imgs, labels, "yolox_x@1280")
+    _check_eval_decode_yolox(model, sd0, imgs, 33600)
+
+
+def _set_i_head_maps(B, gen):
+    """SURVEY 8d cfg5 set (i): raw head maps [B,85,160,160] / [B,85,80,80] / [B,85,40,40] with background objectness
+    logit -12 and, per image, 200 random sites x 5 adjacent anchors = 1000 anchors carrying obj ~U(0,4), one class
+    logit ~U(0,4) (others -8), box logits ~N(0, 0.5)."""
+    sizes = [(160, 160), (80, 80), (40, 40)]
+    A = sum(h * w for h, w in sizes)
+    flat = torch.zeros(B, A, 5 + NC)
+    flat[..., 0:4] = torch.randn(B, A, 4, generator=gen) * 0.5
+    flat[..., 4] = -12.0
+    flat[..., 5:] = -8.0
+    for b in range(B):
+        sites = torch.randint(0, A - 5, (200,), generator=gen)
+        idx = (sites[:, None] + torch.arange(5)[None, :]).reshape(-1)
+        flat[b, idx, 4] = torch.rand(1000, generator=gen) * 4
+        cls = torch.randint(0, NC, (1000,), generator=gen)
+        flat[b, idx, 5 + cls] = torch.rand(1000, generator=gen) * 4
+    maps, a0 = [], 0
+    for (h, w) in sizes:
+        maps.append(flat[:, a0:a0 + h * w].reshape(B, h, w, 5 + NC).permute(0, 3, 1, 2).contiguous())
+        a0 += h * w
+    return maps, sizes
+
+
+def test_cfg5_eval_decode_and_postprocess_set_i():
+    """The eval leg of cfg5 on the synthetic set-(i) head maps: device eval decode == closed form, then `postprocess`
+    (conf 0.01, NMS 0.65, pl_detection.py:24-25) == the CPU oracle's post-processing, image by image, box by box."""
+    import ctypes as C
+    from pl_yolo_amd._lib import call
+    from pl_yolo_amd.postprocess import postprocess
+    from oracle import nms as onms
+    B = 16
+    maps, sizes = _set_i_head_maps(B, torch.Generator().manual_seed(2025))
+    d, rows = hu.yolox_desc(B, NC, 1, sizes, (8, 16, 32))
+    raw = hu.maps_to_raw([m.to(hu.DEV) for m in maps])
+    ev = torch.zeros(B * d.A * (5 + NC), device=hu.DEV)
+    call("plyolo_yolox_eval_decode", C.byref(d), raw.data_ptr(), ev.data_ptr(), hu.stream())
+    pred = ev.view(B, d.A, 5 + NC)
+    want = _decode_yolox([m.to(hu.DEV) for m in maps], (8, 16, 32))
+    err = float((pred - want).abs().max() / want.abs().max())
+    assert err <= 1e-5, err
+    dets = postprocess(pred, conf_thre=0.01, nms_thre=0.65)
+    ref = onms.postprocess(pred.cpu().numpy(), 0.01, 0.65)
+    n_in = int((pred[..., 4] * pred[..., 5:].max(-1).values >= 0.01).sum())
+    kept = 0
+    for b in range(B):
+        assert (dets[b] is None) == (ref[b] is None)
+        if ref[b] is None:
+            continue
+        got = dets[b].cpu().numpy()
+        assert got.shape == ref[b].shape, (b, got.shape, ref[b].shape)
+        np.testing.assert_array_equal(got[:, 5], ref[b][:, 5])
+        np.testing.assert_allclose(got[:, :5], ref[b][:, :5], rtol=1e-6, atol=1e-5)
+        kept += got.shape[0]
+    print("set (i): %d candidates into NMS (%.0f / image), %d kept" % (n_in, n_in / B, kept))
+    assert 900 * B <= n_in <= 1000 * B and 0 < kept <= 300 * B

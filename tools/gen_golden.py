@@ -465,7 +465,96 @@ def gen_repconv():
     save("repconv_blocks", d)
 
 
+def gen_network_warm():
+    """"Warm weights": the toy YOLOX after 50 SGD steps of the REFERENCE on a small fixed data set, then one
+    recorded training step at that state (losses, every gradient, head maps).  A trained-for-a-while BatchNorm net
+    is far less chaotic than a random-initialised one, so the bf16 path can be held to tight end-to-end bounds on it."""
+    cfg = load_cfg("yolox_test")
+    C = 3
+    torch.manual_seed(96)
+    model = build_model(cfg, C)
+    model.train()
+    gen = torch.Generator().manual_seed(4242)
+    S, B = 128, 4
+    data = []
+    for i in range(4):
+        x = torch.rand(B, 3, S, S, generator=gen) * 255
+        labels = rand_labels(gen, [3, 4, 2, 3], C, S, 8, min_wh=12.0)
+        data.append((x, labels))
+    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9)
+    losses = []
+    for step in range(50):
+        x, labels = data[step % 4]
+        out = model(x, labels)
+        opt.zero_grad()
+        out["loss"].backward()
+        opt.step()
+        losses.append(float(out["loss"]))
+    x, labels = data[0]
+    d = dict(x=x, labels=labels, num_classes=C, warm_losses=np.asarray(losses))
+    for k, v in model.state_dict().items():
+        d["state/" + k] = v.clone()
+    maps = model(x)
+    for i, m in enumerate(maps):
+        d["maps_train%d" % i] = m.detach().clone()
+    model.load_state_dict({k[len("state/"):]: torch.as_tensor(v) for k, v in d.items() if k.startswith("state/")})
+    model.zero_grad()
+    _calls.clear()
+    out = model(x, labels)
+    out["loss"].backward()
+    for k in ("loss", "loss_iou", "loss_obj", "loss_cls"):
+        d["out/" + k] = out[k].detach()
+    d["out/proportion"] = float(out["proportion"])
+    d["boundary_gap"] = min([c["gap"] for c in _calls] + [float("inf")])
+    for n, p in model.named_parameters():
+        if p.grad is not None:
+            d["grad/" + n] = p.grad.clone()
+    print("warm fixture: loss %.4f -> %.4f over 50 steps; recorded step loss=%.6f gap=%.3g" % (losses[0], losses[-1], float(out["loss"]), d["boundary_gap"]))
+    save("network_yolox_warm", d)
+
+
+def gen_cfg1():
+    """BASELINE.json configs[0]: "YOLOX-nano" (yolox_s.yaml at width 0.25) 416x416 batch 4 through the
+    REFERENCE on the benchmark's synthetic batch: loss scalars + a handful of gradients + weight checksums."""
+    cfg = load_cfg("yolox_nano")
+    C = 80
+    torch.manual_seed(96)
+    model = build_model(cfg, C)
+    model.train()
+    g = torch.Generator().manual_seed(1234)
+    B, S, num_gt, max_gt = 4, 416, 30, 100
+    imgs = torch.rand(B, 3, S, S, generator=g) * 255
+    labels = torch.zeros(B, max_gt, 5)
+    labels[:, :num_gt, 0] = torch.randint(0, C, (B, num_gt), generator=g).float()
+    labels[:, :num_gt, 1:3] = (0.15 + 0.7 * torch.rand(B, num_gt, 2, generator=g)) * S
+    labels[:, :num_gt, 3:5] = 8 + torch.rand(B, num_gt, 2, generator=g) * 0.3 * S
+    d = dict(batch=B, size=S, num_classes=C, seed_weights=96, seed_data=1234)
+    d["param_sum"] = float(sum(p.double().sum() for p in model.parameters()))
+    d["param_abs_sum"] = float(sum(p.double().abs().sum() for p in model.parameters()))
+    d["stem_weight"] = model.backbone.stem.conv.conv.weight.detach().clone()
+    _calls.clear()
+    out = model(imgs, labels)
+    out["loss"].backward()
+    for k in ("loss", "loss_iou", "loss_obj", "loss_cls"):
+        d["out/" + k] = out[k].detach()
+    d["out/proportion"] = float(out["proportion"])
+    d["boundary_gap"] = min([c["gap"] for c in _calls] + [float("inf")])
+    d["num_fg"] = sum(c["num_fg"] for c in _calls)
+    for n in ("backbone.stem.conv.conv.weight", "backbone.stage4.1.conv1.norm.weight", "neck.p4_p3.conv3.conv.weight",
+              "head.cls_preds.0.bias", "head.obj_preds.2.bias", "head.reg_preds.1.weight"):
+        d["grad/" + n] = dict(model.named_parameters())[n].grad.clone()
+    d["grad_sq_sum"] = float(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None))
+    print("cfg1 fixture: loss=%.6f num_fg=%d gap=%.3g" % (float(out["loss"]), d["num_fg"], d["boundary_gap"]))
+    save("cfg1_nano416", d)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "warm":
+        gen_network_warm()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "cfg1":
+        gen_cfg1()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "repconv":
         gen_repconv()
         sys.exit(0)
@@ -478,4 +567,6 @@ if __name__ == "__main__":
     gen_loss_cases()
     gen_blocks()
     gen_network()
+    gen_network_warm()
+    gen_cfg1()
     gen_schedule()
