@@ -93,6 +93,15 @@ typedef struct plyolo_conv_desc {
   int stride;         /* 1 or 2 */
   int x_ld, y_ld;     /* pixel pitch (elements) of x and y */
   int y_f32;          /* 1: y (fwd) / dy (bwd) is fp32 regardless of dtype (head preds) */
+  /* Lazy input (training plans): x is the RAW output z of the producing BaseConv's convolution and its
+   * BatchNorm + activation (network_blocks.py:30-37) are applied while x is staged -- forward and weight
+   * gradient read act(x[c] * x_coef[c] + x_coef[x_coef_ld + c]) wherever they would read x[c] (zero padding
+   * stays zero); the activated tensor is never written.  x_coef = NULL: x is used as stored.  x_coef points
+   * at channel 0 of x inside a planar (scale | shift | ...) table with row pitch x_coef_ld
+   * (plyolo_bn_finalize).  Ignored by plyolo_conv2d_dgrad. */
+  const float* x_coef;
+  int x_coef_ld;
+  int x_act;          /* PLYOLO_ACT_* applied after the affine */
 } plyolo_conv_desc;
 
 /* y[n,oh,ow,co] = sum x[n,oh*s+kh-p,ow*s+kw-p,ci] * w[co,ci,kh,kw] (+ bias[co]).

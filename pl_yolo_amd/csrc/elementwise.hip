@@ -168,22 +168,50 @@ __global__ void maxpool_bwd_kernel(int N, int H, int W, int C, int k, const T* i
 // separable (first row holding the window maximum, first column of that row's maximum), so each
 // pool costs 2k LDS reads per element instead of k*k global reads; the routed gradients are
 // accumulated in LDS and written once (no fp32 scratch image, no global atomics).
-constexpr int SPP_CG = 8;
-template <typename T>
+// Determinism: several source pixels route their gradient to the same maximum; the sums are kept in FP64 in LDS
+// (ds_add_f64), so the order in which the waves arrive cannot change the rounded result (bf16 / fp32 addends are
+// summed exactly unless they span more than 2^29 in magnitude) -- with fp32 LDS atomics two runs of the same step
+// differed in the last bit here and the backbone upstream amplified that to percents (YOLOX-x at 1280x1280).
+// CG = channels per workgroup plane: 8 (16-byte vectors) while the plane fits in LDS, 4 for the larger maps.
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+template <typename T, int CG> DEVINL void spp_ld(const T* q, float* f) {
+  if constexpr (sizeof(T) == 2 && CG == 8) { Vec<T>::load(q, f); }
+  else if constexpr (sizeof(T) == 2 && CG == 4) {
+    const u32x2 v = *(const u32x2*)q;
+    f[0] = __uint_as_float(v[0] << 16); f[1] = __uint_as_float(v[0] & 0xffff0000u);
+    f[2] = __uint_as_float(v[1] << 16); f[3] = __uint_as_float(v[1] & 0xffff0000u);
+  } else {
+#pragma unroll
+    for (int i = 0; i < CG; i += 4) Vec<T>::load(q + i, f + i);
+  }
+}
+template <typename T, int CG> DEVINL void spp_st(T* q, const float* f) {
+  if constexpr (sizeof(T) == 2 && CG == 8) { Vec<T>::store(q, f); }
+  else if constexpr (sizeof(T) == 2 && CG == 4) {
+    u32x2 v;
+    v[0] = pack2bf(f[0], f[1]); v[1] = pack2bf(f[2], f[3]);
+    *(u32x2*)q = v;
+  } else {
+#pragma unroll
+    for (int i = 0; i < CG; i += 4) Vec<T>::store(q + i, f + i);
+  }
+}
+
+template <typename T, int SPP_CG>
 __global__ __launch_bounds__(256) void spp_pools_bwd_kernel(int H, int W, int C, int nk, int k0, int k1, int k2, const T* __restrict__ in,
                                                             int i_ld, const T* d0, const T* d1, const T* d2, int dl0, int dl1, int dl2,
                                                             T* din, int di_ld, int accumulate) {
   extern __shared__ __align__(16) unsigned char spp_smem[];
   const int HW = H * W, n = blockIdx.x, c0 = blockIdx.y * SPP_CG;
-  float* gs = (float*)spp_smem;                              // [HW][8] routed gradient
-  T* xs = (T*)(gs + (size_t)HW * SPP_CG);                    // [HW][8] input plane
-  T* rv = xs + (size_t)HW * SPP_CG;                          // [HW][8] row-pass maximum
-  unsigned short* ra = (unsigned short*)(rv + (size_t)HW * SPP_CG);  // [HW][8] its column
+  double* gs = (double*)spp_smem;                            // [HW][CG] routed gradient (fp64: order-independent sums)
+  T* xs = (T*)(gs + (size_t)HW * SPP_CG);                    // [HW][CG] input plane
+  T* rv = xs + (size_t)HW * SPP_CG;                          // [HW][CG] row-pass maximum
+  unsigned short* ra = (unsigned short*)(rv + (size_t)HW * SPP_CG);  // [HW][CG] its column
   const int items = HW * SPP_CG;
   for (int it = threadIdx.x; it < items; it += 256) {
     const int p = it / SPP_CG, ch = it % SPP_CG;
     xs[it] = (c0 + ch < C) ? in[((size_t)n * HW + p) * i_ld + c0 + ch] : (T)0;
-    gs[it] = 0.f;
+    gs[it] = 0.0;
   }
   __syncthreads();
   for (int j = 0; j < nk; ++j) {
@@ -196,15 +224,9 @@ __global__ __launch_bounds__(256) void spp_pools_bwd_kernel(int H, int W, int C,
     // reads of a window are issued before the first compare (a data-dependent loop serialised read -> compare ->
     // read: ~100 cycles of LDS latency x 54 reads per element).  Out-of-range taps are clamped onto the border
     // element: a duplicate of an element already seen never wins a strict '>' -- the first maximum is unchanged.
-    // One thread = one pixel, all 8 channels of the plane in registers: 16-byte LDS vectors instead of one 2-byte
-    // read per (pixel, channel, tap) -- the element-wise form issued ~1000 LDS instructions per thread and was bound
-    // by the LDS instruction rate.
-    auto ld8 = [&](const T* q, float* f) {
-      if constexpr (sizeof(T) == 2) { Vec<T>::load(q, f); } else { Vec<T>::load(q, f); Vec<T>::load(q + 4, f + 4); }
-    };
-    auto st8 = [&](T* q, const float* f) {
-      if constexpr (sizeof(T) == 2) { Vec<T>::store(q, f); } else { Vec<T>::store(q, f); Vec<T>::store(q + 4, f + 4); }
-    };
+    // One thread = one pixel, all CG channels of the plane in registers: 16- / 8-byte LDS vectors instead of one
+    // 2-byte read per (pixel, channel, tap) -- the element-wise form issued ~1000 LDS instructions per thread and
+    // was bound by the LDS instruction rate.
     auto pool = [&](auto KC) {
       constexpr int K = decltype(KC)::value;
       for (int p = threadIdx.x; p < HW; p += 256) {
@@ -215,12 +237,12 @@ __global__ __launch_bounds__(256) void spp_pools_bwd_kernel(int H, int W, int C,
         for (int d = 0; d < K; ++d) {
           const int xi = min(max(x + d - K / 2, 0), W - 1);
           float v[SPP_CG];
-          ld8(xs + (y * W + xi) * SPP_CG, v);
+          spp_ld<T, SPP_CG>(xs + (y * W + xi) * SPP_CG, v);
 #pragma unroll
           for (int ch = 0; ch < SPP_CG; ++ch)
             if (d == 0 || v[ch] > best[ch]) { best[ch] = v[ch]; ax[ch] = xi; }
         }
-        st8(rv + p * SPP_CG, best);
+        spp_st<T, SPP_CG>(rv + p * SPP_CG, best);
 #pragma unroll
         for (int ch = 0; ch < SPP_CG; ++ch) ra[p * SPP_CG + ch] = (unsigned short)ax[ch];
       }
@@ -233,17 +255,17 @@ __global__ __launch_bounds__(256) void spp_pools_bwd_kernel(int H, int W, int C,
         for (int d = 0; d < K; ++d) {
           const int yi = min(max(y + d - K / 2, 0), H - 1);
           float v[SPP_CG];
-          ld8(rv + (yi * W + x) * SPP_CG, v);
+          spp_ld<T, SPP_CG>(rv + (yi * W + x) * SPP_CG, v);
 #pragma unroll
           for (int ch = 0; ch < SPP_CG; ++ch)
             if (d == 0 || v[ch] > best[ch]) { best[ch] = v[ch]; ay[ch] = yi; }
         }
         float g[SPP_CG];
-        ld8(dout + ((size_t)n * HW + p) * dl + c0, g);
+        spp_ld<T, SPP_CG>(dout + ((size_t)n * HW + p) * dl + c0, g);
 #pragma unroll
         for (int ch = 0; ch < SPP_CG; ++ch) {
           const int arg = ay[ch] * W + ra[(ay[ch] * W + x) * SPP_CG + ch];
-          atomicAdd(gs + arg * SPP_CG + ch, g[ch]);
+          atomicAdd(gs + arg * SPP_CG + ch, (double)g[ch]);
         }
       }
       __syncthreads();
@@ -279,7 +301,7 @@ __global__ __launch_bounds__(256) void spp_pools_bwd_kernel(int H, int W, int C,
       }
       const int arg = ay * W + ra[(ay * W + x) * SPP_CG + ch];
       const float g = ActT<T>::ld(dout + ((size_t)n * HW + p) * dl + c0 + ch);
-      atomicAdd(gs + arg * SPP_CG + ch, g);
+      atomicAdd(gs + arg * SPP_CG + ch, (double)g);
     }
     __syncthreads();
   }
@@ -287,7 +309,7 @@ __global__ __launch_bounds__(256) void spp_pools_bwd_kernel(int H, int W, int C,
     const int p = it / SPP_CG, ch = it % SPP_CG;
     if (c0 + ch >= C) continue;
     T* dst = din + ((size_t)n * HW + p) * di_ld + c0 + ch;
-    float v = gs[it];
+    float v = (float)gs[it];
     if (accumulate) v += ActT<T>::ld(dst);
     ActT<T>::st(dst, v);
   }
@@ -778,12 +800,19 @@ int plyolo_maxpool_s1_bwd(int dtype, int N, int H, int W, int C, int k, const vo
   });
 }
 
-static size_t spp_bwd_lds(int dtype, int H, int W) {
+static size_t spp_bwd_lds(int dtype, int H, int W, int cg) {
   const size_t es = dtype == PLYOLO_BF16 ? 2 : 4;
-  return (size_t)H * W * SPP_CG * (4 + 2 * es + 2);
+  return (size_t)H * W * cg * (8 + 2 * es + 2);
+}
+// channels per workgroup plane: 8 while the plane fits in LDS, else 4; 0 = does not fit at all
+static int spp_bwd_cg(int dtype, int H, int W) {
+  if (H * W > 65535) return 0;
+  if (spp_bwd_lds(dtype, H, W, 8) <= 150 * 1024) return 8;
+  if (spp_bwd_lds(dtype, H, W, 4) <= 150 * 1024) return 4;
+  return 0;
 }
 
-int plyolo_spp_pools_bwd_fits(int dtype, int H, int W) { return H * W <= 65535 && spp_bwd_lds(dtype, H, W) <= 150 * 1024 ? 1 : 0; }
+int plyolo_spp_pools_bwd_fits(int dtype, int H, int W) { return spp_bwd_cg(dtype, H, W) ? 1 : 0; }
 
 int plyolo_spp_pools_bwd(int dtype, int N, int H, int W, int C, int nk, const int* ks, const void* in, int i_ld,
                          const void* const* douts, const int* d_lds, void* din, int di_ld, int accumulate, void* stream) {
@@ -795,13 +824,15 @@ int plyolo_spp_pools_bwd(int dtype, int N, int H, int W, int C, int nk, const in
     PLY_CHECK_ARG(ks[j] & 1, "spp_pools_bwd: k must be odd");
     k[j] = ks[j]; d[j] = douts[j]; dl[j] = d_lds[j];
   }
-  const size_t lds = spp_bwd_lds(dtype, H, W);
+  const int cg = spp_bwd_cg(dtype, H, W);
+  const size_t lds = spp_bwd_lds(dtype, H, W, cg);
+  PLY_CHECK_ARG(cg == 8 || C % 4 == 0, "spp_pools_bwd: C must be a multiple of 4");
   plyolo::annotate("spp_pools_bwd", 0.0, (double)N * H * W * C * (dtype == PLYOLO_BF16 ? 2.0 : 4.0) * (2.0 + nk));
   return submit(stream, [=](hipStream_t s) -> hipError_t {
     DISPATCH_T(dtype, {
-      auto kern = spp_pools_bwd_kernel<T>;
+      auto kern = cg == 8 ? spp_pools_bwd_kernel<T, 8> : spp_pools_bwd_kernel<T, 4>;
       if (hipError_t e = plyolo::ensure_dynamic_lds((const void*)kern, lds); e != hipSuccess) return e;
-      hipLaunchKernelGGL(kern, dim3(N, cdiv(C, SPP_CG)), dim3(256), lds, s, H, W, C, nk, k[0], k[1], k[2], (const T*)in, i_ld,
+      hipLaunchKernelGGL(kern, dim3(N, cdiv(C, cg)), dim3(256), lds, s, H, W, C, nk, k[0], k[1], k[2], (const T*)in, i_ld,
                          (const T*)d[0], (const T*)d[1], (const T*)d[2], dl[0], dl[1], dl[2], (T*)din, di_ld, accumulate);
     })
     return hipGetLastError();

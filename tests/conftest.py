@@ -21,3 +21,20 @@ def load_golden(name):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+@pytest.fixture(autouse=True)
+def _release_device_memory():
+    """A detector keeps every activation / gradient / dz buffer of its traced shapes resident (YOLOX-x at 1280x1280
+    batch 16: tens of GB) and model <-> runner reference each other, so a finished test's buffers only go away after a
+    cycle collection: collect and hand the blocks back after every test, or the full-size tests of one pytest process
+    pile up to the 288 GB of the GPU."""
+    yield
+    import gc
+    gc.collect()
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()
+    except Exception:
+        pass
