@@ -101,6 +101,38 @@ def cpu_baseline(cfg, nc, size, b=4, budget_s=25.0, threads=""):
 def nms_boxes(B, n):
     """SURVEY 8d set (ii): 200 cluster centres x 5 jittered copies per image -> [B, n, 6] (x1,y1,x2,y2,score,class)."""
     import numpy as np
+    rng = np.random.default_rng(0)
+    boxes = np.zeros((B, n, 6), np.float32)
+    for b in range(B):
+        c = np.repeat(rng.uniform(50, 1230, (n // 5, 2)), 5, 0) + rng.normal(0, 4, (n, 2))
+        wh = np.exp(rng.uniform(np.log(16), np.log(256), (n, 2)))
+        boxes[b, :, 0:2], boxes[b, :, 2:4] = c - wh / 2, c + wh / 2
+        boxes[b, :, 4] = rng.uniform(0.01, 1, n)
+        boxes[b, :, 5] = rng.integers(0, 80, n)
+    return boxes
+
+
+def nms_cpu_baseline(boxes, nms_thre=0.65, max_det=300, reps=3):
+    """The oracle's greedy class-NMS (numpy port of torchvision's published rule, oracle/nms.py) on the same boxes,
+    one host thread -- the CPU figure beside the device boxes/ms."""
+    from oracle import nms as onms
+    B, n = boxes.shape[0], boxes.shape[1]
+    t0 = time.time()
+    kept = 0
+    for _ in range(reps):
+        kept = 0
+        for b in range(B):
+            k = onms.batched_nms(boxes[b, :, 0:4], boxes[b, :, 4], boxes[b, :, 5].astype("int64"), nms_thre)
+            kept += min(len(k), max_det)
+    ms = (time.time() - t0) * 1e3 / reps
+    return {"boxes_per_ms": B * n / ms, "ms_per_batch": ms, "cores": 1, "kind": "port", "kept_mean": kept / B,
+            "sample": "oracle.nms.batched_nms (numpy), %d x %d boxes, %d repetitions" % (B, n, reps)}
+
+
+def nms_bench(device, B=16, n=1000, reps=20, cpu=True):
+    import ctypes as C
+    from pl_yolo_amd import _lib
+    from pl_yolo_amd._lib import NmsDesc, call
     boxes = nms_boxes(B, n)
     d = NmsDesc()
     d.B, d.A, d.C, d.conf_thre, d.nms_thre, d.class_agnostic, d.max_nms, d.max_det, d.numel_threshold = B, n, 80, 0.01, 0.65, 0, 10000, 300, 20000
