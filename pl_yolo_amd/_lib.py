@@ -19,7 +19,9 @@ class PlyoloError(RuntimeError):
 
 
 class ConvDesc(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("dtype", "N", "H", "W", "Cin", "Cout", "ksize", "stride", "x_ld", "y_ld", "y_f32")]
+    # mirrors plyolo_conv_desc (include/plyolo.h); x_coef / x_coef_ld / x_act describe a lazy input (NULL: x as stored)
+    _fields_ = [(n, C.c_int) for n in ("dtype", "N", "H", "W", "Cin", "Cout", "ksize", "stride", "x_ld", "y_ld", "y_f32")] + \
+               [("x_coef", C.c_void_p), ("x_coef_ld", C.c_int), ("x_act", C.c_int)]
 
 
 STAT_SLOTS = 8  # PLYOLO_STAT_SLOTS

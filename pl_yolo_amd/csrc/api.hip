@@ -56,9 +56,16 @@ void conv_mfma_pack_elems(int Cout_total, int Cin_p, int ksize, size_t* wp, size
 int conv_mfma_dgrad(const plyolo_conv_desc*, const void*, const void*, void*, int, void*);
 int conv_mfma_wgrad(const plyolo_conv_desc*, const void*, const void*, float*, void*);
 int conv_mfma_wgrad_slabs(const plyolo_conv_desc*);
+bool conv_pw_enabled();
+int conv_pw_fwd(const plyolo_conv_desc*, const void*, const void*, const float*, void*, double*, const float*, int, const void*, int, void*);
+int conv_pw_dgrad(const plyolo_conv_desc*, const void*, const void*, void*, int, void*);
 int conv_ref_fwd(const plyolo_conv_desc*, const void*, const void*, const float*, void*, double*, void*);
 int conv_ref_dgrad(const plyolo_conv_desc*, const void*, const void*, void*, int, void*);
 int conv_ref_wgrad(const plyolo_conv_desc*, const void*, const void*, float*, void*);
+
+// 1x1 stride-1 layers run on the dedicated pointwise kernel (conv_pw.hip); PLYOLO_PW=0 keeps them on the 3x3 kernel's one-tap path
+static bool lazy_3x3_ok(const plyolo_conv_desc* d) { return d->x_coef_ld % 4 == 0 && ((size_t)d->x_coef & 15) == 0; }   // 16-byte coefficient loads
+static bool is_pointwise(const plyolo_conv_desc* d) { return d->ksize == 1 && d->stride == 1 && conv_pw_enabled(); }
 
 static int check_conv(const plyolo_conv_desc* d, const char* who, bool fwd) {
   PLY_CHECK_ARG(d != nullptr, "%s: null descriptor", who);
@@ -75,6 +82,11 @@ static int check_conv(const plyolo_conv_desc* d, const char* who, bool fwd) {
     const double img = (double)d->H * d->W * (d->x_ld > d->y_ld ? d->x_ld : d->y_ld);
     const double pack = 2.0 * d->ksize * d->ksize * (double)((d->Cout + 31) / 32 * 32) * ((d->Cin + 31) / 32 * 32);
     PLY_CHECK_ARG(img < 2147483000.0 && pack < 2147483000.0, "%s: image plane or weight pack beyond the 32-bit offsets of the bf16 kernels", who);
+    PLY_CHECK_ARG((double)d->N * d->H * d->W < 2147483000.0, "%s: more than 2^31 pixels", who);
+  }
+  if (d->x_coef != nullptr) {
+    PLY_CHECK_ARG(d->x_coef_ld >= d->Cin && d->x_act >= 0 && d->x_act <= PLYOLO_ACT_LRELU, "%s: lazy input needs x_coef_ld >= Cin and a valid x_act", who);
+    PLY_CHECK_ARG(d->dtype != PLYOLO_BF16 || is_pointwise(d) || lazy_3x3_ok(d), "%s: lazy input is not available for this bf16 convolution shape", who);
   }
   return 0;
 }
@@ -304,13 +316,16 @@ int plyolo_plan_graph_launch(plyolo_plan* p, void* stream) {
 
 int plyolo_conv2d_fwd(const plyolo_conv_desc* d, const void* x, const void* wp, const float* bias, void* y, double* stats, void* stream) {
   if (check_conv(d, "conv2d_fwd", true)) return -1;
-  return d->dtype == PLYOLO_BF16 ? conv_mfma_fwd(d, x, wp, bias, y, stats, nullptr, 0, nullptr, 0, stream) : conv_ref_fwd(d, x, wp, bias, y, stats, stream);
+  if (d->dtype != PLYOLO_BF16) return conv_ref_fwd(d, x, wp, bias, y, stats, stream);
+  if (is_pointwise(d)) return conv_pw_fwd(d, x, wp, bias, y, stats, nullptr, 0, nullptr, 0, stream);
+  return conv_mfma_fwd(d, x, wp, bias, y, stats, nullptr, 0, nullptr, 0, stream);
 }
 int plyolo_conv2d_fwd_bn_act(const plyolo_conv_desc* d, const void* x, const void* wp, const float* coef, int act,
                              const void* res, int r_ld, void* y, void* stream) {
   if (check_conv(d, "conv2d_fwd_bn_act", true)) return -1;
   PLY_CHECK_ARG(d->dtype == PLYOLO_BF16 && !d->y_f32 && coef != nullptr, "conv2d_fwd_bn_act: bf16 activations and a coefficient vector required");
   PLY_CHECK_ARG(!res || r_ld % 8 == 0, "conv2d_fwd_bn_act: residual pitch must be a multiple of 8");
+  if (is_pointwise(d)) return conv_pw_fwd(d, x, wp, nullptr, y, nullptr, coef, act, res, r_ld, stream);
   return conv_mfma_fwd(d, x, wp, nullptr, y, nullptr, coef, act, res, r_ld, stream);
 }
 
@@ -328,7 +343,9 @@ int plyolo_pack_elems(int dtype, int Cout_total, int Cin_p, int ksize, size_t* w
 
 int plyolo_conv2d_dgrad(const plyolo_conv_desc* d, const void* dy, const void* wpd, void* dx, int accumulate, void* stream) {
   if (check_conv(d, "conv2d_dgrad", false)) return -1;
-  return d->dtype == PLYOLO_BF16 ? conv_mfma_dgrad(d, dy, wpd, dx, accumulate, stream) : conv_ref_dgrad(d, dy, wpd, dx, accumulate, stream);
+  if (d->dtype != PLYOLO_BF16) return conv_ref_dgrad(d, dy, wpd, dx, accumulate, stream);
+  if (is_pointwise(d)) return conv_pw_dgrad(d, dy, wpd, dx, accumulate, stream);
+  return conv_mfma_dgrad(d, dy, wpd, dx, accumulate, stream);
 }
 int plyolo_conv2d_wgrad_slabs(const plyolo_conv_desc* d) {
   if (check_conv(d, "conv2d_wgrad_slabs", false)) return -1;

@@ -36,6 +36,8 @@ struct ConvP {
   const bf16_t* ep_res;  // fused epilogue only: residual added after the activation (Bottleneck shortcut), or NULL
   int ep_res_ld;
   double* stats;  // fp64 stat slots [PLYOLO_STAT_SLOTS][2][Cout] or NULL
+  const float* pre;  // lazy input (plyolo_conv_desc::x_coef): the halo tile is staged as act(x * pre[c] + pre[pre_ld + c]); padding stays 0
+  int pre_ld, pre_act;
   int N, H, W, Cin, Cout, x_ld, y_ld;
   int OHt, OWt;  // extent of the output position grid handled by this launch
   int OHf, OWf;  // full output tensor spatial dims
@@ -89,7 +91,22 @@ struct ConvJobs {
   int start[5];
 };
 
-template <int BN, int CK, int TH, bool OUT_F32, int ABL, bool DB = false>
+// BatchNorm + activation of the producing layer applied to one staged 16-byte vector (8 channels c .. c+7)
+DEVINL u32x4 pre_apply(u32x4 t, const float* __restrict__ pre, int pre_ld, int act, int c) {
+  const f32x4 s0 = *(const f32x4*)(pre + c), s1 = *(const f32x4*)(pre + c + 4);
+  const f32x4 h0 = *(const f32x4*)(pre + pre_ld + c), h1 = *(const f32x4*)(pre + pre_ld + c + 4);
+  const float sc[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+  const float sh[8] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float lo = act_fwd(fmaf(__uint_as_float(t[i] << 16), sc[2 * i], sh[2 * i]), act);
+    const float hi = act_fwd(fmaf(__uint_as_float(t[i] & 0xffff0000u), sc[2 * i + 1], sh[2 * i + 1]), act);
+    t[i] = pack2bf(lo, hi);
+  }
+  return t;
+}
+
+template <int BN, int CK, int TH, bool OUT_F32, int ABL, bool DB = false, bool PRE = false>
 DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
   constexpr int BM = TH * TW;
   constexpr int WN = BN / 32, WM = 4 / WN, MT = BM / (32 * WM);
@@ -203,9 +220,18 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
   auto halo_store = [&](const int c0, const u32x4* hv, const int boff) {
     const bool cok = c0 + cvt * 8 < p.Cin;
     const u32x4 zero = {0u, 0u, 0u, 0u};
+    if constexpr (PRE) {
+      // lazy input: the 8 channels of this thread's vectors are the same for the whole chunk; their coefficients are
+      // read once (L1/L2 hits) and the affine + activation runs between the global load and the LDS write
+      const int c = cok ? c0 + cvt * 8 : 0;
 #pragma unroll
-    for (int v = 0; v < HVT; ++v)
-      if (loff[v] >= 0) *(u32x4*)(smem + boff + loff[v]) = (goff[v] >= 0 && cok) ? hv[v] : zero;
+      for (int v = 0; v < HVT; ++v)
+        if (loff[v] >= 0) *(u32x4*)(smem + boff + loff[v]) = (goff[v] >= 0 && cok) ? pre_apply(hv[v], p.pre, p.pre_ld, p.pre_act, c) : zero;
+    } else {
+#pragma unroll
+      for (int v = 0; v < HVT; ++v)
+        if (loff[v] >= 0) *(u32x4*)(smem + boff + loff[v]) = (goff[v] >= 0 && cok) ? hv[v] : zero;
+    }
   };
   // generic loader (stride-2 forward tiles): batches of HV 16-byte loads in flight before the first LDS write
   auto halo_generic = [&](const int c0) {
@@ -220,8 +246,10 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
           const int pix = idx / CV, cv = idx - pix * CV;
           const int iy = pix / p.ITW, ix = pix - iy * p.ITW;
           const int gy = iy0 + iy, gx = ix0 + ix, c = c0 + cv * 8;
-          if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && c < p.Cin)
+          if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && c < p.Cin) {
             val = *(const u32x4*)(xn + ((size_t)gy * p.W + gx) * p.x_ld + c);
+            if constexpr (PRE) val = pre_apply(val, p.pre, p.pre_ld, p.pre_act, c);
+          }
         }
         hv[v] = val;
       }
@@ -458,9 +486,9 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
   }
 }
 
-template <int BN, int CK, int TH, bool OUT_F32, int ABL = 0, bool DB = false>
+template <int BN, int CK, int TH, bool OUT_F32, int ABL = 0, bool DB = false, bool PRE = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvP p) {
-  conv_mfma_body<BN, CK, TH, OUT_F32, ABL, DB>(p, (int)blockIdx.x, (int)gridDim.x);
+  conv_mfma_body<BN, CK, TH, OUT_F32, ABL, DB, PRE>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 
 template <int BN, int CK, int TH, bool DB = false>
@@ -471,7 +499,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_jobs_kernel(const ConvJobs j
   conv_mfma_body<BN, CK, TH, false, 0, DB>(jobs.c[j], (int)blockIdx.x - jobs.start[j], jobs.start[j + 1] - jobs.start[j]);
 }
 
-template <int BN, int CK, int TH, bool OUT_F32>
+template <int BN, int CK, int TH, bool OUT_F32, bool PRE = false>
 hipError_t launch_inst(ConvP p, hipStream_t s) {
   constexpr int BM = TH * TW, WN = BN / 32, WM = 4 / WN;
   constexpr int ROWB = CK * 2 + 16;
@@ -481,7 +509,7 @@ hipError_t launch_inst(ConvP p, hipStream_t s) {
   size_t lds_main = (size_t)p.ITH * p.rowp;
   size_t lds_epi = (size_t)BM * SROW + WM * 2 * BN * 4;
   size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
-  auto kern = conv_mfma_kernel<BN, CK, TH, OUT_F32>;
+  auto kern = conv_mfma_kernel<BN, CK, TH, OUT_F32, 0, false, PRE>;
   // double-buffered halo tile: stride-1 tiles with more than one Cin chunk
   constexpr bool HAS_DB = !OUT_F32 && ((TH == 8 && (CK == 32 || CK == 64)) || (TH == 16 && CK == 32));
   if constexpr (HAS_DB) {
@@ -489,11 +517,11 @@ hipError_t launch_inst(ConvP p, hipStream_t s) {
       p.bufsz = p.ITH * p.rowp;
       lds_main = 2 * (size_t)p.bufsz;
       lds = lds_main > lds_epi ? lds_main : lds_epi;
-      kern = conv_mfma_kernel<BN, CK, TH, OUT_F32, 0, true>;
+      kern = conv_mfma_kernel<BN, CK, TH, OUT_F32, 0, true, PRE>;
     }
   }
 #ifdef PLYOLO_DIAG_ABLATE   // diagnostic instantiations (results are wrong by design): make DIAG=1
-  if (BN == 128 && CK == 64 && TH == 16 && !OUT_F32 && p.ablate) {  // diagnostic instantiations of the main shape only
+  if (!PRE && BN == 128 && CK == 64 && TH == 16 && !OUT_F32 && p.ablate) {  // diagnostic instantiations of the main shape only
     switch (p.ablate) {
       case 1: kern = conv_mfma_kernel<128, 64, 16, false, 1>; break;
       case 8: kern = conv_mfma_kernel<128, 64, 16, false, 8>; break;
@@ -520,8 +548,23 @@ hipError_t launch_inst(ConvP p, hipStream_t s) {
   return hipGetLastError();
 }
 
+// lazy-input instances: 16- and 32-channel chunks only (pick_tiles never chooses wider chunks for them)
+template <bool OUT_F32>
+hipError_t launch_bn_pre(const ConvP& p, int BN, int CK, int TH, hipStream_t s) {
+#define PLY_PCASE(bn, ck)                                                         \
+  if (BN == bn && CK == ck) {                                                     \
+    if (TH == 16) return launch_inst<bn, ck, 16, OUT_F32, true>(p, s);            \
+    return launch_inst<bn, ck, 8, OUT_F32, true>(p, s);                           \
+  }
+  PLY_PCASE(32, 16) PLY_PCASE(32, 32) PLY_PCASE(64, 16) PLY_PCASE(64, 32)
+  if (!OUT_F32) { PLY_PCASE(128, 16) PLY_PCASE(128, 32) }
+#undef PLY_PCASE
+  return hipErrorInvalidValue;
+}
+
 template <bool OUT_F32>
 hipError_t launch_bn(const ConvP& p, int BN, int CK, int TH, hipStream_t s) {
+  if (p.pre) return launch_bn_pre<OUT_F32>(p, BN, CK, TH, s);
 #define PLY_CASE(bn, ck)                                                      \
   if (BN == bn && CK == ck) {                                                 \
     if (TH == 16) return launch_inst<bn, ck, 16, OUT_F32>(p, s);              \
@@ -615,6 +658,7 @@ void pick_tiles(const ConvP& p, int ext_y, bool out_f32, int* BN, int* CK, int* 
   if (ck_mode == 1 && th == 8 && p.si == 1 && p.Cin == 128 && !out_f32 && bn >= 64 && ck == 64) ck = 128;
   // the 16-row tile double-buffers its halo only with 32-channel chunks (two 64-channel buffers leave no LDS for a second workgroup)
   if (th == 16 && p.si == 1 && ck == 64 && !out_f32 && p.db >= 2) ck = 32;
+  if (p.pre && ck > 32) ck = 32;   // lazy-input instances exist for 16- / 32-channel chunks
   if (const char* e = getenv("PLYOLO_FORCE_CK")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) ck = v < ck ? v : ck; }
   if (const char* e = getenv("PLYOLO_FORCE_BN")) { const int v = atoi(e); if (v == 32 || v == 64 || v == 128) bn = v < bn ? v : bn; }
   if (const char* e = getenv("PLYOLO_FORCE_TH")) { const int v = atoi(e); if (v == 8 || v == 16) th = v; }
@@ -704,12 +748,13 @@ int conv_mfma_fwd(const plyolo_conv_desc* d, const void* x, const void* wp, cons
   p.ep_act = ep_act;
   p.ep_res = (const bf16_t*)ep_res;
   p.ep_res_ld = ep_res_ld;
+  p.pre = d->x_coef; p.pre_ld = d->x_coef_ld; p.pre_act = d->x_act;
   int BN, CK, TH;
   setup_fwd(d, p, &BN, &CK, &TH);
   const bool f32 = d->y_f32 != 0;
   {
     char lab[64];
-    snprintf(lab, sizeof(lab), "conv_mfma_fwd<BN%d,CK%d,TH%d>%s", BN, CK, TH, f32 ? "f32out" : "");
+    snprintf(lab, sizeof(lab), "conv_mfma_fwd<BN%d,CK%d,TH%d>%s%s", BN, CK, TH, f32 ? "f32out" : "", p.pre ? "+bnact" : "");
     const double M = (double)p.N * p.OHf * p.OWf;
     annotate(lab, 2.0 * M * d->Cout * d->Cin * d->ksize * d->ksize, M * (d->Cout * (f32 ? 4.0 : 2.0)) + (double)d->N * d->H * d->W * d->Cin * 2.0);
   }

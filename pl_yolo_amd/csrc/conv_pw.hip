@@ -1,0 +1,367 @@
+// bf16 MFMA pointwise (1x1, stride 1) convolution for gfx950: forward and data gradient.
+//
+// Replaces nn.Conv2d(kernel_size=1) inside BaseConv (reference models/layers/network_blocks.py:18-26), the
+// prediction convs of DecoupledHead (models/heads/decoupled_head.py:43-62) and what ATen's convolution_backward
+// computes for their inputs.  41 of the 69 convolutions of YOLOX-s are pointwise, all of them HBM- or
+// latency-bound:   Y[M, N] = X[M, K] . W[N, K]^T   with M = N*H*W pixels (12.8 k ... 3.3 M), K, N in 32 ... 1024.
+//
+// The 3x3 kernel (conv_mfma.hip) serves them as a degenerate one-tap case, but pays for its halo machinery on
+// every launch: per-thread halo descriptors, 32-channel chunks with one barrier AND one exposed memory round trip
+// per chunk (a chunk of a 1x1 layer is only 8 MFMAs per wave), 24 KB of loads in flight per CU.  Here:
+//   * one workgroup = 128 pixel rows x BN output channels; the WHOLE K extent of the rows (up to KC = 256
+//     channels, else chunks of 256) is requested up front -- 32-64 KB in flight per workgroup, one memory round
+//     trip and one barrier per tile instead of one per 32 channels;
+//   * A (pixels): 16-byte vectors of full rows -> registers -> [optional BatchNorm + activation of the producing
+//     layer, "lazy input"] -> LDS (row pitch K*2+16 bytes: conflict-free ds_read_b128 fragments);
+//   * B (weights): never touches LDS -- fragment-ordered pack (conv_mfma.hip), one coalesced KiB per fragment
+//     straight into registers, requested BEFORE the pixel rows so both are in flight together;
+//   * epilogue as in the 3x3 kernel: BatchNorm sum / sum-of-squares partials -> fp64 stat slots, bias, LDS
+//     transpose, whole 16-byte channel vectors to HBM, strided store (y_ld) = free concat, accumulate (dgrad).
+// Workgroups sharing a pixel tile (different BN blocks) are adjacent in the XCD-aware tile order: the rows are
+// re-read from that XCD's L2, not from HBM.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+struct PwP {
+  const bf16_t* x;
+  const bf16_t* w;       // fragment-native pack [nb = N/32][kb = K/16][64 lanes][8] (one tap)
+  void* y;
+  const float* bias;
+  const float* ep_coef;  // inference: fused BatchNorm (scale | shift) + activation in the epilogue, or NULL
+  int ep_act;
+  const bf16_t* ep_res;  // fused epilogue only: residual added after the activation, or NULL
+  int ep_res_ld;
+  double* stats;         // fp64 stat slots [PLYOLO_STAT_SLOTS][2][N] or NULL
+  const float* pre;      // lazy input: x is a raw conv output, rows are staged as act(x * pre[c] + pre[pre_ld + c])
+  int pre_ld, pre_act;
+  int M, K, N, x_ld, y_ld;
+  int nkb, nnb;          // packed weight geometry: 16-channel k-blocks, 32-channel n-blocks
+  int nmt, nnblk;        // pixel tiles, BN blocks
+  int accumulate;
+};
+
+DEVINL u32x4 pw_add_bf16x8(u32x4 a, u32x4 b) {
+  u32x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float lo = __uint_as_float(a[i] << 16) + __uint_as_float(b[i] << 16);
+    float hi = __uint_as_float(a[i] & 0xffff0000u) + __uint_as_float(b[i] & 0xffff0000u);
+    r[i] = pack2bf(lo, hi);
+  }
+  return r;
+}
+
+constexpr int PW_BM = 128;
+
+template <int BN, int KC, bool OUT_F32, bool PRE>
+__global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwP p) {
+  constexpr int BM = PW_BM;
+  constexpr int WN = BN / 32, WM = 4 / WN, MT = BM / (32 * WM);
+  constexpr int ROWB = KC * 2 + 16;   // LDS row pitch (bytes)
+  constexpr int CV = KC / 8;          // 16-byte vectors per row
+  constexpr int KS = KC / 16;         // k-steps per chunk
+  constexpr int RPP = 256 / CV;       // rows covered by one pass of the 256 threads
+  constexpr int NV = BM / RPP;        // vectors per thread and chunk
+  extern __shared__ __align__(16) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int r = lane & 31, h = lane >> 5;
+
+  // XCD-aware bijective remap (workgroups with equal blockIdx.x % 8 share an XCD's L2): every XCD gets a contiguous run
+  // of tiles, BN blocks of one pixel tile adjacent
+  int tile;
+  {
+    const int nwg = (int)gridDim.x, bid = (int)blockIdx.x;
+    const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+  }
+  const int nblk = tile % p.nnblk, mt_i = tile / p.nnblk;
+  const int m0 = mt_i * BM;
+  const int cout0 = nblk * BN;
+  const int nb = nblk * WN + wn;   // this wave's 32-channel block of the packed weights
+  const bool nb_ok = nb < p.nnb;
+
+  f32x16 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+
+  const char* wbase = (const char*)p.w + (size_t)((nb_ok ? nb : p.nnb - 1) * p.nkb) * 1024u + (size_t)lane * 16u;
+  const int cvt = tid % CV, row0 = tid / CV;
+  const int nchunks = (p.K + KC - 1) / KC;
+  int arow[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) arow[mt] = ((wm * MT + mt) * 32 + r) * ROWB + h * 16;
+
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    const int c0 = chunk * KC;
+    // ---- weights first (L2-resident, tiny), then the pixel rows: everything this tile needs is in flight at once
+    u32x4 bq[KS];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      const int kb = chunk * KS + kk;
+      // a k-block beyond K meets zero-filled LDS columns (finite weights x 0 = 0): clamp instead of masking
+      bq[kk] = *(const u32x4*)(wbase + (size_t)(kb < p.nkb ? kb : p.nkb - 1) * 1024u);
+    }
+    const int c = c0 + cvt * 8;
+    const bool cok = c < p.K;
+    u32x4 av[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int m = m0 + row0 + v * RPP;
+      const bool ok = cok && m < p.M;
+      av[v] = *(const u32x4*)(p.x + (ok ? (size_t)m * p.x_ld + c : 0));
+    }
+    if (chunk) __syncthreads();   // every wave is done with the previous chunk's rows
+    if constexpr (PRE) {
+      float sc[8], sh[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        sc[i] = cok ? p.pre[c + i] : 0.f;
+        sh[i] = cok ? p.pre[p.pre_ld + c + i] : 0.f;
+      }
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        u32x4 t = av[v];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float lo = act_fwd(fmaf(__uint_as_float(t[i] << 16), sc[2 * i], sh[2 * i]), p.pre_act);
+          const float hi = act_fwd(fmaf(__uint_as_float(t[i] & 0xffff0000u), sc[2 * i + 1], sh[2 * i + 1]), p.pre_act);
+          t[i] = pack2bf(lo, hi);
+        }
+        av[v] = t;
+      }
+    }
+    {
+      const u32x4 zero = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int row = row0 + v * RPP;
+        const bool ok = cok && (m0 + row) < p.M;
+        *(u32x4*)(smem + row * ROWB + cvt * 16) = ok ? av[v] : zero;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      const bf16x8 b = *(const bf16x8*)&bq[kk];
+      bf16x8 a[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) a[mt] = *(const bf16x8*)(smem + arow[mt] + kk * 32);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b, acc[mt], 0, 0, 0);
+    }
+  }
+  __syncthreads();  // all LDS operand reads retired; LDS is reused for the epilogue
+
+  // ---- epilogue ---------------------------------------------------------------
+  constexpr int SROW = OUT_F32 ? (BN + 4) * 4 : (BN * 2 + 16);  // staging row pitch (bytes)
+  float* red = (float*)(smem + BM * SROW);                       // [WM][2][BN]
+
+  if (p.stats != nullptr) {
+    float s1 = 0.f, s2 = 0.f;
+    if (m0 + BM <= p.M) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          s1 += acc[mt][i];
+          s2 = fmaf(acc[mt][i], acc[mt][i], s2);
+        }
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int m = (wm * MT + mt) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          const float v = (m0 + m < p.M) ? acc[mt][i] : 0.f;
+          s1 += v;
+          s2 = fmaf(v, v, s2);
+        }
+    }
+    s1 += __shfl_xor(s1, 32);
+    s2 += __shfl_xor(s2, 32);
+    if (h == 0) {
+      red[(wm * 2 + 0) * BN + wn * 32 + r] = s1;
+      red[(wm * 2 + 1) * BN + wn * 32 + r] = s2;
+    }
+  }
+  const bool fused = !OUT_F32 && p.ep_coef != nullptr;
+  float ep_sc = 1.f, ep_sh = 0.f;
+  if (fused) {
+    const int co = cout0 + wn * 32 + r;
+    if (co < p.N) { ep_sc = p.ep_coef[co]; ep_sh = p.ep_coef[p.N + co]; }
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int m = (wm * MT + mt) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+      const int col = wn * 32 + r;
+      if (OUT_F32)
+        *(float*)(smem + m * SROW + col * 4) = acc[mt][i];
+      else
+        *(bf16_t*)(smem + m * SROW + col * 2) = f2bf(fused ? act_fwd(fmaf(acc[mt][i], ep_sc, ep_sh), p.ep_act) : acc[mt][i]);
+    }
+  __syncthreads();
+
+  if (p.stats != nullptr && tid < BN) {
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int w = 0; w < WM; ++w) {
+      s += red[(w * 2 + 0) * BN + tid];
+      ss += red[(w * 2 + 1) * BN + tid];
+    }
+    const int co = cout0 + tid;
+    if (co < p.N) {  // one fp64 add per workgroup and channel (agent scope); the order cannot change the fp32 result
+      double* slot = p.stats + (size_t)(mt_i % PLYOLO_STAT_SLOTS) * 2 * p.N;
+      __hip_atomic_fetch_add(slot + co, (double)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(slot + p.N + co, (double)ss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+
+  if (OUT_F32) {
+    // fp32 rows (the raw head maps, pitch 5+C floats) are only 4-byte aligned: dwordx4 stores with a 4-byte aligned type
+    typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+    float* y = (float*)p.y;
+    constexpr int VPR4 = BN / 4;
+    for (int idx = tid; idx < BM * VPR4; idx += 256) {
+      const int m = idx / VPR4, v = idx - m * VPR4;
+      const int co = cout0 + v * 4;
+      if (m0 + m < p.M && co < p.N) {
+        f32x4 val = *(const f32x4*)(smem + m * SROW + v * 16);
+        float* dst = y + (size_t)(m0 + m) * p.y_ld + co;
+        if (co + 4 <= p.N) {
+          if (p.bias) val += *(const f32x4_u*)(p.bias + co);
+          if (p.accumulate) val += *(const f32x4_u*)dst;
+          *(f32x4_u*)dst = val;
+        } else {
+          for (int j = 0; co + j < p.N; ++j) {
+            float t = val[j];
+            if (p.bias) t += p.bias[co + j];
+            if (p.accumulate) t += dst[j];
+            dst[j] = t;
+          }
+        }
+      }
+    }
+  } else {
+    bf16_t* y = (bf16_t*)p.y;
+    constexpr int VPR = BN / 8;
+    for (int idx = tid; idx < BM * VPR; idx += 256) {
+      const int m = idx / VPR, v = idx - m * VPR;
+      const int co = cout0 + v * 8;
+      if (m0 + m < p.M && co < p.N) {
+        u32x4 val = *(const u32x4*)(smem + m * SROW + v * 16);
+        const size_t pix = (size_t)(m0 + m);
+        bf16_t* dst = y + pix * p.y_ld + co;
+        if (p.ep_res) val = pw_add_bf16x8(*(const u32x4*)(p.ep_res + pix * p.ep_res_ld + co), val);
+        if (p.accumulate) val = pw_add_bf16x8(*(const u32x4*)dst, val);
+        *(u32x4*)dst = val;
+      }
+    }
+  }
+}
+
+template <int BN, int KC, bool OUT_F32, bool PRE>
+hipError_t pw_launch_inst(const PwP& p, hipStream_t s) {
+  constexpr int WN = BN / 32, WM = 4 / WN;
+  constexpr int ROWB = KC * 2 + 16;
+  constexpr int SROW = OUT_F32 ? (BN + 4) * 4 : (BN * 2 + 16);
+  const size_t lds_main = (size_t)PW_BM * ROWB;
+  const size_t lds_epi = (size_t)PW_BM * SROW + WM * 2 * BN * 4;
+  const size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+  auto kern = conv_pw_kernel<BN, KC, OUT_F32, PRE>;
+  if (hipError_t e = plyolo::ensure_dynamic_lds((const void*)kern, lds); e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(p.nmt * p.nnblk), dim3(256), lds, s, p);
+  return hipGetLastError();
+}
+
+template <bool OUT_F32, bool PRE>
+hipError_t pw_launch(const PwP& p, int BN, int KC, hipStream_t s) {
+#define PW_CASE(bn, kc) \
+  if (BN == bn && KC == kc) return pw_launch_inst<bn, kc, OUT_F32, PRE>(p, s);
+  PW_CASE(32, 32) PW_CASE(32, 64) PW_CASE(32, 128) PW_CASE(32, 256)
+  PW_CASE(64, 32) PW_CASE(64, 64) PW_CASE(64, 128) PW_CASE(64, 256)
+  if constexpr (!OUT_F32) { PW_CASE(128, 32) PW_CASE(128, 64) PW_CASE(128, 128) PW_CASE(128, 256) }
+#undef PW_CASE
+  return hipErrorInvalidValue;
+}
+
+void pw_tiles(PwP& p, bool out_f32, int* BN, int* KC) {
+  int bn = p.N > 64 ? 128 : (p.N > 32 ? 64 : 32);
+  if (out_f32 && bn > 64) bn = 64;
+  int kc = p.K > 128 ? 256 : (p.K > 64 ? 128 : (p.K > 32 ? 64 : 32));
+  if (const char* e = getenv("PLYOLO_PW_KC")) { const int v = atoi(e); if (v == 32 || v == 64 || v == 128 || v == 256) kc = v < kc ? v : kc; }
+  *BN = bn;
+  *KC = kc;
+  p.nmt = (p.M + PW_BM - 1) / PW_BM;
+  p.nnblk = (p.N + bn - 1) / bn;
+}
+
+}  // namespace
+
+namespace plyolo {
+
+// PLYOLO_PW=0 sends the pointwise layers through the 3x3 kernel's one-tap path again (A/B switch)
+bool conv_pw_enabled() {
+  static const bool on = !(getenv("PLYOLO_PW") && atoi(getenv("PLYOLO_PW")) == 0);
+  return on;
+}
+
+int conv_pw_fwd(const plyolo_conv_desc* d, const void* x, const void* wp, const float* bias, void* y, double* stats,
+                const float* ep_coef, int ep_act, const void* ep_res, int ep_res_ld, void* stream) {
+  PwP p{};
+  p.x = (const bf16_t*)x;
+  p.w = (const bf16_t*)wp;
+  p.y = y;
+  p.bias = bias;
+  p.stats = stats;
+  p.ep_coef = ep_coef; p.ep_act = ep_act; p.ep_res = (const bf16_t*)ep_res; p.ep_res_ld = ep_res_ld;
+  p.pre = d->x_coef; p.pre_ld = d->x_coef_ld; p.pre_act = d->x_act;
+  p.M = d->N * d->H * d->W;
+  p.K = d->Cin; p.N = d->Cout; p.x_ld = d->x_ld; p.y_ld = d->y_ld;
+  p.nkb = (d->Cin + 15) / 16;
+  p.nnb = (d->Cout + 31) / 32;
+  const bool f32 = d->y_f32 != 0, pre = p.pre != nullptr;
+  int BN, KC;
+  pw_tiles(p, f32, &BN, &KC);
+  {
+    char lab[64];
+    snprintf(lab, sizeof(lab), "conv_pw_fwd<BN%d,KC%d>%s%s", BN, KC, f32 ? "f32out" : "", pre ? "+bnact" : "");
+    annotate(lab, 2.0 * p.M * (double)d->Cout * d->Cin, (double)p.M * (d->Cout * (f32 ? 4.0 : 2.0) + d->Cin * 2.0));
+  }
+  return submit(stream, [=](hipStream_t s) {
+    if (f32) return pre ? pw_launch<true, true>(p, BN, KC, s) : pw_launch<true, false>(p, BN, KC, s);
+    return pre ? pw_launch<false, true>(p, BN, KC, s) : pw_launch<false, false>(p, BN, KC, s);
+  });
+}
+
+// dx[M, Cin] (+)= dy[M, Cout_p8] . Wd   (weights in the dgrad fragment pack: n-blocks over Cin, k-blocks over Cout)
+int conv_pw_dgrad(const plyolo_conv_desc* d, const void* dy, const void* wpd, void* dx, int accumulate, void* stream) {
+  PwP p{};
+  p.x = (const bf16_t*)dy;
+  p.w = (const bf16_t*)wpd;
+  p.y = dx;
+  p.M = d->N * d->H * d->W;
+  p.K = (d->Cout + 7) & ~7;   // dy rows are read in 16-byte vectors
+  p.N = d->Cin; p.x_ld = d->y_ld; p.y_ld = d->x_ld;
+  p.nkb = (d->Cout + 15) / 16;
+  p.nnb = (d->Cin + 31) / 32;
+  p.accumulate = accumulate;
+  int BN, KC;
+  pw_tiles(p, false, &BN, &KC);
+  {
+    char lab[64];
+    snprintf(lab, sizeof(lab), "conv_pw_dgrad<BN%d,KC%d>", BN, KC);
+    annotate(lab, 2.0 * p.M * (double)d->Cout * d->Cin, (double)p.M * (p.K + d->Cin * (accumulate ? 2.0 : 1.0)) * 2.0);
+  }
+  return submit(stream, [=](hipStream_t s) { return pw_launch<false, false>(p, BN, KC, s); });
+}
+
+}  // namespace plyolo

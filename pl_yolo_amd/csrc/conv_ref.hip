@@ -14,7 +14,14 @@ struct RefP {
   float* y;
   const float* bias;
   int N, H, W, OH, OW, Cin, Cout, x_ld, y_ld, ks, stride, pad, accumulate, Kc;
+  const float* pre;   // lazy input (plyolo_conv_desc::x_coef): x is read as act(x * pre[c] + pre[pre_ld + c])
+  int pre_ld, pre_act;
 };
+
+DEVINL float ref_x(const float* xr, int ci, const float* pre, int pre_ld, int pre_act) {
+  const float v = xr[ci];
+  return pre ? act_fwd_precise(fmaf(v, pre[ci], pre[pre_ld + ci]), pre_act) : v;
+}
 
 // one thread per (output pixel, co); co fastest so a wave shares the input pixel
 __global__ void k_conv_ref_fwd(const RefP p) {
@@ -36,7 +43,7 @@ __global__ void k_conv_ref_fwd(const RefP p) {
       if (ix < 0 || ix >= p.W) continue;
       const float* xr = p.x + ((size_t)(n * p.H + iy) * p.W + ix) * p.x_ld;
       const float* wr = p.w + ((size_t)(kh * p.ks + kw) * p.Cout + co) * p.Cin;
-      for (int ci = 0; ci < p.Cin; ++ci) acc = fmaf(xr[ci], wr[ci], acc);
+      for (int ci = 0; ci < p.Cin; ++ci) acc = fmaf(ref_x(xr, ci, p.pre, p.pre_ld, p.pre_act), wr[ci], acc);
     }
   }
   if (p.bias) acc += p.bias[co];
@@ -77,7 +84,8 @@ __global__ void k_conv_ref_dgrad(const RefP p) {
 
 // dwp[tap][co][ci] += sum_pixels dy*x ; thread per (tap,co,ci), pixel range split over gridDim.y
 __global__ void k_conv_ref_wgrad(const float* x, const float* dy, float* dwp, int N, int H, int W, int OH, int OW,
-                               int Cin, int Cout, int x_ld, int dy_ld, int ks, int stride, int pad) {
+                               int Cin, int Cout, int x_ld, int dy_ld, int ks, int stride, int pad, const float* pre, int pre_ld,
+                               int pre_act) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int total = ks * ks * Cout * Cin;
   if (idx >= total) return;
@@ -97,7 +105,7 @@ __global__ void k_conv_ref_wgrad(const float* x, const float* dy, float* dwp, in
     const int n = (int)(m2 / OH);
     const int iy = oy * stride + kh - pad, ix = ox * stride + kw - pad;
     if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
-    acc += (double)dy[m * dy_ld + co] * (double)x[((size_t)(n * H + iy) * W + ix) * x_ld + ci];
+    acc += (double)dy[m * dy_ld + co] * (double)ref_x(x + ((size_t)(n * H + iy) * W + ix) * x_ld, ci, pre, pre_ld, pre_act);
   }
   atomicAdd(dwp + idx, (float)acc);
 }
@@ -134,6 +142,7 @@ static RefP make(const plyolo_conv_desc* d) {
   p.OW = (d->W + 2 * p.pad - d->ksize) / d->stride + 1;
   p.Cin = d->Cin; p.Cout = d->Cout; p.x_ld = d->x_ld; p.y_ld = d->y_ld;
   p.Kc = (d->Cout + 7) & ~7;
+  p.pre = d->x_coef; p.pre_ld = d->x_coef_ld; p.pre_act = d->x_act;
   return p;
 }
 
@@ -153,6 +162,7 @@ int conv_ref_fwd(const plyolo_conv_desc* d, const void* x, const void* wp, const
 int conv_ref_dgrad(const plyolo_conv_desc* d, const void* dy, const void* wpd, void* dx, int accumulate, void* stream) {
   RefP p = make(d);
   p.x = (const float*)dy; p.w = (const float*)wpd; p.y = (float*)dx; p.accumulate = accumulate;
+  p.pre = nullptr;   // the data gradient never reads x
   // roles: p.x_ld must be dy's pitch, p.y_ld dx's pitch
   p.x_ld = d->y_ld; p.y_ld = d->x_ld;
   const size_t total = (size_t)p.N * p.H * p.W * p.Cin;
@@ -173,7 +183,7 @@ int conv_ref_wgrad(const plyolo_conv_desc* d, const void* x, const void* dy, flo
   const float* dyf = (const float*)dy;
   return submit(stream, [=](hipStream_t s) -> hipError_t {
     hipLaunchKernelGGL(k_conv_ref_wgrad, dim3(cdiv(total, 128), split), dim3(128), 0, s, xf, dyf, dwp, p.N, p.H, p.W, p.OH, p.OW,
-                       p.Cin, p.Cout, p.x_ld, p.y_ld, p.ks, p.stride, p.pad);
+                       p.Cin, p.Cout, p.x_ld, p.y_ld, p.ks, p.stride, p.pad, p.pre, p.pre_ld, p.pre_act);
     return hipGetLastError();
   });
 }

@@ -32,6 +32,8 @@ struct WgP {
   int N, H, W, OH, OW, Cin, Cout, x_ld, dy_ld;
   int si, pad, ITH, ITW;
   int tiles_y, tiles_x, ntiles;
+  const float* pre;  // lazy input (plyolo_conv_desc::x_coef): X tiles are staged as act(x * pre[c] + pre[pre_ld + c]), padding stays zero
+  int pre_ld, pre_act;
   int nci;  // number of ci tiles (blockIdx.y = co_tile * nci + ci_tile)
   int ablate;  // diagnostics (PLYOLO_ABLATE_WG): 1 skip atomics, 2 skip tile loads after the first, 4 skip MFMA, 8 force S
 };
@@ -46,7 +48,7 @@ constexpr int pitch_for(int ch) { return ch * 2 + ((ch * 2) % 128 == 0 ? 64 : 0)
 
 // CO_T x CI_T: dW slab of the workgroup; MTC x MTI: 32x32 MFMA tiles per wave along co / ci;
 // WK: waves that split the k-steps (tile rows) of one slab (small-channel layers); TH_: tile rows.
-template <int CO_T, int CI_T, int KS, int WK, int MTC, int MTI, int TH_, int SI>
+template <int CO_T, int CI_T, int KS, int WK, int MTC, int MTI, int TH_, int SI, bool PRE>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
   constexpr int NTAPS = KS * KS;
   constexpr int WCO = CO_T / (32 * MTC), WCI = CI_T / (32 * MTI);
@@ -85,6 +87,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
   constexpr int NXV = ITH_ * ITW_ * XV;
   constexpr int HV = (NXV + 255) / 256;
   u32x4 dv[DV], hv[HV];
+  // lazy input: a thread always stages the same 8 input channels (256 % XV == 0), so their BatchNorm coefficients sit in
+  // registers for the whole kernel; `hmask` remembers which of the prefetched vectors are real pixels (padding stays 0)
+  unsigned hmask = 0u;
+  float psc[PRE ? 8 : 1], psh[PRE ? 8 : 1];
+  if constexpr (PRE) {
+    static_assert(256 % XV == 0 && HV <= 32, "lazy input staging assumes a fixed channel vector per thread");
+    const int ci = ci0 + (tid % XV) * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      psc[i] = ci < p.Cin ? p.pre[ci + i] : 0.f;
+      psh[i] = ci < p.Cin ? p.pre[p.pre_ld + ci + i] : 0.f;
+    }
+  }
   auto prefetch = [&](int tile) {
     const int txi = tile % p.tiles_x;
     const int t2 = tile / p.tiles_x;
@@ -105,6 +120,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
       dv[v] = val;
     }
     const bf16_t* xn = p.x + (size_t)n * p.H * p.W * p.x_ld;
+    hmask = 0u;
 #pragma unroll
     for (int v = 0; v < HV; ++v) {
       const int idx = tid + v * 256;
@@ -113,8 +129,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
         const int pix = idx / XV, vv = idx - pix * XV;
         const int iy = pix / ITW_, ix = pix - iy * ITW_;
         const int gy = iy0 + iy, gx = ix0 + ix, ci = ci0 + vv * 8;
-        if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && ci < p.Cin)
+        if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && ci < p.Cin) {
           val = *(const u32x4*)(xn + ((size_t)gy * p.W + gx) * p.x_ld + ci);
+          if constexpr (PRE) hmask |= 1u << v;
+        }
       }
       hv[v] = val;
     }
@@ -133,7 +151,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
       const int idx = tid + v * 256;
       if (idx < NXV) {
         const int pix = idx / XV, vv = idx - pix * XV;
-        *(u32x4*)(x_s + pix * XB + vv * 16) = hv[v];
+        u32x4 t = hv[v];
+        if constexpr (PRE) {
+          if (hmask & (1u << v)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float lo = act_fwd(fmaf(__uint_as_float(t[i] << 16), psc[2 * i], psh[2 * i]), p.pre_act);
+              const float hi = act_fwd(fmaf(__uint_as_float(t[i] & 0xffff0000u), psc[2 * i + 1], psh[2 * i + 1]), p.pre_act);
+              t[i] = pack2bf(lo, hi);
+            }
+          }
+        }
+        *(u32x4*)(x_s + pix * XB + vv * 16) = t;
       }
     }
   };
@@ -201,13 +230,8 @@ template <int CO_T, int CI_T, int KS, int WK, int MTC, int MTI, int TH_, int SI>
 hipError_t launch_wg(const WgP& p, int S, hipStream_t s) {
   constexpr int DZB = pitch_for(CO_T), XB = pitch_for(CI_T);
   const size_t lds = (size_t)TH_ * TW * DZB + (size_t)((TH_ - 1) * SI + KS) * ((TW - 1) * SI + KS) * XB;
-  auto kern = conv_wgrad_kernel<CO_T, CI_T, KS, WK, MTC, MTI, TH_, SI>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    attr_done = true;
-  }
+  auto kern = p.pre ? conv_wgrad_kernel<CO_T, CI_T, KS, WK, MTC, MTI, TH_, SI, true> : conv_wgrad_kernel<CO_T, CI_T, KS, WK, MTC, MTI, TH_, SI, false>;
+  if (hipError_t e = plyolo::ensure_dynamic_lds((const void*)kern, 160 * 1024); e != hipSuccess) return e;
   const int nco = (p.Cout + CO_T - 1) / CO_T;
   dim3 grid(S, nco * p.nci);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
@@ -229,6 +253,7 @@ static WgPlan plan_wgrad(const plyolo_conv_desc* d) {
   p.OW = (d->W + 2 * pad - d->ksize) / d->stride + 1;
   p.Cin = d->Cin; p.Cout = (d->Cout + 7) & ~7;  // dy rows carry Cout rounded up to 8 channels (zeros)
   p.x_ld = d->x_ld; p.dy_ld = d->y_ld;
+  p.pre = d->x_coef; p.pre_ld = d->x_coef_ld; p.pre_act = d->x_act;
   p.si = d->stride; p.pad = pad;
   if (d->ksize == 1 && d->stride == 1 && ((size_t)d->N * d->H * d->W) % TW == 0) {
     const int rows = (int)((size_t)d->N * d->H * d->W / TW);
@@ -304,7 +329,7 @@ int conv_mfma_wgrad(const plyolo_conv_desc* d, const void* x, const void* dy, fl
   const bool th16 = w.th == 16;
   {
     char lab[64];
-    snprintf(lab, sizeof(lab), "conv_wgrad<%dx%d,k%d>", w.CO_T, w.CI_T, ks);
+    snprintf(lab, sizeof(lab), "conv_wgrad<%dx%d,k%d>%s", w.CO_T, w.CI_T, ks, p.pre ? "+bnact" : "");
     const double Mo = (double)p.N * p.OH * p.OW, Mi = (double)p.N * p.H * p.W;
     annotate(lab, 2.0 * Mo * d->Cout * d->Cin * ks * ks, (Mo * d->Cout + Mi * d->Cin) * 2.0 + 4.0 * ks * ks * d->Cout * d->Cin);
   }

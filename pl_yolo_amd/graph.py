@@ -51,6 +51,13 @@ class Act:
         storage.views += 1
         storage.acts.append(self)
         self.fixed = False  # True once something depends on the placement
+        # lazy activation (training plans): `producer` = the conv unit whose BatchNorm + activation would write this
+        # tensor; consumers that can apply them while they stage their input register in `lazy_users`, every other
+        # reader sets `needs_tensor`.  Resolved by Graph.resolve_lazy() after the trace: `lazy` = LazySrc or None.
+        self.producer = None
+        self.lazy_users = []
+        self.needs_tensor = False
+        self.lazy = None
 
     N = property(lambda s: s.storage.N)
     H = property(lambda s: s.storage.H)
@@ -59,11 +66,20 @@ class Act:
     M = property(lambda s: s.storage.rows)
 
     def rebind(self, storage, c_off):
+        self.needs_tensor = True   # placed inside a concat matrix: the consumer reads the matrix, not this unit's z
         self.storage.views -= 1
         self.storage.acts.remove(self)
         self.storage, self.c_off = storage, c_off
         storage.views += 1
         storage.acts.append(self)
+
+
+class LazySrc:
+    """Where a lazy activation really lives: channels [c_off, c_off + C) of the producer's raw conv output `z`
+    (pitch z.ld) + the producer's coefficient table (scale | shift | mean | invstd, row pitch coef_ld) + activation."""
+
+    def __init__(self, op, z, c_off, act):
+        self.op, self.z, self.c_off, self.act = op, z, c_off, act
 
 
 class Graph:
@@ -92,6 +108,50 @@ class Graph:
         # into each convolution's epilogue instead (ConvUnitOp.fwd), which needs one output matrix per conv
         self.pair_convs = os.environ.get("PLYOLO_PAIR", "1") == "1" and training
         self.fuse_eval = os.environ.get("PLYOLO_FUSE_EVAL", "1") == "1"
+        # lazy activations (training, PLYOLO_LAZY=1): a BaseConv whose output only feeds convolutions does not write it --
+        # the consumers apply BatchNorm + activation to the raw conv output while staging it (plyolo_conv_desc.x_coef).
+        # Bit-identical to the materialised path and OFF by default: measured on YOLOX-s B=32 it removes 36 of the 63
+        # bn_act_fwd passes (-0.72 ms) but costs +0.75 ms in the forward convolutions and +1.8 ms in the weight-gradient
+        # kernels (10.5 -> 12.2 ms/step): SiLU is 2 transcendental + ~6 plain VALU instructions per element, the whole
+        # chip sustains ~3.8 T SiLU/s -- the same order as the HBM stream itself -- so inside a loader the work does not
+        # disappear, it lengthens every workgroup's load -> stage -> MFMA chain
+        self.lazy_acts = os.environ.get("PLYOLO_LAZY", "0") == "1" and training
+
+    # ------------------------------------------------------------------ lazy activations
+    def resolve_lazy(self):
+        """After the trace: decide per conv unit whether its activated output is materialised (bn_act_fwd, as the
+        reference does) or stays lazy.  Lazy needs: every reader is a convolution that registered as lazy-capable, no
+        residual is added by the unit, and the output was not placed into a concat matrix."""
+        n = 0
+        for op in self.ops:
+            outs = op.lazy_outputs() if hasattr(op, "lazy_outputs") else []
+            ok = self.lazy_acts and bool(outs) and all(a.lazy_users and not a.needs_tensor for a, _ in outs)
+            for a, c_off in outs:
+                if ok:
+                    a.lazy = LazySrc(op, op.z, c_off, op.act)
+                    if a.storage in self.storages:
+                        self.storages.remove(a.storage)   # never allocated forward; its gradient matrix still is
+                    n += 1
+            if hasattr(op, "lazy_out"):
+                op.lazy_out = ok
+        self.n_lazy = n
+
+    def src(self, a):
+        """(device pointer, pitch) a convolution reads for activation view `a`: the tensor itself, or the producer's z."""
+        if a.lazy is not None:
+            lz = a.lazy
+            return lz.z.tensor.data_ptr() + lz.c_off * self.esize, lz.z.ld
+        return self.aptr(a), a.ld
+
+    def set_lazy(self, desc, a):
+        """Fill the lazy-input fields of a conv descriptor for input view `a` (no-op for a materialised input)."""
+        if a.lazy is None:
+            desc.x_coef, desc.x_coef_ld, desc.x_act = None, 0, 0
+            return desc
+        lz = a.lazy
+        desc.x_coef = lz.op.coef.data_ptr() + lz.c_off * 4
+        desc.x_coef_ld, desc.x_act = lz.op.Cout, lz.act
+        return desc
 
     # ------------------------------------------------------------------ lanes
     def add_op(self, op):
@@ -181,6 +241,7 @@ class Graph:
     # --------------------------------------------------------------- allocation
     def allocate(self):
         dev = self.device
+        self.resolve_lazy()
         for st in self.storages:
             st.tensor = torch.empty(st.rows * st.ld, dtype=self.tdtype, device=dev)
         # shared dz scratch (only used without lanes; with lanes every conv unit owns its dz buffer, see dz_buffer)
@@ -433,9 +494,17 @@ def conv_desc(g, N, H, W, Cin, Cout, k, stride, x_ld, y_ld, y_f32=0):
 
 
 # ------------------------------------------------------------------------- ops
+def _copy_desc(d):
+    """A by-value copy of a ctypes descriptor."""
+    c = type(d)()
+    C.memmove(C.byref(c), C.byref(d), C.sizeof(d))
+    return c
+
+
 class CopyOp:
     def __init__(self, g, src, dst):
         self.g, self.src, self.dst = g, src, dst
+        src.needs_tensor = True
 
     def fwd(self):
         g = self.g
@@ -465,6 +534,11 @@ class ConvUnitOp:
         self.pc = PackedConv(g, [(conv_w, None, 0)], k, self.Cin_p, need_dgrad)
         self.need_dgrad = need_dgrad
         self.out = g.new_act(x.N, self.OH, self.OW, Cout, "a")
+        self.out.producer = self
+        self.lazy_out = False          # set by Graph.resolve_lazy(): the activated output is never written
+        x.lazy_users.append(self)      # this unit can apply its producer's BatchNorm + activation while staging x
+        if residual is not None:
+            residual.needs_tensor = True
         self.z = Storage(x.N, self.OH, self.OW, Cout, "z")
         g.storages.append(self.z)
         self.Cout = Cout
@@ -473,11 +547,22 @@ class ConvUnitOp:
         g.scratch_elems = max(g.scratch_elems, self.z.rows * Cout)
         g.add_op(self)
 
+    def lazy_outputs(self):
+        """[(activation view, channel offset inside z)] that may stay lazy: a residual is added by bn_act_fwd, so a unit
+        with a shortcut always writes its output."""
+        return [(self.out, 0)] if (self.bn is not None and self.res is None and self.g.training) else []
+
     def _alloc_small(self):
         g = self.g
         if hasattr(self, "coef"):
             return
-        self.desc.x_ld = self.x.ld
+        # desc: forward + weight gradient (x as stored, or the producer's z with its coefficients); desc_d: data gradient
+        # (its x_ld is the pitch of the GRADIENT matrix of x, which a lazy input still owns)
+        self.xptr, self.desc.x_ld = g.src(self.x)
+        g.set_lazy(self.desc, self.x)
+        self.desc_d = _copy_desc(self.desc)
+        self.desc_d.x_ld = self.x.ld
+        self.desc_d.x_coef, self.desc_d.x_coef_ld, self.desc_d.x_act = None, 0, 0
         self.coef = torch.empty(4 * self.Cout, dtype=torch.float32, device=g.device)
 
     def fwd(self):
@@ -497,7 +582,7 @@ class ConvUnitOp:
                  g.aptr(self.res) if self.res is not None else None, self.res.ld if self.res is not None else 0, g.aptr(self.out), None)
             return
         slots = g.stat_arena.data_ptr() + self.slot_off * 8 if train_stats else None
-        call("plyolo_conv2d_fwd", C.byref(self.desc), g.aptr(self.x), self.pc.wp, None, zt.data_ptr(), slots, None)
+        call("plyolo_conv2d_fwd", C.byref(self.desc), self.xptr, self.pc.wp, None, zt.data_ptr(), slots, None)
         coef, st = None, None
         if bn is not None:
             coef = self.coef.data_ptr()
@@ -508,6 +593,12 @@ class ConvUnitOp:
                 st.eps, st.momentum = float(bn.eps), float(bn.momentum)
                 st.running_mean, st.running_var = ptr(bn.running_mean), ptr(bn.running_var)
                 st.num_batches_tracked = ptr(bn.num_batches_tracked)
+                if self.lazy_out:
+                    # every reader applies scale/shift + activation itself while staging z: only the per-channel
+                    # coefficients (and the running statistics) are produced here -- one tiny launch instead of a
+                    # read-z / write-a pass over the whole tensor
+                    call("plyolo_bn_finalize", C.byref(st), self.Cout, coef, None)
+                    return
             else:
                 call("plyolo_bn_eval_coef", self.Cout, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
                      ptr(bn.running_var), float(bn.eps), coef, None)
@@ -535,10 +626,10 @@ class ConvUnitOp:
         def dgrad():
             if self.need_dgrad:
                 acc = g.grad_mode(self.x)
-                call("plyolo_conv2d_dgrad", C.byref(self.desc), dz, self.pc.wpd, g.gptr(self.x), acc, None)
+                call("plyolo_conv2d_dgrad", C.byref(self.desc_d), dz, self.pc.wpd, g.gptr(self.x), acc, None)
 
         def wgrad():
-            call("plyolo_conv2d_wgrad", C.byref(self.desc), g.aptr(self.x), dz, self.pc.dwp, None)
+            call("plyolo_conv2d_wgrad", C.byref(self.desc), self.xptr, dz, self.pc.dwp, None)
             self.pc.reduce_slabs()
 
         if lanes:
@@ -571,6 +662,9 @@ class ConvPairOp:
         self.pc = PackedConv(g, [(conv_a, None, 0), (conv_b, None, Ca)], k, Cin, True)
         self.out_a = g.new_act(x.N, self.OH, self.OW, Ca, "a")
         self.out_b = g.new_act(x.N, self.OH, self.OW, Cb, "a")
+        self.out_a.producer = self.out_b.producer = self
+        self.lazy_out = False
+        x.lazy_users.append(self)
         self.out = self.out_a
         self.z = Storage(x.N, self.OH, self.OW, self.Cout, "z")
         g.storages.append(self.z)
@@ -580,6 +674,10 @@ class ConvPairOp:
         self.need_dgrad, self.bn, self.res = True, bn_a, None
         g.add_op(self)
 
+    def lazy_outputs(self):
+        """Both halves or none (one bn_act launch writes both)."""
+        return [(self.out_a, 0), (self.out_b, self.Ca)] if self.g.training else []
+
     def _split(self, base_ptr_fn, act_b):
         sp = Split()
         sp.split, sp.p2, sp.ld2 = self.Ca, base_ptr_fn(act_b), act_b.ld
@@ -588,11 +686,15 @@ class ConvPairOp:
     def fwd(self):
         g, a, b = self.g, self.bn_a, self.bn_b
         if not hasattr(self, "coef"):
-            self.desc.x_ld = self.x.ld
+            self.xptr, self.desc.x_ld = g.src(self.x)
+            g.set_lazy(self.desc, self.x)
+            self.desc_d = _copy_desc(self.desc)
+            self.desc_d.x_ld = self.x.ld
+            self.desc_d.x_coef, self.desc_d.x_coef_ld, self.desc_d.x_act = None, 0, 0
             self.coef = torch.empty(4 * self.Cout, dtype=torch.float32, device=g.device)
         zt = self.z.tensor
         slots = g.stat_arena.data_ptr() + self.slot_off * 8 if g.training else None
-        call("plyolo_conv2d_fwd", C.byref(self.desc), g.aptr(self.x), self.pc.wp, None, zt.data_ptr(), slots, None)
+        call("plyolo_conv2d_fwd", C.byref(self.desc), self.xptr, self.pc.wp, None, zt.data_ptr(), slots, None)
         st = None
         if g.training:
             st = BnStats()
@@ -601,6 +703,9 @@ class ConvPairOp:
             st.eps, st.momentum, st.split = float(a.eps), float(a.momentum), self.Ca
             st.running_mean, st.running_var, st.num_batches_tracked = ptr(a.running_mean), ptr(a.running_var), ptr(a.num_batches_tracked)
             st.running_mean2, st.running_var2, st.num_batches_tracked2 = ptr(b.running_mean), ptr(b.running_var), ptr(b.num_batches_tracked)
+            if self.lazy_out:
+                call("plyolo_bn_finalize", C.byref(st), self.Cout, self.coef.data_ptr(), None)
+                return
         else:
             for bn, off, n in ((a, 0, self.Ca), (b, self.Ca, self.Cb)):
                 call("plyolo_bn_eval_coef_at", n, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var),
@@ -631,15 +736,15 @@ class ConvPairOp:
         acc = g.grad_mode(self.x)
 
         def wgrad():
-            call("plyolo_conv2d_wgrad", C.byref(self.desc), g.aptr(self.x), dz, self.pc.dwp, None)
+            call("plyolo_conv2d_wgrad", C.byref(self.desc), self.xptr, dz, self.pc.dwp, None)
             self.pc.reduce_slabs()
 
         if lanes:
-            call("plyolo_conv2d_dgrad", C.byref(self.desc), dz, self.pc.wpd, g.gptr(self.x), acc, None)
+            call("plyolo_conv2d_dgrad", C.byref(self.desc_d), dz, self.pc.wpd, g.gptr(self.x), acc, None)
             g.defer_param_grads(me, wgrad)
         else:
             wgrad()
-            call("plyolo_conv2d_dgrad", C.byref(self.desc), dz, self.pc.wpd, g.gptr(self.x), acc, None)
+            call("plyolo_conv2d_dgrad", C.byref(self.desc_d), dz, self.pc.wpd, g.gptr(self.x), acc, None)
 
 
 class ActOp:
@@ -648,6 +753,7 @@ class ActOp:
 
     def __init__(self, g, x, act):
         self.g, self.x, self.act = g, x, ACT[act]
+        x.needs_tensor = True
         self.out = g.new_act(x.N, x.H, x.W, x.C, "act")
         g.add_op(self)
 
@@ -669,6 +775,9 @@ class BnOnlyOp:
 
     def __init__(self, g, x, bn, residual=None):
         self.g, self.x, self.bn, self.res = g, x, bn, residual
+        x.needs_tensor = True
+        if residual is not None:
+            residual.needs_tensor = True
         self.Cout = x.C
         self.out = g.new_act(x.N, x.H, x.W, x.C, "bn")
         g.scratch_elems = max(g.scratch_elems, x.M * x.C)
@@ -717,6 +826,7 @@ class BnOnlyOp:
 class UpsampleOp:
     def __init__(self, g, x):
         self.g, self.x = g, x
+        x.needs_tensor = True
         self.out = g.new_act(x.N, 2 * x.H, 2 * x.W, x.C, "up")
         g.add_op(self)
 
@@ -739,6 +849,7 @@ class SppPoolsOp:
 
     def __init__(self, g, x, ks=(5, 9, 13)):
         self.g, self.x, self.ks = g, x, tuple(ks)
+        x.needs_tensor = True
         self.outs = [g.new_act(x.N, x.H, x.W, x.C, "pool%d" % k) for k in ks]
         g.scratch_f32 = max(g.scratch_f32, x.M * x.C)
         g.add_op(self)
@@ -779,6 +890,7 @@ class MaxPool2x2Op:
 
     def __init__(self, g, x):
         self.g, self.x = g, x
+        x.needs_tensor = True
         self.out = g.new_act(x.N, x.H // 2, x.W // 2, x.C, "mp2")
         g.add_op(self)
 
@@ -803,6 +915,7 @@ class ImplicitHeadOp:
 
     def __init__(self, g, head, level, x, conv, ia, im):
         self.g, self.head, self.level, self.x = g, head, level, x
+        x.needs_tensor = True
         self.conv, self.ia, self.im = conv, ia, im
         self.Cout, self.Cin = conv.weight.shape[0], conv.weight.shape[1]
         self.pc = PackedConv(g, [(conv.weight, None, 0)], 1, self.Cin)  # bias handled by implicit_bias
@@ -943,6 +1056,8 @@ class HeadPredOp:
     def __init__(self, g, head, level, cls_feat, reg_feat, cls_conv, reg_conv, obj_conv):
         self.g, self.head, self.level = g, head, level
         self.cls_feat, self.reg_feat = cls_feat, reg_feat
+        cls_feat.lazy_users.append(self)
+        reg_feat.lazy_users.append(self)
         self.nc = cls_conv.weight.shape[0]
         Cin = cls_conv.weight.shape[1]
         self.pc_cls = PackedConv(g, [(cls_conv.weight, cls_conv.bias, 0)], 1, Cin)
@@ -958,9 +1073,12 @@ class HeadPredOp:
     def fwd(self):
         g, hd = self.g, self.head
         base = hd.raw.data_ptr() + hd.lvl_row[self.level] * hd.nch * 4
-        self.d_cls.x_ld, self.d_ro.x_ld = self.cls_feat.ld, self.reg_feat.ld
-        call("plyolo_conv2d_fwd", C.byref(self.d_ro), g.aptr(self.reg_feat), self.pc_ro.wp, self.pc_ro.bp, base, None, None)
-        call("plyolo_conv2d_fwd", C.byref(self.d_cls), g.aptr(self.cls_feat), self.pc_cls.wp, self.pc_cls.bp, base + 5 * 4, None, None)
+        self.x_cls, self.d_cls.x_ld = g.src(self.cls_feat)
+        self.x_ro, self.d_ro.x_ld = g.src(self.reg_feat)
+        g.set_lazy(self.d_cls, self.cls_feat)
+        g.set_lazy(self.d_ro, self.reg_feat)
+        call("plyolo_conv2d_fwd", C.byref(self.d_ro), self.x_ro, self.pc_ro.wp, self.pc_ro.bp, base, None, None)
+        call("plyolo_conv2d_fwd", C.byref(self.d_cls), self.x_cls, self.pc_cls.wp, self.pc_cls.bp, base + 5 * 4, None, None)
 
     def bwd(self):
         g, hd = self.g, self.head
@@ -975,9 +1093,17 @@ class HeadPredOp:
         else:
             base = hd.draw.data_ptr() + row0 * hd.nch * 4
             dro, dcl = base, base + 5 * 4
-            d_ro, d_cl = self.d_ro, self.d_cls
+            d_ro, d_cl = _copy_desc(self.d_ro), _copy_desc(self.d_cls)
+            d_ro.x_ld, d_cl.x_ld = self.reg_feat.ld, self.cls_feat.ld
+            d_ro.x_coef = d_cl.x_coef = None
             ld_ro = ld_cl = hd.nch
-        self.keep = (d_ro, d_cl)
+        # d_ro / d_cl: data gradients (x_ld = pitch of the features' gradient matrices); w_ro / w_cl: weight gradients
+        # (x = the features as the forward read them: stored, or the producer's z + coefficients)
+        w_ro, w_cl = _copy_desc(d_ro), _copy_desc(d_cl)
+        w_ro.x_ld, w_cl.x_ld = self.d_ro.x_ld, self.d_cls.x_ld
+        g.set_lazy(w_ro, self.reg_feat)
+        g.set_lazy(w_cl, self.cls_feat)
+        self.keep = (d_ro, d_cl, w_ro, w_cl)
         # the data gradients continue the main chain; the parameter gradients (bias sums, weight gradients)
         # only feed the optimizer and go to the weight-gradient lane (their inputs -- the loss gradients and the
         # forward features -- are not written again in this plan)
@@ -990,9 +1116,9 @@ class HeadPredOp:
         def param_grads():
             call("plyolo_bias_grad", g.dtype, dro, M, 5, ld_ro, self.pc_ro.dbp, None)
             call("plyolo_bias_grad", g.dtype, dcl, M, self.nc, ld_cl, self.pc_cls.dbp, None)
-            call("plyolo_conv2d_wgrad", C.byref(d_ro), g.aptr(self.reg_feat), dro, self.pc_ro.dwp, None)
+            call("plyolo_conv2d_wgrad", C.byref(w_ro), self.x_ro, dro, self.pc_ro.dwp, None)
             self.pc_ro.reduce_slabs()
-            call("plyolo_conv2d_wgrad", C.byref(d_cl), g.aptr(self.cls_feat), dcl, self.pc_cls.dwp, None)
+            call("plyolo_conv2d_wgrad", C.byref(w_cl), self.x_cls, dcl, self.pc_cls.dwp, None)
             self.pc_cls.reduce_slabs()
 
         if lanes:

@@ -476,3 +476,47 @@ def test_stale_forward_and_gradient_accumulation_are_refused():
     for n, p in model.named_parameters():   # (the fp32 parity weight gradient sums with atomics: equal up to summation order)
         if p.grad is not None:
             assert float((p.grad - g2[n]).abs().max()) <= 1e-5 * max(float(g2[n].abs().max()), 1e-6), n
+
+
+def _step_with_env(env, dtype, g):
+    """One training step of the golden toy model with environment switches applied while its plans are recorded."""
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        _, model = _golden_model(dtype)
+        model.train()
+        x = torch.from_numpy(g["x"]).to(hu.DEV)
+        labels = torch.from_numpy(g["labels"]).to(hu.DEV)
+        out = model(x, labels)
+        out["loss"].backward()
+        torch.cuda.synchronize()
+        sess = [s for k, s in model.runner().sessions.items() if k[4] == "train"][0]
+        grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        return {k: float(out[k]) for k in ("loss", "loss_iou", "loss_obj", "loss_cls")}, grads, sess.g.n_lazy
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_lazy_activations_match_materialised(dtype):
+    """PLYOLO_LAZY=1: BaseConv outputs that only feed convolutions are never written; the consumers' loaders (pointwise
+    and 3x3 forward, weight gradient) apply BatchNorm + SiLU to the producer's raw output instead.  Same arithmetic on
+    the same bf16 / fp32 values: losses and every gradient equal the materialised plan's -- and in fp32 the golden
+    fixture's (1e-4), so the lazy lowering is pinned to the reference too."""
+    g = load_golden("network_yolox_test")
+    l0, g0, n0 = _step_with_env({"PLYOLO_LAZY": "0"}, dtype, g)
+    l1, g1, n1 = _step_with_env({"PLYOLO_LAZY": "1"}, dtype, g)
+    assert n0 == 0 and n1 >= 20, (n0, n1)
+    for k in l0:
+        assert abs(l0[k] - l1[k]) <= 1e-6 * max(1.0, abs(l0[k])), (k, l0[k], l1[k])
+    gmax = max(float(v.abs().max()) for v in g0.values())
+    for n in g0:
+        tol = 1e-6 if dtype == "bf16" else 2e-5   # fp32: the parity weight gradient sums with atomics
+        assert float((g0[n] - g1[n]).abs().max()) <= tol * max(float(g0[n].abs().max()), 1e-3 * gmax), n
+    if dtype == "fp32":
+        for k in l1:
+            assert abs(l1[k] - float(g["out/" + k])) <= 1e-4 * max(1.0, abs(float(g["out/" + k]))), k
