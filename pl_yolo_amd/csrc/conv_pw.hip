@@ -8,9 +8,10 @@
 // The 3x3 kernel (conv_mfma.hip) serves them as a degenerate one-tap case, but pays for its halo machinery on
 // every launch: per-thread halo descriptors, 32-channel chunks with one barrier AND one exposed memory round trip
 // per chunk (a chunk of a 1x1 layer is only 8 MFMAs per wave), 24 KB of loads in flight per CU.  Here:
-//   * one workgroup = 128 pixel rows x BN output channels; the WHOLE K extent of the rows (up to KC = 256
-//     channels, else chunks of 256) is requested up front -- 32-64 KB in flight per workgroup, one memory round
-//     trip and one barrier per tile instead of one per 32 channels;
+//   * one workgroup = 128 pixel rows x BN output channels, K in chunks of 64 channels (16 KB of rows); the requests
+//     of chunk i+1 -- weights and rows -- are issued before the MFMAs of chunk i, so only the first round trip of a
+//     tile is exposed (whole-K tiles of 128 / 256 channels are instantiated too: equally fast alone, slower in the
+//     step, see pw_tiles);
 //   * A (pixels): 16-byte vectors of full rows -> registers -> [optional BatchNorm + activation of the producing
 //     layer, "lazy input"] -> LDS (row pitch K*2+16 bytes: conflict-free ds_read_b128 fragments);
 //   * B (weights): never touches LDS -- fragment-ordered pack (conv_mfma.hip), one coalesced KiB per fragment
@@ -41,6 +42,7 @@ struct PwP {
   int nkb, nnb;          // packed weight geometry: 16-channel k-blocks, 32-channel n-blocks
   int nmt, nnblk;        // pixel tiles, BN blocks
   int accumulate;
+  int pf;                // 1: requests of chunk i+1 before the MFMAs of chunk i (PLYOLO_PW_PF, A/B switch)
 };
 
 DEVINL u32x4 pw_add_bf16x8(u32x4 a, u32x4 b) {
@@ -98,25 +100,29 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwP p) {
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) arow[mt] = ((wm * MT + mt) * 32 + r) * ROWB + h * 16;
 
-  for (int chunk = 0; chunk < nchunks; ++chunk) {
-    const int c0 = chunk * KC;
-    // ---- weights first (L2-resident, tiny), then the pixel rows: everything this tile needs is in flight at once
-    u32x4 bq[KS];
+  // one chunk = KC channels of the tile's 128 rows.  Requests of chunk i+1 (weights first -- L2-resident, tiny -- then the
+  // pixel rows) are issued BEFORE the MFMAs of chunk i, so a memory round trip is only exposed for the first chunk
+  u32x4 bq[KS], av[NV];
+  auto request = [&](const int chunk) {
+    const int c = chunk * KC + cvt * 8;
+    const bool cok = c < p.K;
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
       const int kb = chunk * KS + kk;
       // a k-block beyond K meets zero-filled LDS columns (finite weights x 0 = 0): clamp instead of masking
       bq[kk] = *(const u32x4*)(wbase + (size_t)(kb < p.nkb ? kb : p.nkb - 1) * 1024u);
     }
-    const int c = c0 + cvt * 8;
-    const bool cok = c < p.K;
-    u32x4 av[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       const int m = m0 + row0 + v * RPP;
       const bool ok = cok && m < p.M;
       av[v] = *(const u32x4*)(p.x + (ok ? (size_t)m * p.x_ld + c : 0));
     }
+  };
+  request(0);
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    const int c = chunk * KC + cvt * 8;
+    const bool cok = c < p.K;
     if (chunk) __syncthreads();   // every wave is done with the previous chunk's rows
     if constexpr (PRE) {
       float sc[8], sh[8];
@@ -146,16 +152,23 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwP p) {
         *(u32x4*)(smem + row * ROWB + cvt * 16) = ok ? av[v] : zero;
       }
     }
+    u32x4 bc[KS];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) bc[kk] = bq[kk];
     __syncthreads();
+    if (p.pf && chunk + 1 < nchunks) request(chunk + 1);
+    __builtin_amdgcn_sched_barrier(0);   // keep the next chunk's requests ABOVE the MFMA block
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
-      const bf16x8 b = *(const bf16x8*)&bq[kk];
+      const bf16x8 b = *(const bf16x8*)&bc[kk];
       bf16x8 a[MT];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) a[mt] = *(const bf16x8*)(smem + arow[mt] + kk * 32);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b, acc[mt], 0, 0, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    if (!p.pf && chunk + 1 < nchunks) request(chunk + 1);
   }
   __syncthreads();  // all LDS operand reads retired; LDS is reused for the epilogue
 
@@ -296,10 +309,16 @@ hipError_t pw_launch(const PwP& p, int BN, int KC, hipStream_t s) {
 void pw_tiles(PwP& p, bool out_f32, int* BN, int* KC) {
   int bn = p.N > 64 ? 128 : (p.N > 32 ? 64 : 32);
   if (out_f32 && bn > 64) bn = 64;
-  int kc = p.K > 128 ? 256 : (p.K > 64 ? 128 : (p.K > 32 ? 64 : 32));
+  // Measured on the whole training step (YOLOX-s B=32, PLYOLO_PW_KC sweep): 64-channel chunks beat 128 / 256 (9.96 vs
+  // 10.29 / 10.33 ms) although the pointwise launches alone are equally fast -- the lighter workgroup (18 KB of LDS,
+  // ~120 VGPRs) leaves more of each CU to the weight-gradient lane that runs beside the data-gradient chain
+  int kc = p.K > 32 ? 64 : 32;
+  if (const char* e = getenv("PLYOLO_PW_KCMAX")) { const int v = atoi(e); if (v == 128 || v == 256) kc = p.K > 128 ? (v == 256 ? 256 : 128) : (p.K > 64 ? 128 : kc); }
   if (const char* e = getenv("PLYOLO_PW_KC")) { const int v = atoi(e); if (v == 32 || v == 64 || v == 128 || v == 256) kc = v < kc ? v : kc; }
   *BN = bn;
   *KC = kc;
+  static const int pf = getenv("PLYOLO_PW_PF") ? atoi(getenv("PLYOLO_PW_PF")) : 0;   // measured: requests ahead of the MFMAs make the pointwise launches 2.5 % faster alone and the step 0.8 % slower
+  p.pf = pf;
   p.nmt = (p.M + PW_BM - 1) / PW_BM;
   p.nnblk = (p.N + bn - 1) / bn;
 }
