@@ -43,6 +43,8 @@ extern "C" {
 #define PLYOLO_ACT_SILU 1
 #define PLYOLO_ACT_RELU 2
 #define PLYOLO_ACT_LRELU 3 /* slope 0.1, models/layers/activation.py:13 */
+#define PLYOLO_ACT_HSWISH 4 /* x * relu6(x + 3) / 6, models/layers/activation.py:22-26 */
+#define PLYOLO_ACT_GELU 5 /* nn.GELU(): 0.5 x (1 + erf(x / sqrt 2)), models/layers/activation.py:16-17 */
 
 /* ---------------------------------------------------------------- probes */
 int plyolo_version(void);            /* ABI version */
@@ -202,6 +204,29 @@ int plyolo_bn_finalize(const plyolo_bn_stats* st, int C, float* coef, void* stre
 /* eval mode: coef from running statistics */
 int plyolo_bn_eval_coef(int C, const float* gamma, const float* beta, const float* running_mean,
                         const float* running_var, float eps, float* coef, void* stream);
+/* ------------------------------------------------------------ deploy-time folding (inference export)
+ * Replaces RepConv._fuse_bn_tensor / get_equivalent_kernel_bias / fuse_conv_bn / fuse_repvgg_block
+ * (models/necks/yolov7_neck.py:213-348) and prepares BaseConv.fuseforward (network_blocks.py:39-40): fp32 weights in
+ * the torch layout [Cout][Cin][k][k], fp32 results, one launch each. */
+typedef struct plyolo_bn_params {
+  const float* gamma;         /* [C] or NULL (1) */
+  const float* beta;          /* [C] or NULL (0) */
+  const float* running_mean;  /* [C] */
+  const float* running_var;   /* [C] */
+  float eps;
+} plyolo_bn_params;
+/* w_out[co][k] = w[co][k] * gamma[co] / sqrt(var[co] + eps);  b_out[co] = beta[co] - mean[co] * gamma[co] / sqrt(var[co] + eps)
+ * (+ conv_bias[co] * gamma / std when the convolution has a bias).  K = Cin * ksize * ksize. */
+int plyolo_fold_conv_bn(const float* w, const float* conv_bias, const plyolo_bn_params* bn, int Cout, int K, float* w_out,
+                        float* b_out, void* stream);
+/* One 3x3 kernel + bias equivalent to  bn3(conv3x3(x)) + bn1(conv1x1(x)) [+ bn_id(x)]  in inference mode:
+ * w3 [Cout][Cin][3][3], w1 [Cout][Cin]; bn_id NULL when the block has no identity branch (needs Cout == Cin otherwise). */
+int plyolo_repconv_fuse(const float* w3, const plyolo_bn_params* bn3, const float* w1, const plyolo_bn_params* bn1,
+                        const plyolo_bn_params* bn_id, int Cout, int Cin, float* w_out, float* b_out, void* stream);
+/* coef = (1 | bias | 0 | 1) [4][C]: the fused-epilogue coefficients of a BatchNorm-free conv unit with bias
+ * (plyolo_conv2d_fwd_bn_act with scale 1, shift = bias) -- the deploy form of BaseConv / RepConv. */
+int plyolo_bias_coef(int C, const float* bias, float* coef, void* stream);
+
 /* same, for one module of a merged convolution: coef rows are C_total wide, this module's C channels
  * start at column c_off */
 int plyolo_bn_eval_coef_at(int C, const float* gamma, const float* beta, const float* running_mean,

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libplyolo_hip.so")
 
 BF16, F32 = 0, 1
-ACT = {None: 0, "silu": 1, "relu": 2, "lrelu": 3}
+ACT = {None: 0, "silu": 1, "relu": 2, "lrelu": 3, "hswish": 4, "gelu": 5}
 
 
 class PlyoloError(RuntimeError):
@@ -33,6 +33,10 @@ class BnStats(C.Structure):
                 ("num_batches_tracked", C.c_void_p),
                 ("split", C.c_int), ("gamma2", C.c_void_p), ("beta2", C.c_void_p), ("running_mean2", C.c_void_p),
                 ("running_var2", C.c_void_p), ("num_batches_tracked2", C.c_void_p)]
+
+
+class BnParams(C.Structure):
+    _fields_ = [("gamma", C.c_void_p), ("beta", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("eps", C.c_float)]
 
 
 class Split(C.Structure):          # plyolo_split
@@ -130,6 +134,9 @@ SIGNATURES = {
     "plyolo_unpack_wgrads": (_i, [_vp, _i, _i, _i, _vp]),
     "plyolo_bn_finalize": (_i, [_P(BnStats), _i, _vp, _vp]),
     "plyolo_bn_eval_coef": (_i, [_i, _vp, _vp, _vp, _vp, _f, _vp, _vp]),
+    "plyolo_bias_coef": (_i, [_i, _vp, _vp, _vp]),
+    "plyolo_fold_conv_bn": (_i, [_vp, _vp, _P(BnParams), _i, _i, _vp, _vp, _vp]),
+    "plyolo_repconv_fuse": (_i, [_vp, _P(BnParams), _vp, _P(BnParams), _P(BnParams), _i, _i, _vp, _vp, _vp]),
     "plyolo_bn_eval_coef_at": (_i, [_i, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _vp]),
     "plyolo_bn_act_fwd": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _P(BnStats), _P(Split), _vp]),
     "plyolo_channel_stats": (_i, [_i, _i, _i, _vp, _i, _vp, _vp]),

@@ -63,6 +63,21 @@ class OneStageD(nn.Module):
             self.__dict__['_runner'] = r
         return r
 
+    def fuse(self):
+        """Inference export: fold every BaseConv's BatchNorm into its convolution and collapse every RepConv into its single
+        3x3 convolution (the reference provides the per-module pieces -- BaseConv.fuseforward, network_blocks.py:39-40;
+        RepConv.fuse_repvgg_block, yolov7_neck.py:288-348 -- this walks the tree).  The fused model is eval-only; its traced
+        plans are rebuilt on the next call."""
+        from .layers import BaseConv
+        from .necks import RepConv
+        for m in self.modules():
+            if isinstance(m, RepConv):
+                m.fuse_repvgg_block()
+            elif isinstance(m, BaseConv):
+                m.fuse()
+        self.__dict__['_runner'] = None
+        return self.eval()
+
     def forward(self, x, labels=None):
         r = self.runner()
         if labels is None:                     # list of raw NCHW head maps (build_detection.py:51-52)

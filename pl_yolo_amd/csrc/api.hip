@@ -85,7 +85,7 @@ static int check_conv(const plyolo_conv_desc* d, const char* who, bool fwd) {
     PLY_CHECK_ARG((double)d->N * d->H * d->W < 2147483000.0, "%s: more than 2^31 pixels", who);
   }
   if (d->x_coef != nullptr) {
-    PLY_CHECK_ARG(d->x_coef_ld >= d->Cin && d->x_act >= 0 && d->x_act <= PLYOLO_ACT_LRELU, "%s: lazy input needs x_coef_ld >= Cin and a valid x_act", who);
+    PLY_CHECK_ARG(d->x_coef_ld >= d->Cin && d->x_act >= 0 && d->x_act <= PLYOLO_ACT_GELU, "%s: lazy input needs x_coef_ld >= Cin and a valid x_act", who);
     PLY_CHECK_ARG(d->dtype != PLYOLO_BF16 || is_pointwise(d) || lazy_3x3_ok(d), "%s: lazy input is not available for this bf16 convolution shape", who);
   }
   return 0;

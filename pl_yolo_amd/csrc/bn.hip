@@ -341,6 +341,61 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(int M, int C, const T* __r
   }
 }
 
+// ---- deploy-time folding (inference export): BatchNorm folded into the convolution it follows, and the three
+// branches of a RepConv collapsed into one 3x3 convolution with bias (reference models/necks/yolov7_neck.py:213-348:
+// _fuse_bn_tensor / get_equivalent_kernel_bias / fuse_conv_bn / fuse_repvgg_block; network_blocks.py:39-40 fuseforward).
+// fp32 master weights in, fp32 out; one thread per output weight, same operation order as the reference
+// (std = sqrt(var + eps); t = gamma / std; w * t; beta - mean * gamma / std).
+struct FoldBn {
+  const float *gamma, *beta, *mean, *var;
+  float eps;
+};
+DEVINL void fold_coef(const FoldBn& bn, int co, float* t, float* bias) {
+  const float sd = sqrtf(bn.var[co] + bn.eps);
+  const float g = bn.gamma ? bn.gamma[co] : 1.f, be = bn.beta ? bn.beta[co] : 0.f;
+  *t = g / sd;
+  *bias = be - bn.mean[co] * g / sd;
+}
+// conv [Cout][K] (K = Cin*k*k) + optional conv bias -> folded weights / bias
+__global__ void fold_conv_bn_kernel(const float* w, const float* cb, FoldBn bn, int Cout, int K, float* wo, float* bo) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)Cout * K) return;
+  const int co = (int)(idx / K);
+  float t, bias;
+  fold_coef(bn, co, &t, &bias);
+  wo[idx] = w[idx] * t;
+  if (idx % K == 0) bo[co] = cb ? bias + cb[co] * t : bias;   // fuse_conv_bn is only defined for bias-free convs; a bias scales with t
+}
+// RepConv: 3x3 branch + 1x1 branch padded to the centre tap + identity BatchNorm (an identity 1x1 kernel), each folded with
+// its own BatchNorm, summed.  w3 [Cout][Cin][3][3], w1 [Cout][Cin]; has_id needs Cout == Cin.
+__global__ void repconv_fuse_kernel(const float* w3, FoldBn bn3, const float* w1, FoldBn bn1, FoldBn bnid, int has_id, int Cout, int Cin,
+                                    float* wo, float* bo) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)Cout * Cin * 9) return;
+  const int tap = (int)(idx % 9), ci = (int)((idx / 9) % Cin), co = (int)(idx / (9 * (size_t)Cin));
+  float t3, b3, t1, b1, ti = 0.f, bi = 0.f;
+  fold_coef(bn3, co, &t3, &b3);
+  fold_coef(bn1, co, &t1, &b1);
+  if (has_id) fold_coef(bnid, co, &ti, &bi);
+  float v = w3[idx] * t3;
+  if (tap == 4) {
+    float c = w1[(size_t)co * Cin + ci] * t1;
+    if (has_id) c = c + (ci == co ? 1.f : 0.f) * ti;     // kernel3x3 + pad(kernel1x1) + kernelid, in that order (:217)
+    v = v + c;
+  }
+  wo[idx] = v;
+  if (tap == 0 && ci == 0) bo[co] = has_id ? (b3 + b1) + bi : b3 + b1;
+}
+// coef (scale | shift) of a BatchNorm-free conv unit with bias: scale 1, shift = bias (fused inference epilogue)
+__global__ void bias_coef_kernel(int C, const float* bias, float* coef) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  coef[c] = 1.f;
+  coef[C + c] = bias ? bias[c] : 0.f;
+  coef[2 * C + c] = 0.f;
+  coef[3 * C + c] = 1.f;
+}
+
 // 256 CUs x 4 workgroups; every workgroup re-reads the stat slots, so keep the grid bounded
 inline int stream_grid(int M, int cvn) {
   const int cols = cvn < 256 ? cvn : 256, rpb = 256 / cols;
@@ -377,6 +432,45 @@ int plyolo_bn_eval_coef(int C, const float* gamma, const float* beta, const floa
                         float eps, float* coef, void* stream) {
   return submit(stream, [=](hipStream_t s) -> hipError_t {
     hipLaunchKernelGGL(bn_eval_coef_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, C, gamma, beta, running_mean, running_var, eps, coef, C, 0);
+    return hipGetLastError();
+  });
+}
+
+int plyolo_bias_coef(int C, const float* bias, float* coef, void* stream) {
+  PLY_CHECK_ARG(C > 0 && coef, "bias_coef: bad arguments");
+  return submit(stream, [=](hipStream_t s) -> hipError_t {
+    hipLaunchKernelGGL(bias_coef_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, C, bias, coef);
+    return hipGetLastError();
+  });
+}
+
+static FoldBn fold_of(const plyolo_bn_params* b) {
+  FoldBn f{};
+  if (b) { f.gamma = b->gamma; f.beta = b->beta; f.mean = b->running_mean; f.var = b->running_var; f.eps = b->eps; }
+  return f;
+}
+
+int plyolo_fold_conv_bn(const float* w, const float* conv_bias, const plyolo_bn_params* bn, int Cout, int K, float* w_out, float* b_out,
+                        void* stream) {
+  PLY_CHECK_ARG(w && bn && bn->running_mean && bn->running_var && w_out && b_out && Cout > 0 && K > 0, "fold_conv_bn: incomplete arguments");
+  const FoldBn f = fold_of(bn);
+  const size_t total = (size_t)Cout * K;
+  return submit(stream, [=](hipStream_t s) -> hipError_t {
+    hipLaunchKernelGGL(fold_conv_bn_kernel, dim3((unsigned)cdivz(total, 256)), dim3(256), 0, s, w, conv_bias, f, Cout, K, w_out, b_out);
+    return hipGetLastError();
+  });
+}
+
+int plyolo_repconv_fuse(const float* w3, const plyolo_bn_params* bn3, const float* w1, const plyolo_bn_params* bn1,
+                        const plyolo_bn_params* bn_id, int Cout, int Cin, float* w_out, float* b_out, void* stream) {
+  PLY_CHECK_ARG(w3 && w1 && bn3 && bn1 && bn3->running_var && bn1->running_var && w_out && b_out && Cout > 0 && Cin > 0,
+                "repconv_fuse: incomplete arguments");
+  PLY_CHECK_ARG(!bn_id || (Cout == Cin && bn_id->running_var), "repconv_fuse: the identity branch needs Cout == Cin");
+  const FoldBn f3 = fold_of(bn3), f1 = fold_of(bn1), fi = fold_of(bn_id);
+  const int has_id = bn_id != nullptr;
+  const size_t total = (size_t)Cout * Cin * 9;
+  return submit(stream, [=](hipStream_t s) -> hipError_t {
+    hipLaunchKernelGGL(repconv_fuse_kernel, dim3((unsigned)cdivz(total, 256)), dim3(256), 0, s, w3, f3, w1, f1, fi, has_id, Cout, Cin, w_out, b_out);
     return hipGetLastError();
   });
 }

@@ -42,6 +42,8 @@ DEVINL float act_fwd(float u, int act) {
     case PLYOLO_ACT_SILU: return u * __builtin_amdgcn_rcpf(1.0f + __expf(-u));  // hardware exp2 / rcp (1 ulp): bf16 storage path
     case PLYOLO_ACT_RELU: return u > 0.f ? u : 0.f;
     case PLYOLO_ACT_LRELU: return u > 0.f ? u : 0.1f * u;
+    case PLYOLO_ACT_HSWISH: return u * fminf(fmaxf(u + 3.0f, 0.f), 6.0f) * (1.0f / 6.0f);
+    case PLYOLO_ACT_GELU: return 0.5f * u * (1.0f + erff(u * 0.70710678118654752f));
     default: return u;
   }
 }
@@ -50,6 +52,8 @@ DEVINL float act_fwd_precise(float u, int act) {
     case PLYOLO_ACT_SILU: return u / (1.0f + expf(-u));
     case PLYOLO_ACT_RELU: return u > 0.f ? u : 0.f;
     case PLYOLO_ACT_LRELU: return u > 0.f ? u : 0.1f * u;
+    case PLYOLO_ACT_HSWISH: return u * fminf(fmaxf(u + 3.0f, 0.f), 6.0f) / 6.0f;   // x * relu6(x + 3) / 6, activation.py:24
+    case PLYOLO_ACT_GELU: return 0.5f * u * (1.0f + erff(u * 0.70710678118654752f));
     default: return u;
   }
 }
@@ -64,6 +68,10 @@ DEVINL float act_grad(float u, int act) {
     }
     case PLYOLO_ACT_RELU: return u > 0.f ? 1.f : 0.f;
     case PLYOLO_ACT_LRELU: return u > 0.f ? 1.f : 0.1f;
+    // d/du [u * relu6(u+3) / 6] = (relu6(u+3) + u * [0 < u+3 < 6]) / 6   (autograd's subgradient 0 at both kinks)
+    case PLYOLO_ACT_HSWISH: return (fminf(fmaxf(u + 3.0f, 0.f), 6.0f) + ((u > -3.0f && u < 3.0f) ? u : 0.f)) * (1.0f / 6.0f);
+    // d/du [u * Phi(u)] = Phi(u) + u * phi(u)
+    case PLYOLO_ACT_GELU: return 0.5f * (1.0f + erff(u * 0.70710678118654752f)) + u * 0.3989422804014327f * (PRECISE ? expf(-0.5f * u * u) : __expf(-0.5f * u * u));
     default: return 1.f;
   }
 }

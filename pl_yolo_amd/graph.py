@@ -522,8 +522,9 @@ class ConvUnitOp:
     """BaseConv: conv (no bias) -> BatchNorm (batch stats in training) -> activation
     [+ residual].  reference models/layers/network_blocks.py:7-40, :86-90."""
 
-    def __init__(self, g, x, conv_w, bn, act, stride, residual=None, need_dgrad=True, cin_pad=None):
+    def __init__(self, g, x, conv_w, bn, act, stride, residual=None, need_dgrad=True, cin_pad=None, conv_b=None):
         self.g, self.x, self.bn, self.act, self.stride, self.res = g, x, bn, ACT[act], stride, residual
+        self.conv_b = conv_b   # deploy form (BatchNorm folded into the convolution: BaseConv.fuse / RepConv.fuse_repvgg_block)
         Cout, Cin, k, _ = conv_w.shape
         self.k = k
         self.Cin_p = cin_pad or Cin
@@ -531,7 +532,7 @@ class ConvUnitOp:
         pad = (k - 1) // 2
         self.OH = (x.H + 2 * pad - k) // stride + 1
         self.OW = (x.W + 2 * pad - k) // stride + 1
-        self.pc = PackedConv(g, [(conv_w, None, 0)], k, self.Cin_p, need_dgrad)
+        self.pc = PackedConv(g, [(conv_w, conv_b, 0)], k, self.Cin_p, need_dgrad)
         self.need_dgrad = need_dgrad
         self.out = g.new_act(x.N, self.OH, self.OW, Cout, "a")
         self.out.producer = self
@@ -570,11 +571,15 @@ class ConvUnitOp:
         self._alloc_small()
         zt = self.z.tensor
         train_stats = g.training and bn is not None
-        if (not g.training) and bn is not None and g.dtype == BF16 and g.fuse_eval:
+        if (not g.training) and (bn is not None or self.conv_b is not None) and g.dtype == BF16 and g.fuse_eval:
             # inference: BatchNorm is a fixed affine -> applied with the activation in the conv epilogue; the
-            # activated tensor is written straight into its (possibly concat-slice) destination
-            call("plyolo_bn_eval_coef", self.Cout, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var),
-                 float(bn.eps), self.coef.data_ptr(), None)
+            # activated tensor is written straight into its (possibly concat-slice) destination.  The deploy form
+            # (BatchNorm already folded into weights + bias) is the same epilogue with scale 1, shift = bias
+            if bn is not None:
+                call("plyolo_bn_eval_coef", self.Cout, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var),
+                     float(bn.eps), self.coef.data_ptr(), None)
+            else:
+                call("plyolo_bias_coef", self.Cout, self.pc.bp, self.coef.data_ptr(), None)
             if not hasattr(self, "desc_eval"):
                 self.desc_eval = conv_desc(g, self.desc.N, self.desc.H, self.desc.W, self.Cin_p, self.Cout, self.k, self.stride,
                                            self.x.ld, self.out.ld)
@@ -582,7 +587,8 @@ class ConvUnitOp:
                  g.aptr(self.res) if self.res is not None else None, self.res.ld if self.res is not None else 0, g.aptr(self.out), None)
             return
         slots = g.stat_arena.data_ptr() + self.slot_off * 8 if train_stats else None
-        call("plyolo_conv2d_fwd", C.byref(self.desc), self.xptr, self.pc.wp, None, zt.data_ptr(), slots, None)
+        call("plyolo_conv2d_fwd", C.byref(self.desc), self.xptr, self.pc.wp, self.pc.bp if self.conv_b is not None else None,
+             zt.data_ptr(), slots, None)
         coef, st = None, None
         if bn is not None:
             coef = self.coef.data_ptr()

@@ -11,21 +11,18 @@ import torch.nn as nn
 from . import graph as G
 from ._lib import PlyoloError
 
-_ACTS = ("silu", "relu", "lrelu")
+_ACTS = ("silu", "relu", "lrelu", "hswish", "gelu")
 
 
 def get_activation(name="silu", inplace=True):
-    """activation.py:5-20.  Returns a marker module (the activation is fused into the
-    BatchNorm-apply kernel).  hswish/gelu exist in the reference but are not used by
-    the YOLOX/YOLOv7 configs; they are rejected here rather than silently changed."""
+    """activation.py:5-26.  Returns a marker module (the activation is fused into the
+    BatchNorm-apply / conv-epilogue kernels: csrc/common.h act_fwd / act_grad)."""
     if name is None:
         return None
     if name in _ACTS:
         m = nn.Identity()
         m.act_name = name
         return m
-    if name in ("hswish", "gelu"):
-        raise NotImplementedError("activation '%s' has no HIP epilogue yet" % name)
     raise AttributeError("Unsupported activation function type: {}".format(name))
 
 
@@ -66,8 +63,52 @@ class BaseConv(HipModule):
 
     def emit(self, g, x, residual=None, need_dgrad=True, cin_pad=None):
         act = self.act.act_name if self.act is not None else None
-        op = G.ConvUnitOp(g, x, self.conv.weight, self.norm, act, self.stride, residual, need_dgrad, cin_pad)
+        op = G.ConvUnitOp(g, x, self.conv.weight, self.norm, act, self.stride, residual, need_dgrad, cin_pad, conv_b=self.conv.bias)
         return op.out
+
+    def fuse(self):
+        """Deploy form: fold the BatchNorm into the convolution (weights scaled per output channel, a bias appears) and drop
+        it, so that forward == the reference's `fuseforward` = act(conv(x)) (network_blocks.py:39-40; the folding rule is
+        RepConv.fuse_conv_bn, yolov7_neck.py:265-286).  One HIP launch (plyolo_fold_conv_bn); inference only."""
+        if self.norm is None:
+            return self
+        if not isinstance(self.norm, nn.BatchNorm2d):
+            raise NotImplementedError("only BatchNorm2d folds into a convolution")
+        self.conv = fold_conv_bn(self.conv, self.norm)
+        self.norm = None
+        return self
+
+    fuseforward = HipModule.forward   # same contract as forward: the module only describes its launch-plan ops
+
+
+def _bn_params(bn):
+    from ._lib import BnParams, ptr
+    b = BnParams()
+    b.gamma, b.beta = ptr(bn.weight), ptr(bn.bias)
+    b.running_mean, b.running_var, b.eps = ptr(bn.running_mean), ptr(bn.running_var), float(bn.eps)
+    return b
+
+
+def fold_conv_bn(conv, bn):
+    """nn.Conv2d (+ optional bias) followed by an inference-mode BatchNorm2d -> one nn.Conv2d with bias
+    (RepConv.fuse_conv_bn, yolov7_neck.py:265-286), computed on the device by plyolo_fold_conv_bn."""
+    import ctypes as C
+    from ._lib import call, ptr
+    w = conv.weight.detach()
+    if not w.is_cuda:
+        raise PlyoloError("BatchNorm folding runs on the MI355X (move the model to the device first); there is no CPU path")
+    w = w.float().contiguous()
+    Cout, K = w.shape[0], w[0].numel()
+    w_out = torch.empty_like(w)
+    b_out = torch.empty(Cout, dtype=torch.float32, device=w.device)
+    bp = _bn_params(bn)
+    call("plyolo_fold_conv_bn", w.data_ptr(), ptr(conv.bias), C.byref(bp), Cout, K, w_out.data_ptr(), b_out.data_ptr(),
+         torch.cuda.current_stream().cuda_stream)
+    fused = nn.Conv2d(conv.in_channels, conv.out_channels, conv.kernel_size, conv.stride, conv.padding, conv.dilation, conv.groups,
+                      bias=True, padding_mode=conv.padding_mode, device=w.device)
+    fused.weight = nn.Parameter(w_out)
+    fused.bias = nn.Parameter(b_out)
+    return fused
 
 
 def emit_pair(g, x, unit_a, unit_b):

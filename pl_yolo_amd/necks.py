@@ -1,7 +1,9 @@
 """CSP-PAFPN neck (reference models/necks/pafpn_csp.py:7-86)."""
+import torch
 import torch.nn as nn
 
 from . import graph as G
+from ._lib import PlyoloError
 from .layers import emit_pair, BaseConv, CSPLayer, HipModule
 
 
@@ -93,21 +95,68 @@ class RepConv(HipModule):
         super().__init__()
         if k != 3 or (p is not None and p != 1):
             raise AssertionError("RepConv: k == 3 and padding 1 (yolov7_neck.py:180-181)")
-        if deploy or g != 1 or s != 1 or act is not True:
-            raise NotImplementedError("RepConv: only the train-time form with stride 1, groups 1 and SiLU has HIP kernels")
+        if g != 1 or s != 1 or act is not True:
+            raise NotImplementedError("RepConv: stride 1, groups 1 and SiLU only (what the HIP conv kernels cover)")
         self.in_channels, self.out_channels, self.groups, self.deploy = c1, c2, g, deploy
         self.act = nn.SiLU()
-        self.rbr_identity = nn.BatchNorm2d(num_features=c1) if c2 == c1 and s == 1 else None
-        self.rbr_dense = nn.Sequential(nn.Conv2d(c1, c2, 3, s, 1, groups=g, bias=False), nn.BatchNorm2d(num_features=c2))
-        self.rbr_1x1 = nn.Sequential(nn.Conv2d(c1, c2, 1, s, 0, groups=g, bias=False), nn.BatchNorm2d(num_features=c2))
+        if deploy:      # yolov7_neck.py:187-188
+            self.rbr_reparam = nn.Conv2d(c1, c2, 3, s, 1, groups=g, bias=True)
+        else:
+            self.rbr_identity = nn.BatchNorm2d(num_features=c1) if c2 == c1 and s == 1 else None
+            self.rbr_dense = nn.Sequential(nn.Conv2d(c1, c2, 3, s, 1, groups=g, bias=False), nn.BatchNorm2d(num_features=c2))
+            self.rbr_1x1 = nn.Sequential(nn.Conv2d(c1, c2, 1, s, 0, groups=g, bias=False), nn.BatchNorm2d(num_features=c2))
 
     def emit(self, g, x):
+        if hasattr(self, "rbr_reparam"):   # deploy form: act(conv3x3(x) + bias), yolov7_neck.py:203-204
+            return G.ConvUnitOp(g, x, self.rbr_reparam.weight, None, "silu", 1, conv_b=self.rbr_reparam.bias).out
         # three BatchNorm branches accumulated through the residual input of the BN-apply kernel, then SiLU
         t = G.ConvUnitOp(g, x, self.rbr_dense[0].weight, self.rbr_dense[1], None, 1).out
         t = G.ConvUnitOp(g, x, self.rbr_1x1[0].weight, self.rbr_1x1[1], None, 1, residual=t).out
         if self.rbr_identity is not None:
             t = G.BnOnlyOp(g, x, self.rbr_identity, residual=t).out
         return G.ActOp(g, t, "silu").out
+
+    # ---- deploy-time re-parameterisation (yolov7_neck.py:213-348), one HIP launch (plyolo_repconv_fuse)
+    def get_equivalent_kernel_bias(self):
+        """(kernel [c2, c1, 3, 3], bias [c2]) of the single 3x3 convolution equivalent to the three inference-mode branches:
+        kernel3x3 + pad(kernel1x1) + kernel_id, bias3x3 + bias1x1 + bias_id (yolov7_neck.py:213-220)."""
+        import ctypes as C
+        from ._lib import call
+        from .layers import _bn_params
+        w3, w1 = self.rbr_dense[0].weight.detach(), self.rbr_1x1[0].weight.detach()
+        if not w3.is_cuda:
+            raise PlyoloError("RepConv re-parameterisation runs on the MI355X (move the model to the device first); there is no CPU path")
+        w3, w1 = w3.float().contiguous(), w1.float().contiguous()
+        c2, c1 = w3.shape[0], w3.shape[1]
+        kernel = torch.empty(c2, c1, 3, 3, dtype=torch.float32, device=w3.device)
+        bias = torch.empty(c2, dtype=torch.float32, device=w3.device)
+        b3, b1 = _bn_params(self.rbr_dense[1]), _bn_params(self.rbr_1x1[1])
+        bid = _bn_params(self.rbr_identity) if self.rbr_identity is not None else None
+        call("plyolo_repconv_fuse", w3.data_ptr(), C.byref(b3), w1.data_ptr(), C.byref(b1), C.byref(bid) if bid is not None else None,
+             c2, c1, kernel.data_ptr(), bias.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        return kernel, bias
+
+    def repvgg_convert(self):
+        kernel, bias = self.get_equivalent_kernel_bias()
+        return kernel.detach().cpu().numpy(), bias.detach().cpu().numpy()
+
+    def fuse_conv_bn(self, conv, bn):
+        from .layers import fold_conv_bn
+        return fold_conv_bn(conv, bn)
+
+    def fuse_repvgg_block(self):
+        """Switch to the deploy form in place (yolov7_neck.py:288-348): rbr_reparam = one 3x3 conv with bias, branches deleted."""
+        if self.deploy:
+            return
+        kernel, bias = self.get_equivalent_kernel_bias()
+        conv = nn.Conv2d(self.in_channels, self.out_channels, 3, 1, 1, groups=self.groups, bias=True, device=kernel.device)
+        conv.weight = nn.Parameter(kernel)
+        conv.bias = nn.Parameter(bias)
+        self.rbr_reparam = conv
+        self.deploy = True
+        self.rbr_identity = None
+        self.rbr_1x1 = None
+        self.rbr_dense = None
 
 
 class YOLOv7NECK(HipModule):

@@ -465,6 +465,60 @@ def gen_repconv():
     save("repconv_blocks", d)
 
 
+def gen_deploy():
+    """Deploy-time folding: the reference's RepConv re-parameterisation (get_equivalent_kernel_bias,
+    fuse_repvgg_block) and BaseConv BN folding (RepConv.fuse_conv_bn + BaseConv.fuseforward) on seeded modules in eval mode
+    with non-trivial running statistics: inputs, unfused eval outputs, fused kernels / biases, fused outputs."""
+    from models.necks.yolov7_neck import RepConv
+    d = {}
+    gen = torch.Generator().manual_seed(321)
+
+    def perturb_bn(bn):
+        bn.weight.data = 0.5 + torch.rand(bn.weight.shape, generator=gen)
+        bn.bias.data = torch.rand(bn.bias.shape, generator=gen) - 0.5
+        bn.running_mean.data = torch.randn(bn.running_mean.shape, generator=gen) * 0.3
+        bn.running_var.data = 0.3 + torch.rand(bn.running_var.shape, generator=gen)
+
+    for tag, c1, c2 in (("ne", 16, 32), ("id", 24, 24)):
+        torch.manual_seed(7)
+        m = RepConv(c1, c2, 3, 1)
+        for bn in [m.rbr_dense[1], m.rbr_1x1[1]] + ([m.rbr_identity] if m.rbr_identity is not None else []):
+            perturb_bn(bn)
+        m.eval()
+        x = torch.randn(2, c1, 12, 10, generator=gen)
+        for k, v in m.state_dict().items():
+            d["rep_%s/state/%s" % (tag, k)] = v.clone()
+        with torch.no_grad():
+            d["rep_%s/x" % tag] = x
+            d["rep_%s/y_eval" % tag] = m(x).clone()
+            k, b = m.get_equivalent_kernel_bias()
+            d["rep_%s/kernel" % tag], d["rep_%s/bias" % tag] = k.clone(), b.clone()
+            m.fuse_repvgg_block()
+            d["rep_%s/reparam_weight" % tag] = m.rbr_reparam.weight.detach().clone()
+            d["rep_%s/reparam_bias" % tag] = m.rbr_reparam.bias.detach().clone()
+            d["rep_%s/y_fused" % tag] = m(x).clone()
+    helper = RepConv(8, 8, 3, 1)
+    for tag, cin, cout, k, s in (("k3", 8, 16, 3, 1), ("k1", 16, 24, 1, 1), ("k3s2", 8, 16, 3, 2)):
+        torch.manual_seed(11)
+        m = BaseConv(cin, cout, k, s)
+        perturb_bn(m.norm)
+        m.eval()
+        x = torch.randn(2, cin, 12, 10, generator=gen)
+        for kk, v in m.state_dict().items():
+            d["base_%s/state/%s" % (tag, kk)] = v.clone()
+        with torch.no_grad():
+            d["base_%s/x" % tag] = x
+            d["base_%s/y_eval" % tag] = m(x).clone()
+            m.conv = helper.fuse_conv_bn(m.conv, m.norm)
+            d["base_%s/fused_weight" % tag] = m.conv.weight.detach().clone()
+            d["base_%s/fused_bias" % tag] = m.conv.bias.detach().clone()
+            d["base_%s/y_fused" % tag] = m.fuseforward(x).clone()
+        d["base_%s/ksize" % tag], d["base_%s/stride" % tag] = k, s
+    for tag in ("ne", "id"):
+        print("repconv", tag, "fused vs unfused max diff %.3g" % float((d["rep_%s/y_eval" % tag] - d["rep_%s/y_fused" % tag]).abs().max()))
+    save("deploy_fold", d)
+
+
 def gen_network_warm():
     """"Warm weights": the toy YOLOX after 50 SGD steps of the REFERENCE on a small fixed data set, then one
     recorded training step at that state (losses, every gradient, head maps).  A trained-for-a-while BatchNorm net
@@ -549,6 +603,9 @@ def gen_cfg1():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "deploy":
+        gen_deploy()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "warm":
         gen_network_warm()
         sys.exit(0)
@@ -568,5 +625,6 @@ if __name__ == "__main__":
     gen_blocks()
     gen_network()
     gen_network_warm()
+    gen_deploy()
     gen_cfg1()
     gen_schedule()
