@@ -70,6 +70,14 @@ int plyolo_plan_lane(plyolo_plan* p, int lane);
 int plyolo_plan_record(plyolo_plan* p, int lane);          /* returns the event id (>= 0) or < 0 */
 int plyolo_plan_wait(plyolo_plan* p, int lane, int ev);
 int plyolo_plan_lanes(const plyolo_plan* p);                /* number of lanes the plan uses (>= 1) */
+/* Host hooks: plyolo_plan_hook(p, lane, id) marks a point of `lane`; when an EAGER replay (plyolo_plan_run) reaches it,
+ * fn(id, stream of that lane, user) runs on the host thread.  Whatever the callback enqueues on that stream is ordered
+ * after the lane's earlier launches and before the plan's join -- the data-parallel runner issues each gradient
+ * bucket's RCCL all-reduce this way, while the rest of the backward plan is still executing.  hipGraph
+ * replays and plyolo_plan_profile skip hooks.  fn returns 0, anything else aborts the replay. */
+int plyolo_plan_hook(plyolo_plan* p, int lane, int id);
+int plyolo_plan_set_hook(plyolo_plan* p, int (*fn)(int id, void* stream, void* user), void* user);
+int plyolo_plan_hooks(const plyolo_plan* p);                /* number of recorded hooks */
 int plyolo_plan_size(const plyolo_plan*);      /* number of recorded launches */
 int plyolo_plan_run(plyolo_plan*, void* stream); /* replay eagerly */
 int plyolo_plan_graph_instantiate(plyolo_plan*, void* stream); /* capture into a hipGraphExec */
@@ -82,6 +90,14 @@ int plyolo_plan_op_info(const plyolo_plan*, int i, char* label, int label_cap, d
 /* Measurement aid for multi-lane plans: one eager multi-stream replay; ms_out[l] = time from the start of the
  * replay to the end of lane l's last launch (l < lanes), ms_out[lanes] = to the join.  Synchronises the stream. */
 int plyolo_plan_lane_times(plyolo_plan*, void* stream, float* ms_out, int n);
+
+/* ------------------------------------------------------------ RCCL gradient exchange
+ * Data-parallel training exchanges exactly one thing: the mean of the flat fp32 gradient buffer, bucket by bucket
+ * (the reference leaves this to torch DDP: PL_Modules/pl_detection.py + Lightning's ddp strategy).  `comm` is the host's
+ * ncclComm_t; ncclAllReduce is resolved at run time from the RCCL already in the process, or from the library named with
+ * plyolo_rccl_set_library (NULL = "librccl.so").  In place, enqueue-only, on the caller's stream. */
+int plyolo_rccl_set_library(const char* path);
+int plyolo_rccl_allreduce_bucket(void* comm, float* grads, size_t count, int average, void* stream);
 
 /* ------------------------------------------------------------ convolution
  * Replaces nn.Conv2d inside BaseConv (models/layers/network_blocks.py:18-26)

@@ -116,6 +116,11 @@ SIGNATURES = {
     "plyolo_plan_lane": (_i, [_vp, _i]),
     "plyolo_plan_record": (_i, [_vp, _i]),
     "plyolo_plan_wait": (_i, [_vp, _i, _i]),
+    "plyolo_plan_hook": (_i, [_vp, _i, _i]),
+    "plyolo_plan_set_hook": (_i, [_vp, _vp, _vp]),
+    "plyolo_plan_hooks": (_i, [_vp]),
+    "plyolo_rccl_set_library": (_i, [C.c_char_p]),
+    "plyolo_rccl_allreduce_bucket": (_i, [_vp, _vp, _sz, _i, _vp]),
     "plyolo_plan_run": (_i, [_vp, _vp]),
     "plyolo_plan_graph_instantiate": (_i, [_vp, _vp]),
     "plyolo_plan_graph_launch": (_i, [_vp, _vp]),

@@ -1,5 +1,6 @@
 // C-ABI glue: probes, error text, launch plans (record / replay / hipGraph) and the
 // dtype dispatch of the convolution entry points.
+#include <dlfcn.h>
 #include <stdarg.h>
 
 #include <mutex>
@@ -171,6 +172,29 @@ int plyolo_plan_wait(plyolo_plan* p, int lane, int ev) {
   return 0;
 }
 
+// Host hook: at replay, when the issue loop reaches this point of `lane`, the registered callback runs on the host with
+// that lane's stream -- work it enqueues there (an RCCL collective of the framework the host uses) is ordered after
+// everything recorded on the lane before the hook, and the plan's join waits for it.
+int plyolo_plan_hook(plyolo_plan* p, int lane, int id) {
+  PLY_CHECK_ARG(g_rec == (Plan*)p && p != nullptr, "plan_hook: this plan is not recording");
+  Plan* q = (Plan*)p;
+  PLY_CHECK_ARG(lane >= 0 && lane < 16, "plan_hook: bad lane %d", lane);
+  if (lane + 1 > q->nlanes) q->nlanes = lane + 1;
+  PlanOp op;
+  op.kind = 3; op.lane = lane; op.ev = id;
+  op.label = "hook";
+  q->ops.emplace_back(std::move(op));
+  q->nhooks++;
+  return 0;
+}
+int plyolo_plan_set_hook(plyolo_plan* p, int (*fn)(int, void*, void*), void* user) {
+  PLY_CHECK_ARG(p != nullptr, "plan_set_hook: null plan");
+  ((Plan*)p)->hook = fn;
+  ((Plan*)p)->hook_user = user;
+  return 0;
+}
+int plyolo_plan_hooks(const plyolo_plan* p) { return p ? ((const Plan*)p)->nhooks : 0; }
+
 int plyolo_plan_lanes(const plyolo_plan* p) { return p ? ((const Plan*)p)->nlanes : 0; }
 int plyolo_plan_size(const plyolo_plan* p) { return p ? (int)((const Plan*)p)->ops.size() : 0; }
 // Issue every recorded launch: lane l on its own stream (forked from / joined into `s`), events as
@@ -179,6 +203,9 @@ static hipError_t issue_lanes(Plan* q, hipStream_t s, bool lanes, size_t* failed
   if (!lanes || q->nlanes <= 1) {  // single stream, recorded order (a valid serialisation of the lanes)
     hipError_t le = hipSuccess;
     for (size_t i = 0; i < q->ops.size() && le == hipSuccess; ++i) {
+      if (q->ops[i].kind == 3 && lanes && q->hook) {   // hooks run in eager replays only (never under stream capture)
+        if (q->hook(q->ops[i].ev, (void*)s, q->hook_user) != 0) le = hipErrorUnknown;
+      }
       if (q->ops[i].kind != 0) continue;
       le = q->ops[i].fn(s);
       if (le != hipSuccess && failed) *failed = i;
@@ -210,7 +237,8 @@ static hipError_t issue_lanes(Plan* q, hipStream_t s, bool lanes, size_t* failed
     const PlanOp& op = q->ops[i];
     if (op.kind == 0) le = op.fn(lane_stream(op.lane));
     else if (op.kind == 1) le = hipEventRecord(q->events[(size_t)op.ev], lane_stream(op.lane));
-    else le = hipStreamWaitEvent(lane_stream(op.lane), q->events[(size_t)op.ev], 0);
+    else if (op.kind == 2) le = hipStreamWaitEvent(lane_stream(op.lane), q->events[(size_t)op.ev], 0);
+    else if (q->hook && q->hook(op.ev, (void*)lane_stream(op.lane), q->hook_user) != 0) le = hipErrorUnknown;
     if (le != hipSuccess && failed) *failed = i;
   }
   if (tev)
@@ -303,6 +331,36 @@ int plyolo_plan_op_info(const plyolo_plan* p, int i, char* label, int label_cap,
   if (label && label_cap > 0) snprintf(label, (size_t)label_cap, "%s", q->ops[i].label.c_str());
   if (flops) *flops = q->ops[i].flops;
   if (bytes) *bytes = q->ops[i].bytes;
+  return 0;
+}
+
+// ---- RCCL: the gradient exchange of one bucket through the C ABI.  The communicator belongs to the host
+// (ncclCommInitRank over the xGMI ring); the library resolves ncclAllReduce at run time from the RCCL the process already
+// uses (or from the path given to plyolo_rccl_set_library), so libplyolo_hip.so carries no link-time RCCL dependency.
+static void* g_rccl_handle = nullptr;
+typedef int (*nccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+static nccl_allreduce_fn g_nccl_allreduce = nullptr;
+int plyolo_rccl_set_library(const char* path) {
+  void* h = dlopen(path && path[0] ? path : "librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  PLY_CHECK_ARG(h != nullptr, "rccl_set_library: cannot load %s: %s", path ? path : "librccl.so", dlerror());
+  void* f = dlsym(h, "ncclAllReduce");
+  PLY_CHECK_ARG(f != nullptr, "rccl_set_library: %s has no ncclAllReduce", path ? path : "librccl.so");
+  g_rccl_handle = h;
+  g_nccl_allreduce = (nccl_allreduce_fn)f;
+  return 0;
+}
+// In-place all-reduce of `count` fp32 gradients over `comm` (an ncclComm_t) on `stream`; average != 0: ncclAvg (the mean the
+// data-parallel step needs), else ncclSum.  Enqueues only; ordering is the stream's.
+int plyolo_rccl_allreduce_bucket(void* comm, float* grads, size_t count, int average, void* stream) {
+  PLY_CHECK_ARG(comm != nullptr && grads != nullptr && count > 0, "rccl_allreduce_bucket: null communicator / buffer or empty bucket");
+  if (!g_nccl_allreduce) {
+    void* f = dlsym(RTLD_DEFAULT, "ncclAllReduce");
+    if (f) g_nccl_allreduce = (nccl_allreduce_fn)f;
+    else if (plyolo_rccl_set_library(nullptr) != 0) return -1;
+  }
+  const int ncclFloat32 = 7, ncclSum = 0, ncclAvg = 4;   // rccl.h: ncclDataType_t / ncclRedOp_t
+  const int rc = g_nccl_allreduce(grads, grads, count, ncclFloat32, average ? ncclAvg : ncclSum, comm, (hipStream_t)stream);
+  if (rc != 0) { set_error("ncclAllReduce failed (ncclResult_t %d)", rc); return -2; }
   return 0;
 }
 

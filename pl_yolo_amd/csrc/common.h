@@ -125,7 +125,7 @@ struct PlanOp {
   double flops = 0.0;  // algorithmic FLOPs of this launch (0 = not a contraction)
   double bytes = 0.0;  // algorithmic HBM bytes of this launch
   int lane = 0;        // launches of one lane are ordered; lanes run concurrently inside a hipGraph
-  int kind = 0;        // 0 launch, 1 record event `ev` on `lane`, 2 make `lane` wait for event `ev`
+  int kind = 0;        // 0 launch, 1 record event `ev` on `lane`, 2 make `lane` wait for event `ev`, 3 host hook `ev` on `lane`
   int ev = -1;
 };
 struct Plan {
@@ -136,6 +136,9 @@ struct Plan {
   std::vector<hipEvent_t> events;  // fork/join + recorded events
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
+  int (*hook)(int id, void* stream, void* user) = nullptr;   // plyolo_plan_set_hook
+  void* hook_user = nullptr;
+  int nhooks = 0;
 };
 Plan* recording_plan();
 // Describe the NEXT submitted launch (label + algorithmic work); consumed by submit().

@@ -1,39 +1,212 @@
-"""Data-parallel training over the GPUs of one node: one process per GPU, identical
-weights, rank-local BatchNorm statistics and rank-local num_fg normalisation (the
-reference has no SyncBN and no cross-rank num_fg reduction, yolox_loss.py:148-154), and
-exactly one exchange step per iteration: the mean all-reduce of the flat fp32 gradient
-buffer with RCCL over xGMI (torch.distributed backend "nccl" is RCCL on ROCm; "gloo" is
-used by the CPU tests)."""
+"""Data-parallel training over the GPUs of one node: one process per GPU, identical weights, rank-local BatchNorm
+statistics and rank-local num_fg normalisation (the reference has no SyncBN and no cross-rank num_fg reduction,
+yolox_loss.py:148-154), and exactly one exchange per iteration: the MEAN of the flat fp32 gradient buffer, with RCCL
+over xGMI (torch.distributed backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU tests).
+
+The exchange is bucketed and overlapped with the backward plan:
+  * the flat gradient buffer holds the live parameters in `model.parameters()` order (dead Bottleneck.bn pairs behind
+    them, never exchanged); it is cut from the END -- the head, whose gradients are complete first -- into buckets of
+    ~25 MB (PLYOLO_BUCKET_MB).  xGMI is point-to-point: few large collectives beat many small ones;
+  * a bucket is READY when the backward of every layer owning one of its parameters has been recorded.  At that point
+    the backward plan hands the weight-gradient work queued so far to its lane, unpacks the finished weight-gradient
+    slabs into the flat buffer there, and records a HOST HOOK on a communication lane that waits for both lanes
+    (plyolo_plan_hook).  When the eager replay reaches the hook -- the host runs far ahead of the GPU -- the callback
+    enqueues the bucket's all-reduce on that lane's stream; it executes while the data-gradient chain of the layers
+    upstream is still running, and the plan's final join waits for all of it.
+Single bucket / no overlap remains available as GradAllReduce.all_reduce_ (and is what the bucketed path must equal bit
+for bit: tests/test_ddp_cpu.py)."""
+import os
+
 import torch
 import torch.distributed as dist
 
+from . import graph as G
+from ._lib import call, PlyoloError
 
-FORCE_COLLECTIVE = False   # self-test: issue the collective even in a one-rank group (bench.py PLYOLO_BENCH_FORCE_DDP)
+FORCE_COLLECTIVE = False   # self-test: issue the collectives even in a one-rank group (bench.py PLYOLO_BENCH_FORCE_DDP)
+COMM_LANE = 5              # plan lane of the exchange (0 main, 1 weight gradients, 2.. head levels)
+
+
+def bucket_bytes():
+    return int(float(os.environ.get("PLYOLO_BUCKET_MB", "25")) * 1e6)
+
+
+def plan_buckets(offs, sizes, ready, n_live, target_bytes):
+    """Cut the live range [0, n_live) of the flat gradient buffer into buckets, last parameters first.
+
+    offs / sizes: element offset and (aligned) element count of every live parameter in flat order; ready[i]: forward
+    index of the layer that owns parameter i (its gradient is final once the backward has passed that layer), None for
+    a parameter no layer uses.  Returns [(start, end, ready)] in emission order (end of the buffer first), `ready`
+    non-increasing -- bucket k never leaves before bucket k-1."""
+    buckets, end, acc, rdy = [], n_live, 0, None
+    for i in range(len(offs) - 1, -1, -1):
+        acc += sizes[i] * 4
+        if ready[i] is not None:
+            rdy = ready[i] if rdy is None else min(rdy, ready[i])
+        if acc >= target_bytes or i == 0:
+            buckets.append([offs[i], end, rdy])
+            end, acc, rdy = offs[i], 0, None
+    inf = max([b[2] for b in buckets if b[2] is not None] + [0])
+    prev = inf
+    for b in buckets:   # unused-only buckets are ready from the start; enforce emission order
+        b[2] = prev if b[2] is None else min(b[2], prev)
+        prev = b[2]
+    return [tuple(b) for b in buckets]
 
 
 class GradAllReduce:
-    """Averages a flat gradient buffer across ranks.  The whole model is ONE bucket
-    (YOLOX-s: 36 MB): xGMI is point-to-point, so few large collectives beat many small
-    ones; the call is issued on the stream the backward plan ran on."""
+    """Averages (ranges of) a flat gradient buffer across ranks."""
 
     def __init__(self, group=None):
         self.group = group
         self.world = dist.get_world_size(group)
 
-    def all_reduce_(self, flat):
-        if self.world == 1 and not FORCE_COLLECTIVE:
+    def active(self):
+        return self.world > 1 or FORCE_COLLECTIVE
+
+    def all_reduce_(self, flat, start=0, end=None):
+        """In-place mean of flat[start:end] over the ranks, on the current stream (the collective is ordered after the
+        work already queued there, and the stream waits for its result)."""
+        if not self.active():
             return flat
+        view = flat[start:end if end is not None else flat.numel()]
         if dist.get_backend(self.group) == "nccl":   # RCCL averages inside the collective: no second pass over the buffer
-            dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
+            work = dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+            work.wait()                               # a stream-side wait, the host does not block
         else:                                        # gloo (CPU tests) has no AVG
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-            flat.mul_(1.0 / self.world)
+            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+            view.mul_(1.0 / self.world)
+        return flat
+
+    def all_reduce_buckets_(self, flat, buckets):
+        for (a, b, _) in buckets:
+            self.all_reduce_(flat, a, b)
         return flat
 
 
+def _op_params(op):
+    """Every parameter whose gradient the backward of launch-plan op `op` produces."""
+    ps = []
+    for attr in ("pc", "pc_cls", "pc_ro"):
+        pc = getattr(op, attr, None)
+        if pc is not None:
+            for (w, b, _) in pc.sources:
+                ps += [w, b]
+    for attr in ("bn", "bn_a", "bn_b"):
+        bn = getattr(op, attr, None)
+        if bn is not None:
+            ps += [bn.weight, bn.bias]
+    if isinstance(op, G.ImplicitHeadOp):
+        ps += [op.conv.weight, op.conv.bias, op.ia, op.im]
+    return [p for p in ps if p is not None]
+
+
+class BucketSchedule:
+    """Records the bucketed exchange into one backward plan (see the module docstring)."""
+
+    def __init__(self, runner, session, g):
+        self.runner, self.s, self.g, self.ddp = runner, session, g, runner.ddp
+        flat = runner.flat
+        # a fork region (the head levels) is atomic for the schedule: its ops count as their region's first op
+        def owner_index(op):
+            return op.index if op.region is None else min(o.index for o in op.region.ops)
+        ready_of = {}
+        for op in g.ops:
+            for p in _op_params(op):
+                i = owner_index(op)
+                ready_of[id(p)] = min(ready_of.get(id(p), i), i)
+        live = [(p, o) for p, o in zip(flat["params"], flat["offs"]) if o < flat["n_live"]]
+        offs = [o for _, o in live]
+        sizes = [(offs[i + 1] if i + 1 < len(offs) else flat["n_live"]) - offs[i] for i in range(len(offs))]
+        ready = [ready_of.get(id(p)) for p, _ in live]
+        self.buckets = plan_buckets(offs, sizes, ready, flat["n_live"], bucket_bytes())
+        self.next_bucket = 0
+        # weight-gradient slabs are unpacked (and the ImplicitHead extras run) as soon as their layer is done
+        self.entry_op = []
+        op_of_pc = {}
+        for op in g.ops:
+            for attr in ("pc", "pc_cls", "pc_ro"):
+                pc = getattr(op, attr, None)
+                if pc is not None:
+                    op_of_pc[id(pc)] = owner_index(op)
+        ei = 0
+        for c in g.convs:
+            for _ in c.sources:
+                self.entry_op.append(op_of_pc.get(id(c), 0))
+                ei += 1
+        assert ei == len(g.pack_entries)
+        self.entries_left = list(range(len(g.pack_entries)))
+        self.post_left = list(g.post_unpack)
+        self.errors = []
+
+    # ---- recording
+    def after(self, done_idx):
+        """Called by graph.record_ops once every op with forward index >= done_idx has recorded its backward."""
+        ready = []
+        while self.next_bucket < len(self.buckets) and self.buckets[self.next_bucket][2] >= done_idx:
+            ready.append(self.next_bucket)
+            self.next_bucket += 1
+        if ready:
+            self._emit(done_idx, ready)
+
+    def finish(self):
+        self.after(0)
+        if self.entries_left or self.post_left:      # layers whose parameters sit in no bucket (cannot happen; be safe)
+            self._emit(0, [])
+        assert self.next_bucket == len(self.buckets)
+
+    def _emit(self, done_idx, ready):
+        g, plan = self.g, self.g.plan
+        wl = G.WGRAD_LANE if g.use_lanes else 0
+        g.flush_param_grads()
+        plan.lane(wl)
+        todo = [i for i in self.entries_left if self.entry_op[i] >= done_idx]
+        if todo:
+            self.entries_left = [i for i in self.entries_left if self.entry_op[i] < done_idx]
+            t = g.pack_subtable(todo)
+            call("plyolo_unpack_wgrads", t.data_ptr(), len(todo), g.max_pack_elems, 0, None)
+        for op in [o for o in self.post_left if (o.index if o.region is None else min(q.index for q in o.region.ops)) >= done_idx]:
+            op.post_unpack()
+            self.post_left.remove(op)
+        if ready:
+            evs = [plan.record(wl)]
+            if wl != 0:
+                evs.append(plan.record(0))       # BatchNorm / bias gradients are written on the main lane
+            plan.lane(COMM_LANE)
+            for ev in evs:
+                plan.wait(COMM_LANE, ev)
+            for k in ready:
+                plan.hook(COMM_LANE, k)
+        plan.lane(0)
+
+    # ---- replay
+    def install(self, plan):
+        self._streams = {}
+        plan.set_hook(self._exchange)
+        self.plan = plan
+
+    def _exchange(self, k, stream_ptr):
+        a, b, _ = self.buckets[k]
+        flat = self.runner.flat["g"]
+        if flat.is_cuda:
+            st = self._streams.get(stream_ptr)
+            if st is None:
+                st = self._streams[stream_ptr] = torch.cuda.ExternalStream(stream_ptr)
+            with torch.cuda.stream(st):
+                self.ddp.all_reduce_(flat, a, b)
+        else:
+            self.ddp.all_reduce_(flat, a, b)
+
+    def check(self):
+        e = getattr(self.plan, "hook_error", None)
+        if e is not None:
+            self.plan.hook_error = None
+            raise PlyoloError("gradient exchange failed inside the backward plan: %r" % (e,))
+
+
 def attach(model, group=None):
-    """Make `model` (a pl_yolo_amd OneStageD) average its gradients across ranks at the
-    end of every backward, and start from rank 0's weights."""
+    """Make `model` (a pl_yolo_amd OneStageD) average its gradients across ranks inside every backward, and start from
+    rank 0's weights."""
     if not dist.is_initialized():
         raise RuntimeError("torch.distributed is not initialised")
     r = model.runner()
@@ -44,4 +217,5 @@ def attach(model, group=None):
         dist.broadcast(r.flat[key], src=0, group=group)   # ... so the start state is three collectives, not one per tensor
     model.__dict__['_ddp'] = GradAllReduce(group)         # kept on the model: a runner rebuilt later (compute_dtype change) re-attaches it
     r.ddp = model.__dict__['_ddp']
+    r.sessions = {}                                       # backward plans recorded before attach() have no exchange
     return model

@@ -155,6 +155,7 @@ class Graph:
 
     # ------------------------------------------------------------------ lanes
     def add_op(self, op):
+        op.index = len(self.ops)     # position in forward order
         op.lane, op.region = self.cur_lane, self.cur_region
         if self.cur_region is not None:
             self.cur_region.ops.append(op)
@@ -309,6 +310,15 @@ class Graph:
     def zero_bwd_stats(self):
         call("plyolo_memset_async", self.bstat_arena.data_ptr(), 0, self.bstat_arena.numel() * 8, None)
 
+    def pack_subtable(self, indices):
+        """Device table of a subset of the pack entries (build_pack_table must have filled the gradient pointers)."""
+        arr = (PackEntry * max(len(indices), 1))()
+        for j, i in enumerate(indices):
+            arr[j] = self.pack_entries[i][0]
+        t = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+        self.keep.append(t)
+        return t
+
     def build_pack_table(self, grad_ptr_of):
         """Device copy of the PackEntry table; `grad_ptr_of(param)` -> device address of
         that parameter's gradient (inside the flat gradient buffer) or None."""
@@ -409,7 +419,7 @@ class _Branch:
         return False
 
 
-def record_ops(g, plan, ops, method, lanes=True):
+def record_ops(g, plan, ops, method, lanes=True, after=None):
     """Record `op.<method>()` for every op in `ops` (forward order, or reversed for the backward plan)
     with the fork / join events of the regions they belong to.  Inside a region the branches are issued
     round-robin (lane 0 first): the branches are independent, so any interleaving that keeps each lane's
@@ -422,6 +432,8 @@ def record_ops(g, plan, ops, method, lanes=True):
             plan.lane(0)
             getattr(op, method)()
             i += 1
+            if after is not None:
+                after(op.index)      # backward plans: every op with a forward index >= op.index has been recorded
             continue
         j = i
         while j < n and ops[j].region is r:
@@ -449,6 +461,8 @@ def record_ops(g, plan, ops, method, lanes=True):
             if l != 0:
                 g.flush_param_grads(l)  # weight-gradient work queued by this branch leaves with the branch
                 plan.wait(0, plan.record(l))
+        if after is not None:
+            after(min(o.index for o in ops[i:j]))
         i = j
     plan.lane(0)
 
@@ -1258,6 +1272,25 @@ class Plan:
 
     def lanes(self):
         return _lib.lib().plyolo_plan_lanes(self.h)
+
+    def hooks(self):
+        return _lib.lib().plyolo_plan_hooks(self.h)
+
+    def hook(self, lane, hook_id):
+        call("plyolo_plan_hook", self.h, lane, hook_id)
+
+    def set_hook(self, fn):
+        """fn(id, stream_ptr) -> None, called on the host thread by eager replays at every recorded hook."""
+        def tramp(hook_id, stream, user):
+            try:
+                fn(int(hook_id), int(stream or 0))
+                return 0
+            except BaseException as e:      # never let an exception cross the C frame
+                self.hook_error = e
+                return 1
+        self.hook_error = None
+        self._hook_c = C.CFUNCTYPE(C.c_int, C.c_int, C.c_void_p, C.c_void_p)(tramp)   # keep the thunk alive
+        call("plyolo_plan_set_hook", self.h, C.cast(self._hook_c, C.c_void_p), None)
 
     # lanes (concurrent launch sequences inside a hipGraph replay), see include/plyolo.h
     def lane(self, l):

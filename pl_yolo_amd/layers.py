@@ -158,6 +158,11 @@ class Bottleneck(HipModule):
         y = self.conv1.emit(g, x)
         return self.conv2.emit(g, y, residual=x if self.use_add else None)
 
+    def dead_parameters(self):
+        """The reference's Bottleneck carries a BatchNorm it never calls (network_blocks.py:81): its affine pair never gets a
+        gradient.  The runner keeps such parameters behind the live ones in the flat buffers, outside the exchanged buckets."""
+        return list(self.bn.parameters()) if self.bn is not None else []
+
 
 class CSPLayer(HipModule):
     """network_blocks.py:94-131."""

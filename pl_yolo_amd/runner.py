@@ -60,10 +60,16 @@ class DetectorRunner:
         params = list(model.parameters())
         if not params:
             raise PlyoloError("model has no parameters")
-        offs, n = [], 0
+        # parameters no launch plan ever touches (Bottleneck.bn) go behind the live ones: [0, n_live) is what a
+        # data-parallel step exchanges
+        dead = {id(p) for m in model.modules() if hasattr(m, "dead_parameters") for p in m.dead_parameters()}
+        params = [p for p in params if id(p) not in dead] + [p for p in params if id(p) in dead]
+        offs, n, n_live = [], 0, 0
         for p in params:
             offs.append(n)
             n += _align(p.numel())
+            if id(p) not in dead:
+                n_live = n
         w = torch.zeros(n, dtype=torch.float32, device=device)
         gbuf = torch.zeros(n, dtype=torch.float32, device=device)
         with torch.no_grad():
@@ -87,7 +93,7 @@ class DetectorRunner:
             for i, b in enumerate(ib):
                 iw[i:i + 1].copy_(b.data.reshape(-1).to(torch.int64))
                 b.data = iw[i:i + 1].view(b.shape)
-        self.flat = dict(device=device, params=params, offs=offs, w=w, g=gbuf, n=n, fbuf=bw, ibuf=iw,
+        self.flat = dict(device=device, params=params, offs=offs, w=w, g=gbuf, n=n, n_live=n_live, fbuf=bw, ibuf=iw,
                          off_of={id(p): o for p, o in zip(params, offs)})
         self.sessions = {}
 
@@ -179,11 +185,23 @@ class DetectorRunner:
                 if g.dtype != BF16:  # the fp32 parity wgrad accumulates with atomics; the MFMA path overwrites its slabs
                     call("plyolo_memset_async", g.dwp_arena.data_ptr(), 0, g.dwp_arena.numel() * 4, None)
                 g.zero_bwd_stats()
-                G.record_ops(g, s.bwd, list(reversed(g.ops)), "bwd")
-                g.join_lanes()
-                call("plyolo_unpack_wgrads", g.pack_table.data_ptr(), g.n_pack, g.max_pack_elems, 0, None)
-                for op in g.post_unpack:
-                    op.post_unpack()
+                s.sched = None
+                if self.ddp is not None and self.ddp.active():
+                    # data parallel: the gradient buckets leave through host hooks of the backward plan as soon as the
+                    # layers that fill them are done (pl_yolo_amd/ddp.py: BucketSchedule)
+                    from . import ddp as D
+                    s.sched = D.BucketSchedule(self, s, g)
+                    G.record_ops(g, s.bwd, list(reversed(g.ops)), "bwd", after=s.sched.after)
+                    s.sched.finish()
+                    g.join_lanes()
+                else:
+                    G.record_ops(g, s.bwd, list(reversed(g.ops)), "bwd")
+                    g.join_lanes()
+                    call("plyolo_unpack_wgrads", g.pack_table.data_ptr(), g.n_pack, g.max_pack_elems, 0, None)
+                    for op in g.post_unpack:
+                        op.post_unpack()
+            if s.sched is not None:
+                s.sched.install(s.bwd)
             seen = set()
             for op in g.ops:
                 bns = [op.bn] if isinstance(op, (G.ConvUnitOp, G.BnOnlyOp)) else ([op.bn_a, op.bn_b] if isinstance(op, G.ConvPairOp) else [])
@@ -219,6 +237,9 @@ class DetectorRunner:
         private stream (capture is not allowed on the legacy default stream) fenced with
         events on both sides."""
         use_graph = self.use_graph if self.use_graph != "auto" else plan.lanes() <= 1
+        if use_graph and plan.hooks():
+            raise PlyoloError("a data-parallel backward plan issues its gradient buckets from host hooks, which a hipGraph replay "
+                              "cannot run: use the eager replay (PLYOLO_GRAPH=0 / auto)")
         if not use_graph:
             plan.run(self._stream(), False)
             return
@@ -265,8 +286,8 @@ class DetectorRunner:
     def backward_train(self, s, gout):
         s.head.gout[:gout.numel()].copy_(gout.reshape(-1))
         self._run_plan(s.bwd)
-        if self.ddp is not None:
-            self.ddp.all_reduce_(self.flat["g"])
+        if s.sched is not None:
+            s.sched.check()
 
     def forward_eval(self, x):
         x = self._check_input(x)
@@ -294,8 +315,8 @@ class DetectorRunner:
     def backward_maps(self, s, grads):
         s.head.set_map_grads(grads)
         self._run_plan(s.bwd)
-        if self.ddp is not None:
-            self.ddp.all_reduce_(self.flat["g"])
+        if s.sched is not None:
+            s.sched.check()
 
 
 def _check_generation(ctx, s):
