@@ -220,6 +220,26 @@ int plyolo_bn_finalize(const plyolo_bn_stats* st, int C, float* coef, void* stre
 /* eval mode: coef from running statistics */
 int plyolo_bn_eval_coef(int C, const float* gamma, const float* beta, const float* running_mean,
                         const float* running_var, float eps, float* coef, void* stream);
+/* ------------------------------------------------------------ e-yolox family: depthwise 3x3 conv, bicubic x2 upsample
+ * Depthwise conv = nn.Conv2d(C, C, 3, 1, 1, groups=C, bias=False) inside BaseConv (models/backbones/ecmnet.py:157,160;
+ * models/necks/pafpn_al.py:162,165) forward / data gradient / weight gradient; NHWC activations with pixel pitch *_ld,
+ * fp32 master weights [C][1][3][3] read directly (rounded to bf16 in bf16 mode like the MFMA weight packs).
+ * stats (fwd): NULL or the fp64 stat slots [PLYOLO_STAT_SLOTS][2][C] receiving sum / sum of squares of y. */
+int plyolo_dwconv3x3_fwd(int dtype, int N, int H, int W, int C, const void* x, int x_ld, const float* w, void* y, int y_ld,
+                         double* stats, void* stream);
+int plyolo_dwconv3x3_dgrad(int dtype, int N, int H, int W, int C, const void* dy, int dy_ld, const float* w, void* dx, int dx_ld,
+                           int accumulate, void* stream);
+/* dw[c][tap] (+)= sum_pixels dz * x: `partial` holds plyolo_dwconv3x3_wgrad_blocks() fp32 slabs of [C][9] (per-workgroup
+ * partials, folded in a fixed order by a second launch: deterministic, no atomics). */
+int plyolo_dwconv3x3_wgrad_blocks(int dtype, int N, int H, int W, int C);
+int plyolo_dwconv3x3_wgrad(int dtype, int N, int H, int W, int C, const void* x, int x_ld, const void* dz, int dz_ld, float* partial,
+                           float* dw, int accumulate, void* stream);
+/* nn.Upsample(scale_factor=2, mode="bicubic") (models/necks/pafpn_al.py:25), align_corners=False, A = -0.75; in [N,H,W,C]
+ * -> out [N,2H,2W,C]; backward = exact transpose as a gather (din (+)= ...). */
+int plyolo_bicubic2x_fwd(int dtype, int N, int H, int W, int C, const void* in, int i_ld, void* out, int o_ld, void* stream);
+int plyolo_bicubic2x_bwd(int dtype, int N, int H, int W, int C, const void* dout, int d_ld, void* din, int i_ld, int accumulate,
+                         void* stream);
+
 /* ------------------------------------------------------------ deploy-time folding (inference export)
  * Replaces RepConv._fuse_bn_tensor / get_equivalent_kernel_bias / fuse_conv_bn / fuse_repvgg_block
  * (models/necks/yolov7_neck.py:213-348) and prepares BaseConv.fuseforward (network_blocks.py:39-40): fp32 weights in

@@ -9,9 +9,13 @@ from . import net, yolox_loss
 
 
 def forward(state, cfg, num_classes, x, labels=None, training=True, return_assign=False):
-    if cfg["backbone"]["name"] != "cspdarknet" or cfg["head"]["name"] != "decoupled_head":
-        raise NameError("oracle.detector covers the cspdarknet/csppafpn/decoupled_head/yolox path")
-    maps = net.yolox_network(state, cfg, x, training)
+    if cfg["backbone"]["name"] not in ("cspdarknet", "ecmnet") or cfg["head"]["name"] != "decoupled_head":
+        raise NameError("oracle.detector covers the cspdarknet/csppafpn and ecmnet/al_pafpn + decoupled_head/yolox paths")
+    if cfg["backbone"]["name"] == "ecmnet":
+        from . import net_e
+        maps = net_e.eyolox_network(state, cfg, x, training)
+    else:
+        maps = net.yolox_network(state, cfg, x, training)
     if labels is None:
         return maps
     strides = cfg["loss"]["stride"]

@@ -70,12 +70,12 @@ def activation(x, name):
     raise AttributeError("Unsupported activation function type: {}".format(name))
 
 
-def conv_unit(state, prefix, x, stride, training, norm="bn", act="silu", residual=None):
+def conv_unit(state, prefix, x, stride, training, norm="bn", act="silu", residual=None, groups=1):
     """One BaseConv: conv (no bias, same padding) -> BN (batch stats in
     training, running stats in eval; running buffers updated in place) -> act."""
     w = state[prefix + ".conv.weight"]
     k = w.shape[-1]
-    z = F.conv2d(x, _qw(w), state.get(prefix + ".conv.bias"), stride, (k - 1) // 2)
+    z = F.conv2d(x, _qw(w), state.get(prefix + ".conv.bias"), stride, (k - 1) // 2, 1, groups)
     if norm is not None and _EMU[0]:
         if norm != "bn":
             raise AttributeError("Unsupported normalization function type: {}".format(norm))

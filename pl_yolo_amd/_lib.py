@@ -139,6 +139,12 @@ SIGNATURES = {
     "plyolo_unpack_wgrads": (_i, [_vp, _i, _i, _i, _vp]),
     "plyolo_bn_finalize": (_i, [_P(BnStats), _i, _vp, _vp]),
     "plyolo_bn_eval_coef": (_i, [_i, _vp, _vp, _vp, _vp, _f, _vp, _vp]),
+    "plyolo_dwconv3x3_fwd": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp]),
+    "plyolo_dwconv3x3_dgrad": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp]),
+    "plyolo_dwconv3x3_wgrad_blocks": (_i, [_i, _i, _i, _i, _i]),
+    "plyolo_dwconv3x3_wgrad": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp]),
+    "plyolo_bicubic2x_fwd": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
+    "plyolo_bicubic2x_bwd": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp]),
     "plyolo_bias_coef": (_i, [_i, _vp, _vp, _vp]),
     "plyolo_fold_conv_bn": (_i, [_vp, _vp, _P(BnParams), _i, _i, _vp, _vp, _vp]),
     "plyolo_repconv_fuse": (_i, [_vp, _P(BnParams), _vp, _P(BnParams), _P(BnParams), _i, _i, _vp, _vp, _vp]),

@@ -21,6 +21,7 @@ from .backbones import CSPDarkNet, EELAN
 from .necks import CSPPAFPN, YOLOv7NECK
 from .heads import DecoupledHead, ImplicitHead
 from .losses import YOLOXLoss, YOLOv7Loss
+from .eyolox import ECMNet, AL_PAFPN
 from . import runner as R
 
 
@@ -120,6 +121,14 @@ def yolov7(cfg, num_classes):
     return YOLOv7Loss(num_classes, cfg['stride'], cfg['anchors'])
 
 
+def ecmnet(cfg):
+    return ECMNet(cfg['depths'], cfg['channels'], cfg['outputs'], cfg['norm'], cfg['act'])
+
+
+def al_pafpn(cfg):
+    return AL_PAFPN(cfg['depths'], cfg['channels'], cfg['norm'], cfg['act'])
+
+
 def csppafpn(cfg):
     return CSPPAFPN(cfg['depths'], cfg['channels'], cfg['norm'], cfg['act'])
 
@@ -136,10 +145,9 @@ def yolox(cfg, num_classes):
     return YOLOXLoss(num_classes, cfg['stride'])
 
 
-_REGISTRY = {f.__name__: f for f in (cspdarknet, eelan, csppafpn, yolov7neck, none, decoupled_head, implicit_head, yolox, yolov7)}
+_REGISTRY = {f.__name__: f for f in (cspdarknet, eelan, ecmnet, csppafpn, yolov7neck, al_pafpn, none, decoupled_head, implicit_head, yolox, yolov7)}
 # reference plugins that exist upstream but are outside this build's hot path
-_KNOWN_UNBUILT = ("cspmobilenext", "ecmnet", "shufflenetv2", "mobilenetv3s", "mobilenetv3l",
-                  "vision_transformer", "swin_transformer", "al_pafpn")
+_KNOWN_UNBUILT = ("cspmobilenext", "shufflenetv2", "mobilenetv3s", "mobilenetv3l", "vision_transformer", "swin_transformer")
 
 
 def _plugin(name):

@@ -96,6 +96,8 @@ def _op_params(op):
         bn = getattr(op, attr, None)
         if bn is not None:
             ps += [bn.weight, bn.bias]
+    if isinstance(op, G.DwConvUnitOp):
+        ps.append(op.w)
     if isinstance(op, G.ImplicitHeadOp):
         ps += [op.conv.weight, op.conv.bias, op.ia, op.im]
     return [p for p in ps if p is not None]

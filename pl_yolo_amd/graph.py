@@ -255,7 +255,7 @@ class Graph:
         # one memset per plan zeroes a whole arena (zero_fwd_stats / zero_bwd_stats)
         off = 0
         for op in self.ops:
-            if isinstance(op, (ConvUnitOp, ConvPairOp, BnOnlyOp)) and op.bn is not None:
+            if isinstance(op, (ConvUnitOp, ConvPairOp, BnOnlyOp, DwConvUnitOp)) and op.bn is not None:
                 op.slot_off = off
                 off += STAT_SLOTS * 2 * op.Cout
         self.stat_arena = torch.zeros(max(off, 8), dtype=torch.float64, device=dev)
@@ -630,19 +630,23 @@ class ConvUnitOp:
         g, bn = self.g, self.bn
         if not g.grad_ready(self.out):
             return  # nothing downstream contributes a gradient
-        if bn is None:
-            raise NotImplementedError("training a conv unit without BatchNorm is not supported by the HIP plan")
+        if bn is None and self.conv_b is not None:
+            raise NotImplementedError("training the deploy form (conv + bias, BatchNorm folded) is not supported by the HIP plan")
         M, Cout = self.out.M, self.Cout
         dout, zt = g.gptr(self.out), self.z.tensor.data_ptr()
         if self.res is not None:
             acc = g.grad_mode(self.res)
             call("plyolo_copy_add", g.dtype, M, Cout, dout, self.out.ld, g.gptr(self.res), self.res.ld, acc, None)
-        bslots = g.bstat_arena.data_ptr() + self.slot_off * 8
-        call("plyolo_bn_act_bwd_reduce", g.dtype, M, Cout, dout, self.out.ld, zt, Cout, self.coef.data_ptr(), self.act, bslots, None, None)
         plan, lanes, me = g.plan, g.use_lanes, self.lane
         dz, key = g.dz_buffer(self, M * Cout)
-        call("plyolo_bn_act_bwd_dz", g.dtype, M, Cout, dout, self.out.ld, zt, Cout, self.coef.data_ptr(), bslots, ptr(bn.weight),
-             g.grad_ptr_of(bn.weight), g.grad_ptr_of(bn.bias), 0, self.act, dz, Cout, None, None, None)
+        if bn is None:
+            # BaseConv(norm=None): out = act(z)  (ecmnet.py:158 Bottleneck.conv1) -> dz = dout * act'(z)
+            call("plyolo_act_bwd", g.dtype, M, Cout, dout, self.out.ld, zt, Cout, self.act, dz, Cout, 0, None)
+        else:
+            bslots = g.bstat_arena.data_ptr() + self.slot_off * 8
+            call("plyolo_bn_act_bwd_reduce", g.dtype, M, Cout, dout, self.out.ld, zt, Cout, self.coef.data_ptr(), self.act, bslots, None, None)
+            call("plyolo_bn_act_bwd_dz", g.dtype, M, Cout, dout, self.out.ld, zt, Cout, self.coef.data_ptr(), bslots, ptr(bn.weight),
+                 g.grad_ptr_of(bn.weight), g.grad_ptr_of(bn.bias), 0, self.act, dz, Cout, None, None, None)
         def dgrad():
             if self.need_dgrad:
                 acc = g.grad_mode(self.x)
@@ -765,6 +769,100 @@ class ConvPairOp:
         else:
             wgrad()
             call("plyolo_conv2d_dgrad", C.byref(self.desc_d), dz, self.pc.wpd, g.gptr(self.x), acc, None)
+
+
+class DwConvUnitOp:
+    """BaseConv with a depthwise 3x3 convolution (groups == channels, stride 1): conv -> BatchNorm -> activation [+ residual]
+    (reference models/backbones/ecmnet.py:157,160 / models/necks/pafpn_al.py:162,165: Bottleneck.conv0 / conv3).  An HBM stream
+    (csrc/dwconv.hip), not an MFMA contraction; the fp32 master weight [C,1,3,3] is read directly, its gradient written directly."""
+
+    def __init__(self, g, x, conv_w, bn, act, residual=None):
+        self.g, self.x, self.w, self.bn, self.act, self.res = g, x, conv_w, bn, ACT[act], residual
+        Cc = conv_w.shape[0]
+        assert tuple(conv_w.shape) == (Cc, 1, 3, 3) and x.C == Cc and Cc % g.vec == 0, "depthwise 3x3: [C,1,3,3] weights, C %% %d == 0" % g.vec
+        if bn is None:
+            raise NotImplementedError("depthwise conv unit without BatchNorm")
+        self.Cout = Cc
+        x.needs_tensor = True
+        if residual is not None:
+            residual.needs_tensor = True
+        self.out = g.new_act(x.N, x.H, x.W, Cc, "a")
+        self.z = Storage(x.N, x.H, x.W, Cc, "z")
+        g.storages.append(self.z)
+        g.scratch_elems = max(g.scratch_elems, self.z.rows * Cc)
+        g.add_op(self)
+
+    def fwd(self):
+        g, bn, x = self.g, self.bn, self.x
+        if not hasattr(self, "coef"):
+            self.coef = torch.empty(4 * self.Cout, dtype=torch.float32, device=g.device)
+        zt = self.z.tensor.data_ptr()
+        slots = g.stat_arena.data_ptr() + self.slot_off * 8 if g.training else None
+        call("plyolo_dwconv3x3_fwd", g.dtype, x.N, x.H, x.W, self.Cout, g.aptr(x), x.ld, ptr(self.w), zt, self.Cout, slots, None)
+        st = None
+        if g.training:
+            st = BnStats()
+            st.slots, st.count = slots, float(self.out.M)
+            st.gamma, st.beta = ptr(bn.weight), ptr(bn.bias)
+            st.eps, st.momentum = float(bn.eps), float(bn.momentum)
+            st.running_mean, st.running_var = ptr(bn.running_mean), ptr(bn.running_var)
+            st.num_batches_tracked = ptr(bn.num_batches_tracked)
+        else:
+            call("plyolo_bn_eval_coef", self.Cout, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var),
+                 float(bn.eps), self.coef.data_ptr(), None)
+        call("plyolo_bn_act_fwd", g.dtype, self.out.M, self.Cout, zt, self.Cout, self.coef.data_ptr(), self.act,
+             g.aptr(self.res) if self.res is not None else None, self.res.ld if self.res is not None else 0,
+             g.aptr(self.out), self.out.ld, C.byref(st) if st is not None else None, None, None)
+
+    def bwd(self):
+        g, bn, x = self.g, self.bn, self.x
+        if not g.grad_ready(self.out):
+            return
+        M, Cc = self.out.M, self.Cout
+        dout, zt = g.gptr(self.out), self.z.tensor.data_ptr()
+        if self.res is not None:
+            acc = g.grad_mode(self.res)
+            call("plyolo_copy_add", g.dtype, M, Cc, dout, self.out.ld, g.gptr(self.res), self.res.ld, acc, None)
+        bslots = g.bstat_arena.data_ptr() + self.slot_off * 8
+        call("plyolo_bn_act_bwd_reduce", g.dtype, M, Cc, dout, self.out.ld, zt, Cc, self.coef.data_ptr(), self.act, bslots, None, None)
+        dz, _ = g.dz_buffer(self, M * Cc)
+        call("plyolo_bn_act_bwd_dz", g.dtype, M, Cc, dout, self.out.ld, zt, Cc, self.coef.data_ptr(), bslots, ptr(bn.weight),
+             g.grad_ptr_of(bn.weight), g.grad_ptr_of(bn.bias), 0, self.act, dz, Cc, None, None, None)
+        acc = g.grad_mode(x)
+        call("plyolo_dwconv3x3_dgrad", g.dtype, x.N, x.H, x.W, Cc, dz, Cc, ptr(self.w), g.gptr(x), x.ld, acc, None)
+        if not hasattr(self, "partial"):
+            nb = _lib.lib().plyolo_dwconv3x3_wgrad_blocks(g.dtype, x.N, x.H, x.W, Cc)
+            self.partial = torch.empty(max(nb, 1) * Cc * 9, dtype=torch.float32, device=g.device)
+
+        def wgrad():
+            call("plyolo_dwconv3x3_wgrad", g.dtype, x.N, x.H, x.W, Cc, g.aptr(x), x.ld, dz, Cc, self.partial.data_ptr(),
+                 g.grad_ptr_of(self.w), 0, None)
+
+        if g.use_lanes:
+            g.defer_param_grads(self.lane, wgrad)
+        else:
+            wgrad()
+
+
+class BicubicUpsampleOp:
+    """nn.Upsample(scale_factor=2, mode="bicubic") (models/necks/pafpn_al.py:25)."""
+
+    def __init__(self, g, x):
+        self.g, self.x = g, x
+        x.needs_tensor = True
+        self.out = g.new_act(x.N, 2 * x.H, 2 * x.W, x.C, "up3")
+        g.add_op(self)
+
+    def fwd(self):
+        g, x = self.g, self.x
+        call("plyolo_bicubic2x_fwd", g.dtype, x.N, x.H, x.W, x.C, g.aptr(x), x.ld, g.aptr(self.out), self.out.ld, None)
+
+    def bwd(self):
+        g, x = self.g, self.x
+        if not g.grad_ready(self.out):
+            return
+        acc = g.grad_mode(x)
+        call("plyolo_bicubic2x_bwd", g.dtype, x.N, x.H, x.W, x.C, g.gptr(self.out), self.out.ld, g.gptr(x), x.ld, acc, None)
 
 
 class ActOp:

@@ -54,8 +54,10 @@ class BaseConv(HipModule):
     def __init__(self, in_channels, out_channels, ksize, stride, padding=None, groups=1, bias=False, norm="bn", act="silu"):
         super().__init__()
         pad = (ksize - 1) // 2 if padding is None else padding
-        if groups != 1 or bias or pad != (ksize - 1) // 2 or ksize not in (1, 3) or stride not in (1, 2):
-            raise NotImplementedError("HIP conv supports k in {1,3}, stride in {1,2}, same padding, groups=1, no bias")
+        # groups: 1 (MFMA kernels) or depthwise 3x3 stride 1 (groups == in == out: the e-yolox Bottleneck, csrc/dwconv.hip)
+        self.depthwise = groups != 1 and groups == in_channels == out_channels and ksize == 3 and stride == 1
+        if (groups != 1 and not self.depthwise) or bias or pad != (ksize - 1) // 2 or ksize not in (1, 3) or stride not in (1, 2):
+            raise NotImplementedError("HIP conv supports k in {1,3}, stride in {1,2}, same padding, no bias, groups=1 or depthwise 3x3 stride 1")
         self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=ksize, stride=stride, padding=pad, groups=groups, bias=bias)
         self.norm = get_normalization(norm, out_channels)
         self.act = get_activation(act, inplace=True)
@@ -63,6 +65,10 @@ class BaseConv(HipModule):
 
     def emit(self, g, x, residual=None, need_dgrad=True, cin_pad=None):
         act = self.act.act_name if self.act is not None else None
+        if getattr(self, "depthwise", False):
+            if self.norm is None:
+                raise NotImplementedError("depthwise BaseConv without BatchNorm (fold it back or keep norm='bn')")
+            return G.DwConvUnitOp(g, x, self.conv.weight, self.norm, act, residual).out
         op = G.ConvUnitOp(g, x, self.conv.weight, self.norm, act, self.stride, residual, need_dgrad, cin_pad, conv_b=self.conv.bias)
         return op.out
 
@@ -70,7 +76,7 @@ class BaseConv(HipModule):
         """Deploy form: fold the BatchNorm into the convolution (weights scaled per output channel, a bias appears) and drop
         it, so that forward == the reference's `fuseforward` = act(conv(x)) (network_blocks.py:39-40; the folding rule is
         RepConv.fuse_conv_bn, yolov7_neck.py:265-286).  One HIP launch (plyolo_fold_conv_bn); inference only."""
-        if self.norm is None:
+        if self.norm is None or getattr(self, "depthwise", False):   # depthwise units keep their BatchNorm (no fused deploy kernel)
             return self
         if not isinstance(self.norm, nn.BatchNorm2d):
             raise NotImplementedError("only BatchNorm2d folds into a convolution")

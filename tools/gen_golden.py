@@ -519,6 +519,54 @@ def gen_deploy():
     save("deploy_fold", d)
 
 
+def gen_network_e():
+    """The e-yolox family (ecmnet + al_pafpn: depthwise 3x3, BatchNorm-free 1x1, bicubic upsampling) through the reference:
+    toy width, one training step (losses + every gradient + running statistics), raw maps, eval output."""
+    with open(os.path.join(ROOT, "configs", "model", "e-yolox", "e-yolox_test.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    C = 3
+    torch.manual_seed(96)
+    model = build_model(cfg, C)
+    g = torch.Generator().manual_seed(5)
+    for n, p in model.named_parameters():
+        if n.endswith(".norm.weight"):
+            p.data = 0.5 + torch.rand(p.shape, generator=g)
+        if n.endswith(".norm.bias"):
+            p.data = torch.rand(p.shape, generator=g) - 0.5
+    gen = torch.Generator().manual_seed(1234)
+    x = torch.rand(2, 3, 96, 96, generator=gen) * 255
+    labels = torch.zeros(2, 8, 5)
+    labels[0, :3] = torch.tensor([[0, 30.0, 36.0, 28.0, 32.0], [2, 60.0, 60.0, 44.0, 40.0], [1, 76.0, 20.0, 24.0, 18.0]])
+    labels[1, :2] = torch.tensor([[1, 44.0, 44.0, 60.0, 54.0], [0, 18.0, 76.0, 20.0, 28.0]])
+    d = dict(x=x, labels=labels, num_classes=C)
+    for k, v in model.state_dict().items():
+        d["state/" + k] = v.clone()
+    model.train()
+    maps = model(x)
+    for i, m in enumerate(maps):
+        d["maps_train%d" % i] = m.detach().clone()
+    model.load_state_dict({k[len("state/"):]: torch.as_tensor(v) for k, v in d.items() if k.startswith("state/")})
+    model.zero_grad()
+    _calls.clear()
+    out = model(x, labels)
+    out["loss"].backward()
+    for k in ("loss", "loss_iou", "loss_obj", "loss_cls"):
+        d["out/" + k] = out[k].detach()
+    d["out/proportion"] = float(out["proportion"])
+    d["boundary_gap"] = min([c["gap"] for c in _calls] + [float("inf")])
+    for n, p in model.named_parameters():
+        if p.grad is not None:
+            d["grad/" + n] = p.grad.clone()
+    for k, v in model.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            d["state_after/" + k] = v.clone()
+    model.eval()
+    with torch.no_grad():
+        d["eval_out"] = model(x, labels).clone()
+    print("e-yolox fixture: loss=%.6f gap=%.3g params=%d" % (float(out["loss"]), d["boundary_gap"], len(list(model.parameters()))))
+    save("network_eyolox_test", d)
+
+
 def gen_network_warm():
     """"Warm weights": the toy YOLOX after 50 SGD steps of the REFERENCE on a small fixed data set, then one
     recorded training step at that state (losses, every gradient, head maps).  A trained-for-a-while BatchNorm net
@@ -603,6 +651,9 @@ def gen_cfg1():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "eyolox":
+        gen_network_e()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "deploy":
         gen_deploy()
         sys.exit(0)
@@ -625,6 +676,7 @@ if __name__ == "__main__":
     gen_blocks()
     gen_network()
     gen_network_warm()
+    gen_network_e()
     gen_deploy()
     gen_cfg1()
     gen_schedule()
