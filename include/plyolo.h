@@ -240,6 +240,21 @@ int plyolo_bicubic2x_fwd(int dtype, int N, int H, int W, int C, const void* in, 
 int plyolo_bicubic2x_bwd(int dtype, int N, int H, int W, int C, const void* dout, int d_ld, void* din, int i_ld, int accumulate,
                          void* stream);
 
+/* ------------------------------------------------------------ GPU input pipeline (per-image transforms of a batch)
+ * Replaces augment_hsv + _mirror + preproc of models/data/augmentation/data_augments.py:88-133: for every image descriptor the
+ * uint8 HWC BGR source is (optionally) colour-jittered in HSV, mirrored, resized by the letterbox ratio r (bilinear, 8-bit
+ * fixed point like cv2.resize), padded with 114 to out_h x out_w and written as fp32 CHW (values 0..255, BGR order) --
+ * out [B, 3, out_h, out_w], exactly what OneStageD.forward takes.  The OpenCV algorithms are restated (csrc/augment.hip). */
+typedef struct plyolo_aug_image {
+  const unsigned char* src;   /* device pointer, [h][w][3] uint8 */
+  int h, w;
+  float r;                    /* min(out_h / h, out_w / w), computed by the host like preproc (data_augments.py:93) */
+  int flip;                   /* mirror horizontally (data_augments.py:129-133) */
+  int hsv;                    /* apply the HSV jitter with the three gains below (data_augments.py:113-127) */
+  float hgain, sgain, vgain;  /* r = uniform(-1, 1, 3) * [0.015, 0.7, 0.4] + 1 */
+} plyolo_aug_image;
+int plyolo_preproc_batch(const plyolo_aug_image* imgs_dev, int B, int out_h, int out_w, float* out, void* stream);
+
 /* ------------------------------------------------------------ deploy-time folding (inference export)
  * Replaces RepConv._fuse_bn_tensor / get_equivalent_kernel_bias / fuse_conv_bn / fuse_repvgg_block
  * (models/necks/yolov7_neck.py:213-348) and prepares BaseConv.fuseforward (network_blocks.py:39-40): fp32 weights in
@@ -429,6 +444,16 @@ size_t plyolo_postprocess_workspace(const plyolo_nms_desc* d);
  * ncand i32[B] (boxes that entered NMS) */
 int plyolo_postprocess(const plyolo_nms_desc* d, const float* pred, float* det, int32_t* count, int32_t* ncand,
                        void* workspace, size_t ws_bytes, void* stream);
+/* Evaluation formatting (models/evaluators/postprocess.py:95-138 + models/utils/bbox.py:58-63), device side: for every
+ * image descriptor the n detection rows (x1,y1,x2,y2,score,cls, row pitch ld floats) are divided by `scale` IN PLACE (the
+ * reference's side effect) and written as packed (x1, y1, x2, y2, w, h, score, cls) rows out[(row0 + r) * 8] -- one launch and one
+ * device->host copy per validation batch instead of one blocking copy per box.  imgs_dev: device array of B descriptors. */
+typedef struct plyolo_fmt_image {
+  float* det;
+  int n, ld, row0;
+  float scale;
+} plyolo_fmt_image;
+int plyolo_format_detections(const plyolo_fmt_image* imgs_dev, int B, int max_rows, float* out, void* stream);
 /* NMS only: boxes [B,n,6] (x1,y1,x2,y2,score,cls) already filtered, n per image in nbox[B] */
 int plyolo_batched_nms(const plyolo_nms_desc* d, const float* boxes, int n_max, const int32_t* nbox, float* det,
                        int32_t* count, void* workspace, size_t ws_bytes, void* stream);

@@ -1,11 +1,12 @@
 """CPU restatement of the evaluation formatting step (TEST ORACLE -- imported by tests only).
 
 `format_outputs` follows /root/reference/models/evaluators/postprocess.py:95-138 box by box, with
-`xyxy2xywh` from /root/reference/models/utils/bbox.py:58-63.  The reference module cannot be imported
-here (its first lines import torchvision, which is not installable in the build container), so this
-file is a restatement from the text; PARITY UNPINNED against a run of the reference.  The arithmetic is
-two fp32 operations per box (divide by the letterbox scale, subtract corners), pinned by the
-hand-computed cases in tests/test_oracle_nms.py.
+`xyxy2xywh` from /root/reference/models/utils/bbox.py:58-63.  The reference MODULE cannot be imported
+here (its first line imports torchvision, which is not installable in the build container), but the
+reference FUNCTION runs: tools/gen_golden.py parses the reference file, executes only `format_outputs` (with
+the reference's own xyxy2xywh) and records tests/golden/format_outputs.npz -- this restatement is PINNED to
+that fixture (tests/test_oracle_nms.py::test_format_outputs_vs_reference_fixture), records, per-class arrays
+and the in-place rescale side effect included.
 """
 import numpy as np
 import torch

@@ -99,6 +99,15 @@ class NmsDesc(C.Structure):
     ]
 
 
+class AugImage(C.Structure):   # plyolo_aug_image
+    _fields_ = [("src", C.c_void_p), ("h", C.c_int), ("w", C.c_int), ("r", C.c_float), ("flip", C.c_int), ("hsv", C.c_int),
+                ("hgain", C.c_float), ("sgain", C.c_float), ("vgain", C.c_float)]
+
+
+class FmtImage(C.Structure):   # plyolo_fmt_image
+    _fields_ = [("det", C.c_void_p), ("n", C.c_int), ("ld", C.c_int), ("row0", C.c_int), ("scale", C.c_float)]
+
+
 _vp, _i, _f, _d, _sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
 _P = C.POINTER
 
@@ -184,6 +193,8 @@ SIGNATURES = {
     "plyolo_yolov7_eval_decode": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp]),
     "plyolo_postprocess_workspace": (_sz, [_P(NmsDesc)]),
     "plyolo_postprocess": (_i, [_P(NmsDesc), _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "plyolo_preproc_batch": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "plyolo_format_detections": (_i, [_vp, _i, _i, _vp, _vp]),
     "plyolo_batched_nms": (_i, [_P(NmsDesc), _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "plyolo_sgd_momentum": (_i, [_vp, _vp, _vp, _sz, _vp, _f, _f, _i, _vp]),
     "plyolo_ema_update": (_i, [_vp, _vp, _sz, _f, _vp]),

@@ -64,35 +64,44 @@ def format_outputs(outputs, ids, hws, val_size, class_ids, labels=None):
     PL_Modules/pl_detection.py:78,132 right after `postprocess`).
 
     Same results and the same side effect (the boxes of `outputs[i]` are rescaled IN PLACE to the original
-    image, postprocess.py:112-113), but the device is touched once per image for the rescale (asynchronous) and
-    ONCE per batch for the device->host copy; the reference copies every box, score and class mask to the host
-    separately (postprocess.py:125-126,136), i.e. thousands of blocking copies per validation batch.
+    image, postprocess.py:112-113).  The rescale and the xyxy -> xywh conversion of the whole batch are ONE HIP launch
+    (plyolo_format_detections) followed by ONE device->host copy; the reference copies every box, score and class mask
+    to the host separately (postprocess.py:125-126,136), i.e. thousands of blocking copies per validation batch.
     """
+    import ctypes as C
     import numpy as np
+    from ._lib import FmtImage
     n_cls = len(class_ids)
     det_list = [[np.empty(shape=[0, 5]) for _ in range(n_cls)] for _ in range(len(outputs))]
-    live = []
+    live, row0 = [], 0
     for i, (output, img_h, img_w, img_id) in enumerate(zip(outputs, hws[0], hws[1], ids)):
         if output is None:
             continue
+        if not output.is_cuda:
+            raise PlyoloError("format_outputs runs on MI355X device tensors (the output of postprocess); there is no CPU path")
+        if output.dtype != torch.float32 or output.dim() != 2 or output.shape[1] < 6 or output.stride(1) != 1:
+            raise PlyoloError("format_outputs expects fp32 [n, 6] detection rows (x1, y1, x2, y2, conf, cls)")
         scale = min(val_size[0] / float(img_w), val_size[1] / float(img_h))
-        output[:, 0:4] /= scale  # in place, like the reference (fp32 tensor / python float)
-        live.append((i, int(img_id), output))
-    if not live:
+        live.append((i, int(img_id), output, float(scale), row0))
+        row0 += int(output.shape[0])
+    if not live or row0 == 0:
         return [], det_list
-    host = torch.cat([o for _, _, o in live], 0).detach().to("cpu", torch.float32).numpy()  # the only device->host copy
+    dev = live[0][2].device
+    arr = (FmtImage * len(live))()
+    for k, (i, img_id, output, scale, r0) in enumerate(live):
+        arr[k].det, arr[k].n, arr[k].ld, arr[k].row0, arr[k].scale = output.data_ptr(), int(output.shape[0]), int(output.stride(0)), r0, scale
+    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+    packed = torch.empty(row0, 8, dtype=torch.float32, device=dev)
+    call("plyolo_format_detections", table.data_ptr(), len(live), max(int(o.shape[0]) for _, _, o, _, _ in live), packed.data_ptr(),
+         torch.cuda.current_stream().cuda_stream)
+    host = packed.cpu().numpy()  # the only device->host copy (x1, y1, x2, y2, w, h, score, cls)
     json_list = []
-    row = 0
-    for i, img_id, output in live:
-        n = output.shape[0]
-        d = host[row:row + n]
-        row += n
-        xywh = d[:, 0:4].copy()
-        xywh[:, 2] = d[:, 2] - d[:, 0]
-        xywh[:, 3] = d[:, 3] - d[:, 1]
-        clses = d[:, 5]
-        boxes = xywh.tolist()
-        scores = d[:, 4].tolist()
+    for i, img_id, output, scale, r0 in live:
+        n = int(output.shape[0])
+        d = host[r0:r0 + n]
+        clses = d[:, 7]
+        boxes = d[:, [0, 1, 4, 5]].tolist()
+        scores = d[:, 6].tolist()
         for k in range(n):
             json_list.append({
                 "image_id": img_id,
@@ -101,6 +110,7 @@ def format_outputs(outputs, ids, hws, val_size, class_ids, labels=None):
                 "score": scores[k],
                 "segmentation": [],
             })
+        xyxys = d[:, [0, 1, 2, 3, 6]]
         for c in range(n_cls):
-            det_list[i][c] = d[clses == c, 0:5].copy()
+            det_list[i][c] = xyxys[clses == c].copy()
     return json_list, det_list

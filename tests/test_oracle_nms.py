@@ -1,6 +1,8 @@
 """Known-answer + property tests for oracle/nms.py (torchvision semantics;
 parity unpinned against the reference -- see the module header)."""
 import numpy as np
+import pytest
+import torch
 
 from oracle import nms as onms
 
@@ -123,24 +125,39 @@ def test_format_outputs_hand_case():
     assert outs[2][0, :4].tolist() == [200.0, 100.0, 600.0, 500.0]
 
 
-def test_format_outputs_product_vs_oracle_cpu():
-    """pl_yolo_amd.postprocess.format_outputs (one batched device->host copy) == the box-by-box restatement."""
-    import copy
-    from oracle import formatting as ofmt
+def test_format_outputs_product_refuses_cpu_tensors():
+    """The product formats on the device (plyolo_format_detections); host tensors are refused, not silently handled."""
+    import pl_yolo_amd
     from pl_yolo_amd.postprocess import format_outputs
-    n_cls = 6
-    outs = _rand_dets(3, [17, None, 1, 300, 0], n_cls)
-    outs = [o if o is None or o.shape[0] else None for o in outs]  # postprocess returns None for empty images
-    ids = [11, 12, 13, 14, 15]
-    hws = ([480, 333, 1000, 640, 20], [640, 500, 700, 640, 20])
-    class_ids = [1, 2, 3, 5, 8, 13]
-    a_in, b_in = copy.deepcopy(outs), copy.deepcopy(outs)
-    js_a, det_a = ofmt.format_outputs(a_in, ids, hws, (640, 640), class_ids, None)
-    js_b, det_b = format_outputs(b_in, ids, hws, (640, 640), class_ids, None)
-    assert js_a == js_b
-    for ra, rb in zip(det_a, det_b):
-        for x, y in zip(ra, rb):
-            assert x.dtype == y.dtype and x.shape == y.shape
-            np.testing.assert_array_equal(x, y)
-    for x, y in zip(a_in, b_in):
-        assert (x is None and y is None) or bool((x == y).all())
+    outs = _rand_dets(3, [4], 6)
+    with pytest.raises(pl_yolo_amd.PlyoloError):
+        format_outputs(outs, [1], ([480], [640]), (640, 640), [1, 2, 3, 5, 8, 13], None)
+
+
+# ---- format_outputs: pinned to the reference function (tools/gen_golden.py: gen_format_outputs) ------------------
+def _fmt_fixture():
+    from conftest import load_golden
+    g = load_golden("format_outputs")
+    outs = [torch.from_numpy(g["in%d" % i].copy()) if ("in%d" % i) in g else None for i in range(4)]
+    hws = ([int(v) for v in g["hs"]], [int(v) for v in g["ws"]])
+    return g, outs, [int(v) for v in g["ids"]], hws, tuple(int(v) for v in g["val_size"]), [int(v) for v in g["class_ids"]]
+
+
+def check_format_result(g, outs, json_list, det_list, n_cls):
+    assert [j["image_id"] for j in json_list] == g["json_image_id"].tolist()
+    assert [j["category_id"] for j in json_list] == g["json_category_id"].tolist()
+    np.testing.assert_array_equal(np.asarray([j["bbox"] for j in json_list], dtype=np.float64), g["json_bbox"])
+    np.testing.assert_array_equal(np.asarray([j["score"] for j in json_list], dtype=np.float64), g["json_score"])
+    assert all(j["segmentation"] == [] for j in json_list)
+    for i, o in enumerate(outs):
+        if o is not None:
+            np.testing.assert_array_equal(o.cpu().numpy(), g["after%d" % i])        # rescaled IN PLACE like the reference
+        for c in range(n_cls):
+            np.testing.assert_array_equal(np.asarray(det_list[i][c], dtype=np.float64).reshape(-1, 5), g["det_%d_%d" % (i, c)])
+
+
+def test_format_outputs_vs_reference_fixture():
+    from oracle import formatting as ofmt
+    g, outs, ids, hws, val_size, class_ids = _fmt_fixture()
+    json_list, det_list = ofmt.format_outputs(outs, ids, hws, val_size, class_ids, None)
+    check_format_result(g, outs, json_list, det_list, len(class_ids))

@@ -567,6 +567,48 @@ def gen_network_e():
     save("network_eyolox_test", d)
 
 
+def gen_format_outputs():
+    """`format_outputs` of the reference (models/evaluators/postprocess.py:95-138) on seeded detections.  The module's first
+    line imports torchvision (not installable here), so only the FUNCTION is taken from the reference file: its source is
+    parsed and executed with numpy / torch / the reference's own xyxy2xywh in scope -- the reference's code, no stand-in library."""
+    import ast
+    from models.utils.bbox import xyxy2xywh
+    path = os.path.join(REF, "models", "evaluators", "postprocess.py")
+    tree = ast.parse(open(path).read())
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "format_outputs"][0]
+    scope = {"np": np, "torch": torch, "xyxy2xywh": xyxy2xywh}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), path, "exec"), scope)
+    ref_format = scope["format_outputs"]
+    gen = torch.Generator().manual_seed(77)
+    class_ids = [1, 2, 3, 5, 8, 13, 21]
+    outs, d = [], {}
+    for i, n in enumerate((5, 0, 17, 1)):
+        if n == 0:
+            outs.append(None)
+            continue
+        xy = torch.rand(n, 2, generator=gen) * 300
+        wh = 5 + torch.rand(n, 2, generator=gen) * 200
+        o = torch.cat([xy, xy + wh, torch.rand(n, 1, generator=gen), torch.randint(0, len(class_ids), (n, 1), generator=gen).float()], 1)
+        outs.append(o)
+        d["in%d" % i] = o.clone()
+    ids = [42, 7, 99, 1000]
+    hws = ([480, 375, 427, 640], [640, 500, 640, 480])
+    val_size = (416, 416)
+    d["ids"], d["hs"], d["ws"], d["val_size"], d["class_ids"] = np.asarray(ids), np.asarray(hws[0]), np.asarray(hws[1]), np.asarray(val_size), np.asarray(class_ids)
+    json_list, det_list = ref_format(outs, ids, hws, val_size, class_ids, None)
+    d["json_image_id"] = np.asarray([j["image_id"] for j in json_list])
+    d["json_category_id"] = np.asarray([j["category_id"] for j in json_list])
+    d["json_bbox"] = np.asarray([j["bbox"] for j in json_list], dtype=np.float64)
+    d["json_score"] = np.asarray([j["score"] for j in json_list], dtype=np.float64)
+    for i, o in enumerate(outs):
+        if o is not None:
+            d["after%d" % i] = o.clone()                  # boxes rescaled in place
+        for c in range(len(class_ids)):
+            d["det_%d_%d" % (i, c)] = np.asarray(det_list[i][c], dtype=np.float64).reshape(-1, 5)
+    print("format_outputs fixture: %d records" % len(json_list))
+    save("format_outputs", d)
+
+
 def gen_network_warm():
     """"Warm weights": the toy YOLOX after 50 SGD steps of the REFERENCE on a small fixed data set, then one
     recorded training step at that state (losses, every gradient, head maps).  A trained-for-a-while BatchNorm net
@@ -651,6 +693,9 @@ def gen_cfg1():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "format":
+        gen_format_outputs()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "eyolox":
         gen_network_e()
         sys.exit(0)
@@ -677,6 +722,7 @@ if __name__ == "__main__":
     gen_network()
     gen_network_warm()
     gen_network_e()
+    gen_format_outputs()
     gen_deploy()
     gen_cfg1()
     gen_schedule()
