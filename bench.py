@@ -163,8 +163,18 @@ def nms_bench(device, B=16, n=1000, reps=20, cpu=True):
 
 # plan-profile label -> the __global__ function that launch runs (csrc/*.hip); forward, data-gradient and the
 # stride-2 parity-class jobs are all instances of conv_mfma_kernel / conv_mfma_jobs_kernel
-_KERNEL_OF = {"conv_mfma_fwd": "conv_mfma_kernel", "conv_mfma_dgrad": "conv_mfma_kernel", "conv_mfma_dgrad_s2": "conv_mfma_kernel",
+_KERNEL_OF = {"conv_mfma_fwd": "conv_mfma_kernel", "conv_mfma_dgrad": "conv_mfma_kernel", "conv_mfma_dgrad_s2": "conv_mfma_jobs_kernel",
               "conv_wgrad": "conv_wgrad_kernel", "conv_pw_fwd": "conv_pw_kernel", "conv_pw_dgrad": "conv_pw_kernel"}
+
+
+def lib_md5():
+    """Identity of the HIP library this run loaded (the PMC summaries under profiles/ carry the same field)."""
+    import hashlib
+    try:
+        with open(os.path.join(ROOT, "pl_yolo_amd", "libplyolo_hip.so"), "rb") as f:
+            return hashlib.md5(f.read()).hexdigest()
+    except OSError:
+        return None
 
 
 def kernel_of(label):
@@ -186,9 +196,9 @@ def load_pmc_traffic(args):
         except OSError:
             continue
         kernels = {}
-        for k, v in pm.items():
+        for k, v in pm.items():   # rocpd family names drop the "_kernel" suffix of the __global__ functions
             if isinstance(v, dict) and "read_MB_per_launch" in v:
-                kernels[{"conv_mfma": "conv_mfma_kernel", "conv_wgrad": "conv_wgrad_kernel"}.get(k, k)] = v
+                kernels[k + "_kernel" if k.startswith("conv_") and not k.endswith("_kernel") else k] = v
         return {"kernels": kernels, "source": "profiles/%s_pmc_hbm_traffic.json" % tag, "build": pm.get("build", tag)}
     return None
 
@@ -387,6 +397,7 @@ def main():
                 "replay": "hipgraph" if args.graph else "eager multi-stream (weight-gradient + head-level lanes)",
                 "loss": loss},
             "roofline": roof,
+            "lib_md5": lib_md5(),
         }
         try:
             result["nms"] = nms_bench(dev, cpu=(world == 1 and not args.no_cpu_baseline))

@@ -248,10 +248,11 @@ int plyolo_bicubic2x_bwd(int dtype, int N, int H, int W, int C, const void* dout
 typedef struct plyolo_aug_image {
   const unsigned char* src;   /* device pointer, [h][w][3] uint8 */
   int h, w;
-  float r;                    /* min(out_h / h, out_w / w), computed by the host like preproc (data_augments.py:93) */
+  int dh, dw;                 /* resized extent int(h * r), int(w * r) with r = min(out_h / h, out_w / w), computed by the
+                               * host in float64 exactly like preproc (data_augments.py:93-97) */
   int flip;                   /* mirror horizontally (data_augments.py:129-133) */
   int hsv;                    /* apply the HSV jitter with the three gains below (data_augments.py:113-127) */
-  float hgain, sgain, vgain;  /* r = uniform(-1, 1, 3) * [0.015, 0.7, 0.4] + 1 */
+  double hgain, sgain, vgain; /* r = uniform(-1, 1, 3) * [0.015, 0.7, 0.4] + 1  (float64, as numpy draws them) */
 } plyolo_aug_image;
 int plyolo_preproc_batch(const plyolo_aug_image* imgs_dev, int B, int out_h, int out_w, float* out, void* stream);
 

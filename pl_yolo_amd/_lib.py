@@ -100,8 +100,8 @@ class NmsDesc(C.Structure):
 
 
 class AugImage(C.Structure):   # plyolo_aug_image
-    _fields_ = [("src", C.c_void_p), ("h", C.c_int), ("w", C.c_int), ("r", C.c_float), ("flip", C.c_int), ("hsv", C.c_int),
-                ("hgain", C.c_float), ("sgain", C.c_float), ("vgain", C.c_float)]
+    _fields_ = [("src", C.c_void_p), ("h", C.c_int), ("w", C.c_int), ("dh", C.c_int), ("dw", C.c_int), ("flip", C.c_int), ("hsv", C.c_int),
+                ("hgain", C.c_double), ("sgain", C.c_double), ("vgain", C.c_double)]
 
 
 class FmtImage(C.Structure):   # plyolo_fmt_image

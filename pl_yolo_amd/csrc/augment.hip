@@ -41,6 +41,7 @@ DEVINL int sat_u8(float v) {   // saturate_cast<uchar>(float): cvRound then clam
 }
 // cv2 HSV2BGR (8-bit)
 DEVINL void hsv2bgr(int H, int S, int V, int* b, int* g, int* r) {
+#pragma clang fp contract(off)   // OpenCV (and the numpy oracle) round every product: no fused multiply-add here
   float h = (float)H, s = S * (1.f / 255.f), v = V * (1.f / 255.f);
   float fb, fg, fr;
   if (s == 0.f) {
@@ -69,7 +70,7 @@ DEVINL int lut_clip(int x, double rr) { double t = (double)x * rr; t = t < 0.0 ?
 DEVINL void jitter(const plyolo_aug_image& im, int* b, int* g, int* r) {
   int h, s, v;
   bgr2hsv(*b, *g, *r, &h, &s, &v);
-  hsv2bgr(lut_hue(h, (double)im.hgain), lut_clip(s, (double)im.sgain), lut_clip(v, (double)im.vgain), b, g, r);
+  hsv2bgr(lut_hue(h, im.hgain), lut_clip(s, im.sgain), lut_clip(v, im.vgain), b, g, r);
 }
 
 // source pixel (after the optional colour jitter and mirror), channel c of BGR
@@ -84,12 +85,13 @@ DEVINL void src_px(const plyolo_aug_image& im, int y, int x, int* bgr) {
 __global__ void k_preproc(const plyolo_aug_image* imgs, int B, int OH, int OW, float* out) {
   const int b = blockIdx.y;
   const plyolo_aug_image im = imgs[b];
-  const int dw = (int)(im.w * im.r), dh = (int)(im.h * im.r);   // int(img.shape[1] * r), int(img.shape[0] * r)
+  const int dw = im.dw, dh = im.dh;   // int(img.shape[1] * r), int(img.shape[0] * r), computed by the host in float64
   const double sx_scale = (double)im.w / dw, sy_scale = (double)im.h / dh;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < OH * OW; idx += gridDim.x * blockDim.x) {
     const int oy = idx / OW, ox = idx - oy * OW;
     float v[3] = {114.f, 114.f, 114.f};
     if (oy < dh && ox < dw) {
+#pragma clang fp contract(off)
       float fx = (float)((ox + 0.5) * sx_scale - 0.5), fy = (float)((oy + 0.5) * sy_scale - 0.5);
       int x0 = (int)floorf(fx), y0 = (int)floorf(fy);
       fx -= x0; fy -= y0;

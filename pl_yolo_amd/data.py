@@ -43,7 +43,9 @@ def preproc_batch(images, input_size, flips=None, gains=None):
         r = min(input_size[0] / h, input_size[1] / w)
         ratios.append(r)
         a = arr[i]
-        a.src, a.h, a.w, a.r = im.data_ptr(), h, w, r
+        a.src, a.h, a.w, a.dh, a.dw = im.data_ptr(), h, w, int(h * r), int(w * r)
+        if a.dh < 1 or a.dw < 1:
+            raise PlyoloError("image %dx%d vanishes at input size %s" % (h, w, tuple(input_size)))
         a.flip = int(bool(flips[i])) if flips is not None else 0
         g = gains[i] if gains is not None else None
         a.hsv = int(g is not None)

@@ -25,6 +25,14 @@ cd "$R"
 python tools/rocpd_mfma_busy.py "$(db_of "$O/${tag}_pmc_mfma")" "$O/${tag}_mfma_busy.json" | head -4
 python tools/rocpd_stats.py "$(db_of "$O/${tag}_trace")" --csv "$O/${tag}_kstats.csv" | tail -3
 python tools/rocpd_pmc.py "$(db_of "$O/${tag}_pmc_fetch")" "$(db_of "$O/${tag}_pmc_write")" "$O/${tag}_pmc.json" | tail -3
+# stamp the summary with the identity of the library it was measured on (bench.py prints the same lib_md5)
+python - "$O/${tag}_pmc.json" "$tag" <<'PY'
+import hashlib, json, sys
+p, tag = sys.argv[1], sys.argv[2]
+d = json.load(open(p))
+d["build"] = {"tag": tag, "lib_md5": hashlib.md5(open("pl_yolo_amd/libplyolo_hip.so", "rb").read()).hexdigest()}
+json.dump(d, open(p, "w"), indent=1)
+PY
 rm -rf "$O/${tag}_trace" "$O/${tag}_pmc_fetch" "$O/${tag}_pmc_write" "$O/${tag}_pmc_mfma"
 python bench.py --profile-out "$O/${tag}_plan_profile.json" > "$O/${tag}_bench.json" 2> "$O/${tag}_bench.err"
 tail -1 "$O/${tag}_bench.json" | cut -c1-400
