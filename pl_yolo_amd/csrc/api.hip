@@ -86,7 +86,7 @@ static int check_conv(const plyolo_conv_desc* d, const char* who, bool fwd) {
     PLY_CHECK_ARG((double)d->N * d->H * d->W < 2147483000.0, "%s: more than 2^31 pixels", who);
   }
   if (d->x_coef != nullptr) {
-    PLY_CHECK_ARG(d->x_coef_ld >= d->Cin && d->x_act >= 0 && d->x_act <= PLYOLO_ACT_GELU, "%s: lazy input needs x_coef_ld >= Cin and a valid x_act", who);
+    PLY_CHECK_ARG(d->x_coef_ld >= d->Cin && d->x_act >= 0 && d->x_act <= PLYOLO_ACT_LRELU, "%s: lazy input needs x_coef_ld >= Cin and a valid x_act", who);
     PLY_CHECK_ARG(d->dtype != PLYOLO_BF16 || is_pointwise(d) || lazy_3x3_ok(d), "%s: lazy input is not available for this bf16 convolution shape", who);
   }
   return 0;
@@ -382,6 +382,7 @@ int plyolo_conv2d_fwd_bn_act(const plyolo_conv_desc* d, const void* x, const voi
                              const void* res, int r_ld, void* y, void* stream) {
   if (check_conv(d, "conv2d_fwd_bn_act", true)) return -1;
   PLY_CHECK_ARG(d->dtype == PLYOLO_BF16 && !d->y_f32 && coef != nullptr, "conv2d_fwd_bn_act: bf16 activations and a coefficient vector required");
+  PLY_CHECK_ARG(act >= PLYOLO_ACT_NONE && act <= PLYOLO_ACT_LRELU, "conv2d_fwd_bn_act: the fused epilogue covers none / silu / relu / lrelu (got %d); use plyolo_bn_act_fwd", act);
   PLY_CHECK_ARG(!res || r_ld % 8 == 0, "conv2d_fwd_bn_act: residual pitch must be a multiple of 8");
   if (is_pointwise(d)) return conv_pw_fwd(d, x, wp, nullptr, y, nullptr, coef, act, res, r_ld, stream);
   return conv_mfma_fwd(d, x, wp, nullptr, y, nullptr, coef, act, res, r_ld, stream);

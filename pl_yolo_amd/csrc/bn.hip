@@ -106,11 +106,15 @@ struct ColMap {
   }
 };
 
-template <typename T, bool FUSED>
-__global__ __launch_bounds__(256) void bn_act_fwd_kernel(int M, int C, const T* __restrict__ z, int z_ld, float* coef, int act,
+// ACTC: the activation as a compile-time constant (SiLU, the one every shipped config uses) or -1 = the runtime `act`.
+// The runtime switch makes the compiler budget registers for its heaviest branch (GELU: erff + expf) in EVERY launch:
+// with hswish / gelu added, bn_act_bwd_dz went from 79 to 85 VGPRs and lost a wave per SIMD until SiLU got its own instance.
+template <typename T, bool FUSED, int ACTC = -1>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(int M, int C, const T* __restrict__ z, int z_ld, float* coef, int act_rt,
                                                          const T* __restrict__ res, int r_ld, T* __restrict__ out, int o_ld,
                                                          plyolo_bn_stats st, plyolo_split sp) {
   constexpr int V = Vec<T>::N;
+  const int act = ACTC >= 0 ? ACTC : act_rt;
   __shared__ float s_co[FUSED ? 2 * BN_MAXC : 2];
   if (FUSED) {
     for (int c = threadIdx.x; c < C; c += 256) bn_coef(st, C, c, blockIdx.x == 0, coef, &s_co[c], &s_co[C + c]);
@@ -148,11 +152,12 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(int M, int C, const T* 
 }
 
 // bslots[slot][0][c] += sum du ; bslots[slot][1][c] += sum du * zhat ; one add per block and channel
-template <typename T>
+template <typename T, int ACTC = -1>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(int M, int C, const T* __restrict__ dout, int d_ld, const T* __restrict__ z,
-                                                                int z_ld, const float* __restrict__ coef, int act, double* bslots,
+                                                                int z_ld, const float* __restrict__ coef, int act_rt, double* bslots,
                                                                 plyolo_split sp) {
   constexpr int V = Vec<T>::N;
+  const int act = ACTC >= 0 ? ACTC : act_rt;
   __shared__ float red[256 * 2 * V];
   const int cvn = C / V;
   const ColMap cm(cvn);
@@ -215,13 +220,14 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(int M, int C, co
   }
 }
 
-template <typename T>
+template <typename T, int ACTC = -1>
 __global__ __launch_bounds__(256) void bn_act_bwd_dz_kernel(int M, int C, const T* __restrict__ dout, int d_ld, const T* __restrict__ z,
                                                             int z_ld, const float* __restrict__ coef, const double* __restrict__ bslots,
                                                             double count, const float* gamma, float* dgamma, float* dbeta,
-                                                            int accumulate, int act, T* __restrict__ dz, int dz_ld, plyolo_split sp,
+                                                            int accumulate, int act_rt, T* __restrict__ dz, int dz_ld, plyolo_split sp,
                                                             plyolo_bn_bwd_split p2) {
   constexpr int V = Vec<T>::N;
+  const int act = ACTC >= 0 ? ACTC : act_rt;
   __shared__ float s_b[3 * BN_MAXC];
   // dz = A*du + B*z + Cc with A = gamma*invstd, B = -A*invstd*mean(du*zhat), Cc = -A*mean(du) - B*mean
   for (int c = threadIdx.x; c < C; c += 256) {
@@ -508,12 +514,9 @@ int plyolo_bn_act_fwd(int dtype, int M, int C, const void* z, int z_ld, float* c
   plyolo::annotate("bn_act_fwd", 0.0, (double)M * C * (dtype == PLYOLO_BF16 ? 2.0 : 4.0) * (res ? 3.0 : 2.0));
   return submit(stream, [=](hipStream_t s) -> hipError_t {
     DISPATCH_T(dtype, {
-      if (fused)
-        hipLaunchKernelGGL((bn_act_fwd_kernel<T, true>), dim3(grid), dim3(256), 0, s, M, C, (const T*)z, z_ld, coef, act, (const T*)res,
-                           r_ld, (T*)out, o_ld, st, sp);
-      else
-        hipLaunchKernelGGL((bn_act_fwd_kernel<T, false>), dim3(grid), dim3(256), 0, s, M, C, (const T*)z, z_ld, coef, act, (const T*)res,
-                           r_ld, (T*)out, o_ld, st, sp);
+      auto kern = fused ? (act == PLYOLO_ACT_SILU ? bn_act_fwd_kernel<T, true, PLYOLO_ACT_SILU> : bn_act_fwd_kernel<T, true, -1>)
+                        : (act == PLYOLO_ACT_SILU ? bn_act_fwd_kernel<T, false, PLYOLO_ACT_SILU> : bn_act_fwd_kernel<T, false, -1>);
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, M, C, (const T*)z, z_ld, coef, act, (const T*)res, r_ld, (T*)out, o_ld, st, sp);
     })
     return hipGetLastError();
   });
@@ -559,8 +562,10 @@ int plyolo_bn_act_bwd_reduce(int dtype, int M, int C, const void* dout, int d_ld
   if (rows > 1024) rows = 1024;
   plyolo::annotate("bn_act_bwd_reduce", 0.0, (double)M * C * (dtype == PLYOLO_BF16 ? 2.0 : 4.0) * 2.0);
   return submit(stream, [=](hipStream_t s) -> hipError_t {
-    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<T>, dim3(rows), dim3(256), 0, s, M, C, (const T*)dout, d_ld,
-                                         (const T*)z, z_ld, coef, act, bslots, sp);)
+    DISPATCH_T(dtype, {
+      auto kern = act == PLYOLO_ACT_SILU ? bn_act_bwd_reduce_kernel<T, PLYOLO_ACT_SILU> : bn_act_bwd_reduce_kernel<T, -1>;
+      hipLaunchKernelGGL(kern, dim3(rows), dim3(256), 0, s, M, C, (const T*)dout, d_ld, (const T*)z, z_ld, coef, act, bslots, sp);
+    })
     return hipGetLastError();
   });
 }
@@ -580,8 +585,11 @@ int plyolo_bn_act_bwd_dz(int dtype, int M, int C, const void* dout, int d_ld, co
   const double count = (double)M;
   plyolo::annotate("bn_act_bwd_dz", 0.0, (double)M * C * (dtype == PLYOLO_BF16 ? 2.0 : 4.0) * 3.0);
   return submit(stream, [=](hipStream_t s) -> hipError_t {
-    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_bwd_dz_kernel<T>, dim3(grid), dim3(256), 0, s, M, C, (const T*)dout, d_ld, (const T*)z,
-                                         z_ld, coef, bslots, count, gamma, dgamma, dbeta, accumulate, act, (T*)dz, dz_ld, sp, p2);)
+    DISPATCH_T(dtype, {
+      auto kern = act == PLYOLO_ACT_SILU ? bn_act_bwd_dz_kernel<T, PLYOLO_ACT_SILU> : bn_act_bwd_dz_kernel<T, -1>;
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, M, C, (const T*)dout, d_ld, (const T*)z, z_ld, coef, bslots, count, gamma, dgamma,
+                         dbeta, accumulate, act, (T*)dz, dz_ld, sp, p2);
+    })
     return hipGetLastError();
   });
 }

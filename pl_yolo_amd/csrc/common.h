@@ -37,6 +37,19 @@ template <> struct ActT<float> {
   static DEVINL void st(float* p, float v) { *p = v; }
 };
 
+// The three cheap activations, for code that is inlined into the MFMA kernels (fused inference epilogue, lazy-input loaders).
+// hswish / gelu stay out of those: the epilogue applies the activation to 64-128 accumulators per thread, fully unrolled, and
+// the erff expansion of GELU in every one of them made the conv kernels 6-14 % slower even for launches that never take the
+// branch (instruction footprint; measured against the round-1 build on one box).  Units with those activations use the
+// BatchNorm-apply stream (bn_act_fwd) instead.
+DEVINL float act_fwd_core(float u, int act) {
+  switch (act) {
+    case PLYOLO_ACT_SILU: return u * __builtin_amdgcn_rcpf(1.0f + __expf(-u));
+    case PLYOLO_ACT_RELU: return u > 0.f ? u : 0.f;
+    case PLYOLO_ACT_LRELU: return u > 0.f ? u : 0.1f * u;
+    default: return u;
+  }
+}
 DEVINL float act_fwd(float u, int act) {
   switch (act) {
     case PLYOLO_ACT_SILU: return u * __builtin_amdgcn_rcpf(1.0f + __expf(-u));  // hardware exp2 / rcp (1 ulp): bf16 storage path

@@ -43,6 +43,7 @@ struct PwP {
   int nmt, nnblk;        // pixel tiles, BN blocks
   int accumulate;
   int pf;                // 1: requests of chunk i+1 before the MFMAs of chunk i (PLYOLO_PW_PF, A/B switch)
+  int pipe;              // 1: the software-pipelined chunk loop, 0: the plain one (PLYOLO_PW_LOOP, A/B switch)
 };
 
 DEVINL u32x4 pw_add_bf16x8(u32x4 a, u32x4 b) {
@@ -58,7 +59,7 @@ DEVINL u32x4 pw_add_bf16x8(u32x4 a, u32x4 b) {
 
 constexpr int PW_BM = 128;
 
-template <int BN, int KC, bool OUT_F32, bool PRE>
+template <int BN, int KC, bool OUT_F32, bool PRE, bool PIPE>
 __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwP p) {
   constexpr int BM = PW_BM;
   constexpr int WN = BN / 32, WM = 4 / WN, MT = BM / (32 * WM);
@@ -100,6 +101,66 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwP p) {
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) arow[mt] = ((wm * MT + mt) * 32 + r) * ROWB + h * 16;
 
+  if constexpr (!PIPE) {
+  // plain loop: weights first (L2-resident, tiny), then the pixel rows of the chunk, all requested at the top of the iteration
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    const int c0 = chunk * KC;
+    u32x4 bq[KS];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      const int kb = chunk * KS + kk;
+      bq[kk] = *(const u32x4*)(wbase + (size_t)(kb < p.nkb ? kb : p.nkb - 1) * 1024u);
+    }
+    const int c = c0 + cvt * 8;
+    const bool cok = c < p.K;
+    u32x4 av[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int m = m0 + row0 + v * RPP;
+      const bool ok = cok && m < p.M;
+      av[v] = *(const u32x4*)(p.x + (ok ? (size_t)m * p.x_ld + c : 0));
+    }
+    if (chunk) __syncthreads();   // every wave is done with the previous chunk's rows
+    if constexpr (PRE) {
+      float sc[8], sh[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        sc[i] = cok ? p.pre[c + i] : 0.f;
+        sh[i] = cok ? p.pre[p.pre_ld + c + i] : 0.f;
+      }
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        u32x4 t = av[v];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float lo = act_fwd_core(fmaf(__uint_as_float(t[i] << 16), sc[2 * i], sh[2 * i]), p.pre_act);
+          const float hi = act_fwd_core(fmaf(__uint_as_float(t[i] & 0xffff0000u), sc[2 * i + 1], sh[2 * i + 1]), p.pre_act);
+          t[i] = pack2bf(lo, hi);
+        }
+        av[v] = t;
+      }
+    }
+    {
+      const u32x4 zero = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int row = row0 + v * RPP;
+        const bool ok = cok && (m0 + row) < p.M;
+        *(u32x4*)(smem + row * ROWB + cvt * 16) = ok ? av[v] : zero;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      const bf16x8 b = *(const bf16x8*)&bq[kk];
+      bf16x8 a[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) a[mt] = *(const bf16x8*)(smem + arow[mt] + kk * 32);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b, acc[mt], 0, 0, 0);
+    }
+  }
+  } else {
   // one chunk = KC channels of the tile's 128 rows.  Requests of chunk i+1 (weights first -- L2-resident, tiny -- then the
   // pixel rows) are issued BEFORE the MFMAs of chunk i, so a memory round trip is only exposed for the first chunk
   u32x4 bq[KS], av[NV];
@@ -136,8 +197,8 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwP p) {
         u32x4 t = av[v];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float lo = act_fwd(fmaf(__uint_as_float(t[i] << 16), sc[2 * i], sh[2 * i]), p.pre_act);
-          const float hi = act_fwd(fmaf(__uint_as_float(t[i] & 0xffff0000u), sc[2 * i + 1], sh[2 * i + 1]), p.pre_act);
+          const float lo = act_fwd_core(fmaf(__uint_as_float(t[i] << 16), sc[2 * i], sh[2 * i]), p.pre_act);
+          const float hi = act_fwd_core(fmaf(__uint_as_float(t[i] & 0xffff0000u), sc[2 * i + 1], sh[2 * i + 1]), p.pre_act);
           t[i] = pack2bf(lo, hi);
         }
         av[v] = t;
@@ -169,6 +230,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwP p) {
     }
     __builtin_amdgcn_sched_barrier(0);
     if (!p.pf && chunk + 1 < nchunks) request(chunk + 1);
+  }
   }
   __syncthreads();  // all LDS operand reads retired; LDS is reused for the epilogue
 
@@ -219,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwP p) {
       if (OUT_F32)
         *(float*)(smem + m * SROW + col * 4) = acc[mt][i];
       else
-        *(bf16_t*)(smem + m * SROW + col * 2) = f2bf(fused ? act_fwd(fmaf(acc[mt][i], ep_sc, ep_sh), p.ep_act) : acc[mt][i]);
+        *(bf16_t*)(smem + m * SROW + col * 2) = f2bf(fused ? act_fwd_core(fmaf(acc[mt][i], ep_sc, ep_sh), p.ep_act) : acc[mt][i]);
     }
   __syncthreads();
 
@@ -289,7 +351,7 @@ hipError_t pw_launch_inst(const PwP& p, hipStream_t s) {
   const size_t lds_main = (size_t)PW_BM * ROWB;
   const size_t lds_epi = (size_t)PW_BM * SROW + WM * 2 * BN * 4;
   const size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
-  auto kern = conv_pw_kernel<BN, KC, OUT_F32, PRE>;
+  auto kern = p.pipe ? conv_pw_kernel<BN, KC, OUT_F32, PRE, true> : conv_pw_kernel<BN, KC, OUT_F32, PRE, false>;
   if (hipError_t e = plyolo::ensure_dynamic_lds((const void*)kern, lds); e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(p.nmt * p.nnblk), dim3(256), lds, s, p);
   return hipGetLastError();
@@ -319,6 +381,8 @@ void pw_tiles(PwP& p, bool out_f32, int* BN, int* KC) {
   *KC = kc;
   static const int pf = getenv("PLYOLO_PW_PF") ? atoi(getenv("PLYOLO_PW_PF")) : 0;   // measured: requests ahead of the MFMAs make the pointwise launches 2.5 % faster alone and the step 0.8 % slower
   p.pf = pf;
+  static const int pipe = getenv("PLYOLO_PW_LOOP") ? atoi(getenv("PLYOLO_PW_LOOP")) : 0;
+  p.pipe = pipe;
   p.nmt = (p.M + PW_BM - 1) / PW_BM;
   p.nnblk = (p.N + bn - 1) / bn;
 }

@@ -156,8 +156,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
           if (hmask & (1u << v)) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              const float lo = act_fwd(fmaf(__uint_as_float(t[i] << 16), psc[2 * i], psh[2 * i]), p.pre_act);
-              const float hi = act_fwd(fmaf(__uint_as_float(t[i] & 0xffff0000u), psc[2 * i + 1], psh[2 * i + 1]), p.pre_act);
+              const float lo = act_fwd_core(fmaf(__uint_as_float(t[i] << 16), psc[2 * i], psh[2 * i]), p.pre_act);
+              const float hi = act_fwd_core(fmaf(__uint_as_float(t[i] & 0xffff0000u), psc[2 * i + 1], psh[2 * i + 1]), p.pre_act);
               t[i] = pack2bf(lo, hi);
             }
           }

@@ -173,7 +173,6 @@ constexpr int NMS_LDS_N = 1024;   // images with at most this many candidates ru
 __global__ __launch_bounds__(64) void k_mask(NmsWs w, float thr, int class_agnostic, int numel_threshold) {
   const int b = blockIdx.y;
   const int n = w.ncand[b];
-  if (n <= NMS_LDS_N) return;
   const int nb = (n + 63) / 64;
   const bool vanilla = !class_agnostic && (4 * n > numel_threshold);
   __shared__ float cb_box[64][4];
@@ -237,46 +236,23 @@ __global__ __launch_bounds__(64) void k_scan(NmsWs w, int max_det, float* det, i
   if (lane == 0) count[b] = kept;
 }
 
-// Suppression mask AND greedy scan of one image in ONE workgroup, the whole [n][n/64] bit matrix in LDS (n <= 1024: 128 KB).
+// Greedy scan of one image with its whole suppression matrix ([n][n/64] words, n <= 1024: 128 KB) staged in LDS.
 // The global-memory scan above walks the boxes one by one and pays a dependent L2 round trip (~0.5 us) for every KEPT
-// box -- 138 us for 1000 boxes / 300 kept, 73 % of the batch.  Here a block of 64 candidates is resolved with register
-// shuffles only (its diagonal word per lane), and the rows of its survivors are OR-ed into the removed-set of the later
-// blocks from LDS, lanes across the words.  Same greedy order, same results.
-__global__ __launch_bounds__(1024) void k_nms_lds(NmsWs w, float thr, int class_agnostic, int numel_threshold, int max_det, float* det,
-                                                  int* count) {
+// box -- 138 us for 1000 boxes / 300 kept, 73 % of the batch.  Here the matrix k_mask wrote is copied into LDS once
+// (coalesced), a block of 64 candidates is resolved with register shuffles only (its diagonal word per lane), and the
+// rows of its survivors are OR-ed into the removed-set of the later blocks from LDS, lanes across the words.  Same
+// greedy order, same results.  (Computing the mask itself here, on one CU per image, measured 2x SLOWER than the
+// chip-wide k_mask: 1 M IoU evaluations per image are ~160 us of VALU time for a single CU.)
+__global__ __launch_bounds__(1024) void k_nms_lds(NmsWs w, int max_det, float* det, int* count) {
   const int b = blockIdx.x, tid = threadIdx.x;
   const int n = w.ncand[b];
   if (n > NMS_LDS_N) return;
   const int nb = (n + 63) / 64;
   extern __shared__ __align__(16) unsigned char nms_smem[];
   unsigned long long* smask = (unsigned long long*)nms_smem;              // [n][nb]
-  f32x4* sbox = (f32x4*)(nms_smem + (size_t)NMS_LDS_N * (NMS_LDS_N / 64) * 8);   // [1024]
-  float* scls = (float*)(sbox + NMS_LDS_N);
-  const bool vanilla = !class_agnostic && (4 * n > numel_threshold);
-  if (tid < n) {
-    sbox[tid] = *(const f32x4*)(w.nbox + ((size_t)b * w.cap + tid) * 4);
-    scls[tid] = w.sdet[((size_t)b * w.cap + tid) * 6 + 5];
-  }
-  __syncthreads();
   for (int id = tid; id < n * nb; id += 1024) {
     const int i = id / nb, cb = id - i * nb;
-    if (cb < (i >> 6)) continue;               // below the diagonal block: never read
-    const f32x4 me = sbox[i];
-    const float my_cls = scls[i], my_area = (me[2] - me[0]) * (me[3] - me[1]);
-    const int j0 = cb * 64, jn = min(64, n - j0);
-    unsigned long long bits = 0ull;
-    for (int j = (cb == (i >> 6) ? (i & 63) + 1 : 0); j < jn; ++j) {
-      const f32x4 o = sbox[j0 + j];
-      const float xx1 = fmaxf(me[0], o[0]), yy1 = fmaxf(me[1], o[1]);
-      const float xx2 = fminf(me[2], o[2]), yy2 = fminf(me[3], o[3]);
-      const float iw = fmaxf(0.0f, xx2 - xx1), ih = fmaxf(0.0f, yy2 - yy1);
-      const float inter = iw * ih;
-      const float area_j = (o[2] - o[0]) * (o[3] - o[1]);
-      const float ovr = inter / (my_area + area_j - inter);
-      const bool same = !vanilla || (scls[j0 + j] == my_cls);
-      if (same && ovr > thr) bits |= 1ull << j;
-    }
-    smask[(size_t)i * nb + cb] = bits;
+    smask[id] = cb >= (i >> 6) ? w.mask[((size_t)b * w.cap + i) * w.words + cb] : 0ull;   // words below the diagonal block were never written
   }
   __syncthreads();
   if (tid >= 64) return;
@@ -336,13 +312,11 @@ int next_pow2(int v) {
 
 hipError_t run_nms_tail(const plyolo_nms_desc& d, const NmsWs& w, float* det, int32_t* count, hipStream_t s) {
   // every image takes exactly one of the two paths (decided on the device from its candidate count)
-  const size_t lds = (size_t)NMS_LDS_N * (NMS_LDS_N / 64) * 8 + (size_t)NMS_LDS_N * 20;
+  const size_t lds = (size_t)NMS_LDS_N * (NMS_LDS_N / 64) * 8;
   if (hipError_t e = plyolo::ensure_dynamic_lds((const void*)k_nms_lds, lds); e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_nms_lds, dim3(d.B), dim3(1024), lds, s, w, d.nms_thre, d.class_agnostic, d.numel_threshold, d.max_det, det, count);
-  if (w.cap > NMS_LDS_N) {
-    hipLaunchKernelGGL(k_mask, dim3(512, d.B), dim3(64), 0, s, w, d.nms_thre, d.class_agnostic, d.numel_threshold);
-    hipLaunchKernelGGL(k_scan, dim3(d.B), dim3(64), 0, s, w, d.max_det, det, count);
-  }
+  hipLaunchKernelGGL(k_mask, dim3(512, d.B), dim3(64), 0, s, w, d.nms_thre, d.class_agnostic, d.numel_threshold);
+  hipLaunchKernelGGL(k_nms_lds, dim3(d.B), dim3(1024), lds, s, w, d.max_det, det, count);
+  if (w.cap > NMS_LDS_N) hipLaunchKernelGGL(k_scan, dim3(d.B), dim3(64), 0, s, w, d.max_det, det, count);
   return hipGetLastError();
 }
 

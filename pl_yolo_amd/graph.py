@@ -565,7 +565,7 @@ class ConvUnitOp:
     def lazy_outputs(self):
         """[(activation view, channel offset inside z)] that may stay lazy: a residual is added by bn_act_fwd, so a unit
         with a shortcut always writes its output."""
-        return [(self.out, 0)] if (self.bn is not None and self.res is None and self.g.training) else []
+        return [(self.out, 0)] if (self.bn is not None and self.res is None and self.g.training and self.act <= ACT["lrelu"]) else []
 
     def _alloc_small(self):
         g = self.g
@@ -585,7 +585,7 @@ class ConvUnitOp:
         self._alloc_small()
         zt = self.z.tensor
         train_stats = g.training and bn is not None
-        if (not g.training) and (bn is not None or self.conv_b is not None) and g.dtype == BF16 and g.fuse_eval:
+        if (not g.training) and (bn is not None or self.conv_b is not None) and g.dtype == BF16 and g.fuse_eval and self.act <= ACT["lrelu"]:
             # inference: BatchNorm is a fixed affine -> applied with the activation in the conv epilogue; the
             # activated tensor is written straight into its (possibly concat-slice) destination.  The deploy form
             # (BatchNorm already folded into weights + bias) is the same epilogue with scale 1, shift = bias
@@ -700,7 +700,7 @@ class ConvPairOp:
 
     def lazy_outputs(self):
         """Both halves or none (one bn_act launch writes both)."""
-        return [(self.out_a, 0), (self.out_b, self.Ca)] if self.g.training else []
+        return [(self.out_a, 0), (self.out_b, self.Ca)] if (self.g.training and self.act <= ACT["lrelu"]) else []
 
     def _split(self, base_ptr_fn, act_b):
         sp = Split()
