@@ -34,7 +34,10 @@ struct WgP {
   int tiles_y, tiles_x, ntiles;
   const float* pre;  // lazy input (plyolo_conv_desc::x_coef): X tiles are staged as act(x * pre[c] + pre[pre_ld + c]), padding stays zero
   int pre_ld, pre_act;
-  int nci;  // number of ci tiles (blockIdx.y = co_tile * nci + ci_tile)
+  int nci;  // number of ci tiles
+  int nslabt;  // slab tiles per spatial split = nco * nci
+  int S;       // spatial splits; the grid is 1-D: S * nslabt workgroups
+  int xcd;     // 1: slab tiles of one split adjacent in an XCD-contiguous order (PLYOLO_WG_XCD, default), 0: the round-1 order
   int ablate;  // diagnostics (PLYOLO_ABLATE_WG): 1 skip atomics, 2 skip tile loads after the first, 4 skip MFMA, 8 force S
 };
 
@@ -62,7 +65,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wk = wave / (WCO * WCI), wco = (wave / WCI) % WCO, wci = wave % WCI;
   const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
-  const int co_tile = blockIdx.y / p.nci, ci_tile = blockIdx.y % p.nci;
+  // Workgroup -> (spatial split, slab tile).  The nco*nci workgroups of one split read the SAME pixel tiles (each its own
+  // channel slice of dY and X); in the round-1 launch (grid (S, nco*nci)) they were dispatched far apart and every operand tile
+  // came from HBM once per slab column -- 84 MB read per launch against 61 MB algorithmic.  Here they are neighbours in an order
+  // that gives each XCD a contiguous run of workgroups (blocks with equal id % 8 share an XCD), so the second .. fourth reader of
+  // a tile finds it in that XCD's L2.
+  int wg = (int)blockIdx.x;
+  if (p.xcd) {
+    const int nwg = (int)gridDim.x, q = nwg >> 3, r8 = nwg & 7, x = wg & 7;
+    wg = (x < r8 ? x * (q + 1) : r8 * (q + 1) + (x - r8) * q) + (wg >> 3);
+  }
+  const int split = p.xcd ? wg / p.nslabt : wg % p.S, slab_tile = p.xcd ? wg % p.nslabt : wg / p.S;
+  const int co_tile = slab_tile / p.nci, ci_tile = slab_tile % p.nci;
   const int co0 = co_tile * CO_T, ci0 = ci_tile * CI_T;
 
   // per-lane tr-read address pieces: pixel column within the 16-wide k-step, channel column
@@ -167,12 +181,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
     }
   };
 
-  if ((int)blockIdx.x < p.ntiles) prefetch(blockIdx.x);
-  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+  if (split < p.ntiles) prefetch(split);
+  for (int tile = split; tile < p.ntiles; tile += p.S) {
     __syncthreads();  // previous tile fully consumed
     commit();
     __syncthreads();
-    if (tile + (int)gridDim.x < p.ntiles && !(p.ablate & 2)) prefetch(tile + gridDim.x);
+    if (tile + p.S < p.ntiles && !(p.ablate & 2)) prefetch(tile + p.S);
     if (!(p.ablate & 4))
 #pragma unroll 2
     for (int j = wk; j < TH_; j += WK) {
@@ -207,7 +221,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
   // stores (D[row = co][col = ci]: col = lane & 31, row = (i&3) + 8*(i>>2) + 4*(lane>>5)); the
   // slabs are summed in a fixed order by plyolo_unpack_wgrads (deterministic, and no fp32
   // atomics: same-address atomics serialise at ~1.6 us each on gfx950).
-  float* slab = p.dw + ((size_t)blockIdx.x * WK + wk) * ((size_t)NTAPS * p.Cout * p.Cin);
+  float* slab = p.dw + ((size_t)split * WK + wk) * ((size_t)NTAPS * p.Cout * p.Cin);
   const int r = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int b = 0; b < MTI; ++b) {
@@ -233,8 +247,12 @@ hipError_t launch_wg(const WgP& p, int S, hipStream_t s) {
   auto kern = p.pre ? conv_wgrad_kernel<CO_T, CI_T, KS, WK, MTC, MTI, TH_, SI, true> : conv_wgrad_kernel<CO_T, CI_T, KS, WK, MTC, MTI, TH_, SI, false>;
   if (hipError_t e = plyolo::ensure_dynamic_lds((const void*)kern, 160 * 1024); e != hipSuccess) return e;
   const int nco = (p.Cout + CO_T - 1) / CO_T;
-  dim3 grid(S, nco * p.nci);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+  WgP q = p;
+  q.nslabt = nco * p.nci;
+  q.S = S;
+  static const int xcd = getenv("PLYOLO_WG_XCD") ? atoi(getenv("PLYOLO_WG_XCD")) : 1;
+  q.xcd = xcd;
+  hipLaunchKernelGGL(kern, dim3(S * q.nslabt), dim3(256), lds, s, q);
   return hipGetLastError();
 }
 
