@@ -51,9 +51,14 @@ constexpr int pitch_for(int ch) { return ch * 2 + ((ch * 2) % 128 == 0 ? 64 : 0)
 
 // CO_T x CI_T: dW slab of the workgroup; MTC x MTI: 32x32 MFMA tiles per wave along co / ci;
 // WK: waves that split the k-steps (tile rows) of one slab (small-channel layers); TH_: tile rows.
-template <int CO_T, int CI_T, int KS, int WK, int MTC, int MTI, int TH_, int SI, bool PRE>
+// TRS: 1 = the workgroup accumulates all KS*KS taps; 3 (KS == 3 only) = one kernel ROW per workgroup -- a third of the
+// accumulator registers (48 instead of 144: 3-4 waves per SIMD instead of one), a halo tile without the two extra rows,
+// three times as many workgroups for the same number of slabs.
+template <int CO_T, int CI_T, int KS, int WK, int MTC, int MTI, int TH_, int SI, bool PRE, int TRS = 1>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
-  constexpr int NTAPS = KS * KS;
+  static_assert(TRS == 1 || (TRS == 3 && KS == 3), "tap-row split: 3x3 only");
+  constexpr int NTAPS = KS * KS / TRS;     // taps accumulated by this workgroup
+  constexpr int KSY = KS / TRS;            // kernel rows covered by this workgroup
   constexpr int WCO = CO_T / (32 * MTC), WCI = CI_T / (32 * MTI);
   static_assert(WCO * WCI * WK == 4, "four waves per workgroup");
   constexpr int DZB = pitch_for(CO_T), XB = pitch_for(CI_T);
@@ -75,7 +80,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
     const int nwg = (int)gridDim.x, q = nwg >> 3, r8 = nwg & 7, x = wg & 7;
     wg = (x < r8 ? x * (q + 1) : r8 * (q + 1) + (x - r8) * q) + (wg >> 3);
   }
-  const int split = p.xcd ? wg / p.nslabt : wg % p.S, slab_tile = p.xcd ? wg % p.nslabt : wg / p.S;
+  const int split = p.xcd ? wg / p.nslabt : wg % p.S, slab_t0 = p.xcd ? wg % p.nslabt : wg / p.S;
+  const int trow = slab_t0 % TRS, slab_tile = slab_t0 / TRS;    // kernel row of this workgroup (TRS == 3)
   const int co_tile = slab_tile / p.nci, ci_tile = slab_tile % p.nci;
   const int co0 = co_tile * CO_T, ci0 = ci_tile * CI_T;
 
@@ -96,7 +102,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
 
   // Software pipeline over the workgroup's tiles: the 16-byte global loads of tile i+1 are issued
   // into registers before the MFMAs of tile i and written to LDS after them.
-  constexpr int ITH_ = (TH_ - 1) * SI + KS, ITW_ = (TW - 1) * SI + KS;
+  constexpr int ITH_ = (TH_ - 1) * SI + KSY, ITW_ = (TW - 1) * SI + KS;
   constexpr int DV = (TH_ * TW * DZV + 255) / 256;
   constexpr int NXV = ITH_ * ITW_ * XV;
   constexpr int HV = (NXV + 255) / 256;
@@ -120,7 +126,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
     const int tyi = t2 % p.tiles_y;
     const int n = t2 / p.tiles_y;
     const int oy0 = tyi * TH_, ox0 = txi * TW;
-    const int iy0 = oy0 * SI - p.pad, ix0 = ox0 * SI - p.pad;
+    const int iy0 = oy0 * SI - p.pad + (TRS == 3 ? trow : 0), ix0 = ox0 * SI - p.pad;
     const bf16_t* dyn = p.dy + (size_t)n * p.OH * p.OW * p.dy_ld;
 #pragma unroll
     for (int v = 0; v < DV; ++v) {
@@ -201,7 +207,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
       }
 #pragma unroll
       for (int t = 0; t < NTAPS; ++t) {
-        const int dy_ = t / KS, dx_ = t % KS;
+        const int dy_ = t / KS, dx_ = t % KS;     // dy_ is relative to the staged halo rows (0 under the tap-row split)
 #pragma unroll
         for (int b = 0; b < MTI; ++b) {
           const unsigned char* bp = x_s + ((j * SI + dy_) * ITW_ + kpix * SI + dx_) * XB + b_col + b * 64;
@@ -221,7 +227,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
   // stores (D[row = co][col = ci]: col = lane & 31, row = (i&3) + 8*(i>>2) + 4*(lane>>5)); the
   // slabs are summed in a fixed order by plyolo_unpack_wgrads (deterministic, and no fp32
   // atomics: same-address atomics serialise at ~1.6 us each on gfx950).
-  float* slab = p.dw + ((size_t)split * WK + wk) * ((size_t)NTAPS * p.Cout * p.Cin);
+  float* slab = p.dw + ((size_t)split * WK + wk) * ((size_t)KS * KS * p.Cout * p.Cin) + (size_t)(TRS == 3 ? trow * KS : 0) * p.Cout * p.Cin;
   const int r = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int b = 0; b < MTI; ++b) {
@@ -240,15 +246,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
   }
 }
 
-template <int CO_T, int CI_T, int KS, int WK, int MTC, int MTI, int TH_, int SI>
+template <int CO_T, int CI_T, int KS, int WK, int MTC, int MTI, int TH_, int SI, int TRS = 1>
 hipError_t launch_wg(const WgP& p, int S, hipStream_t s) {
   constexpr int DZB = pitch_for(CO_T), XB = pitch_for(CI_T);
-  const size_t lds = (size_t)TH_ * TW * DZB + (size_t)((TH_ - 1) * SI + KS) * ((TW - 1) * SI + KS) * XB;
-  auto kern = p.pre ? conv_wgrad_kernel<CO_T, CI_T, KS, WK, MTC, MTI, TH_, SI, true> : conv_wgrad_kernel<CO_T, CI_T, KS, WK, MTC, MTI, TH_, SI, false>;
+  const size_t lds = (size_t)TH_ * TW * DZB + (size_t)((TH_ - 1) * SI + KS / TRS) * ((TW - 1) * SI + KS) * XB;
+  auto kern = p.pre ? conv_wgrad_kernel<CO_T, CI_T, KS, WK, MTC, MTI, TH_, SI, true, TRS> : conv_wgrad_kernel<CO_T, CI_T, KS, WK, MTC, MTI, TH_, SI, false, TRS>;
   if (hipError_t e = plyolo::ensure_dynamic_lds((const void*)kern, 160 * 1024); e != hipSuccess) return e;
   const int nco = (p.Cout + CO_T - 1) / CO_T;
   WgP q = p;
-  q.nslabt = nco * p.nci;
+  q.nslabt = nco * p.nci * TRS;
   q.S = S;
   static const int xcd = getenv("PLYOLO_WG_XCD") ? atoi(getenv("PLYOLO_WG_XCD")) : 1;
   q.xcd = xcd;
@@ -260,7 +266,7 @@ hipError_t launch_wg(const WgP& p, int S, hipStream_t s) {
 
 namespace plyolo {
 
-struct WgPlan { WgP p; int id, S, WK, CO_T, CI_T, th; };
+struct WgPlan { WgP p; int id, S, WK, CO_T, CI_T, th, trs; };
 
 static WgPlan plan_wgrad(const plyolo_conv_desc* d) {
   const int pad = (d->ksize - 1) / 2;
@@ -313,7 +319,12 @@ static WgPlan plan_wgrad(const plyolo_conv_desc* d) {
   const double dw_bytes = 4.0 * d->ksize * d->ksize * (double)d->Cout * d->Cin;
   int target = 768;  // workgroups per launch (3 per CU)
   if (const char* e = getenv("PLYOLO_WG_TARGET")) { const int v = atoi(e); if (v >= 64) target = v; }
-  int S = target / (nco * p.nci * w.WK);
+  // tap-row split for the 64x64 3x3 variant (PLYOLO_WG_TRS=3): three workgroups per slab tile, one kernel row each
+  // Measured (YOLOX-s B=32, same box, 3 alternations): the 64x64 launches 1.53 -> 1.23 ms, all weight-gradient launches
+  // 3.37 -> 3.07 ms, step 10.34 -> 10.25 ms.  PLYOLO_WG_TRS=1 restores one workgroup per slab tile; =13 also splits the 128x32 variant.
+  static const int trs_env = getenv("PLYOLO_WG_TRS") ? atoi(getenv("PLYOLO_WG_TRS")) : 3;
+  w.trs = ((w.id == 0 && trs_env >= 3) || (w.id == 1 && trs_env == 13)) ? 3 : 1;
+  int S = target / (nco * p.nci * w.WK * w.trs);
   if (S * w.WK > 1024) S = 1024 / w.WK;
   double budget = 20.0e6;  // measured on the whole step (8 / 12 / 16 / 20 / 24 / 32 / 64 MB): slab stores + folds compete with the main lane for HBM
   // wide layers (FLOPs per operand byte k*k*Cin*Cout/(Cin+Cout) >= 1300: 320+ channels at 3x3) are MFMA-bound and sit
@@ -343,7 +354,7 @@ int conv_mfma_wgrad(const plyolo_conv_desc* d, const void* x, const void* dy, fl
   p.x = (const bf16_t*)x;
   p.dy = (const bf16_t*)dy;
   p.dw = dwp;
-  const int id = w.id, S = w.S, ks = d->ksize;
+  const int id = w.id, S = w.S, ks = d->ksize, trs = w.trs;
   const bool th16 = w.th == 16;
   {
     char lab[64];
@@ -354,8 +365,10 @@ int conv_mfma_wgrad(const plyolo_conv_desc* d, const void* x, const void* dy, fl
   return submit(stream, [=](hipStream_t s) -> hipError_t {
     const bool s2 = p.si == 2;
     switch (id) {
-      case 0: return launch_wg<64, 64, 3, 1, 1, 1, 8, 1>(p, S, s);
-      case 1: return s2 ? launch_wg<128, 32, 3, 1, 1, 1, 8, 2>(p, S, s) : launch_wg<128, 32, 3, 1, 1, 1, 8, 1>(p, S, s);
+      case 0: return trs == 3 ? launch_wg<64, 64, 3, 1, 1, 1, 8, 1, 3>(p, S, s) : launch_wg<64, 64, 3, 1, 1, 1, 8, 1>(p, S, s);
+      case 1:
+        if (trs == 3) return s2 ? launch_wg<128, 32, 3, 1, 1, 1, 8, 2, 3>(p, S, s) : launch_wg<128, 32, 3, 1, 1, 1, 8, 1, 3>(p, S, s);
+        return s2 ? launch_wg<128, 32, 3, 1, 1, 1, 8, 2>(p, S, s) : launch_wg<128, 32, 3, 1, 1, 1, 8, 1>(p, S, s);
       case 2: return s2 ? launch_wg<64, 32, 3, 2, 1, 1, 8, 2>(p, S, s) : (th16 ? launch_wg<64, 32, 3, 2, 1, 1, 16, 1>(p, S, s) : launch_wg<64, 32, 3, 2, 1, 1, 8, 1>(p, S, s));
       case 3: return s2 ? launch_wg<32, 32, 3, 4, 1, 1, 8, 2>(p, S, s) : (th16 ? launch_wg<32, 32, 3, 4, 1, 1, 16, 1>(p, S, s) : launch_wg<32, 32, 3, 4, 1, 1, 8, 1>(p, S, s));
       case 4: return s2 ? launch_wg<64, 64, 1, 1, 1, 1, 8, 2>(p, S, s) : launch_wg<64, 64, 1, 1, 1, 1, 8, 1>(p, S, s);
