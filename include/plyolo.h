@@ -175,6 +175,17 @@ int plyolo_pack_elems(int dtype, int Cout_total, int Cin_p, int ksize, size_t* w
 /* dwp slab 0 += slabs 1..nslab-1 in a fixed order (elems = floats per slab, multiple of 4): the
  * host may run this right after a wgrad launch and then unpack with nslab = 1. */
 int plyolo_reduce_slabs(float* dwp, int nslab, size_t elems, void* stream);
+/* The same fold for several weight tensors in two launches (all slab groups, then all group heads): per / groups from
+ * plyolo_reduce_slabs_plan, so the summation order -- and the result -- equals plyolo_reduce_slabs' bit for bit. */
+typedef struct plyolo_reduce_job {
+  float* dwp;
+  int nslab, per, groups;
+  size_t elems;
+} plyolo_reduce_job;
+int plyolo_reduce_slabs_plan(int nslab, size_t elems, int* per, int* groups);
+int plyolo_reduce_slabs_multi(const plyolo_reduce_job* jobs_dev, int njobs, int max_cols, int max_groups, double total_bytes,
+                              void* stream);
+
 /* dw (OIHW) (+)= permute(sum of the nslab slabs of dwp) for the whole table. */
 int plyolo_unpack_wgrads(const plyolo_pack_entry* table_dev, int n, int max_elems, int accumulate, void* stream);
 

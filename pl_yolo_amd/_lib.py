@@ -104,6 +104,10 @@ class AugImage(C.Structure):   # plyolo_aug_image
                 ("hgain", C.c_double), ("sgain", C.c_double), ("vgain", C.c_double)]
 
 
+class ReduceJob(C.Structure):   # plyolo_reduce_job
+    _fields_ = [("dwp", C.c_void_p), ("nslab", C.c_int), ("per", C.c_int), ("groups", C.c_int), ("elems", C.c_size_t)]
+
+
 class FmtImage(C.Structure):   # plyolo_fmt_image
     _fields_ = [("det", C.c_void_p), ("n", C.c_int), ("ld", C.c_int), ("row0", C.c_int), ("scale", C.c_float)]
 
@@ -144,6 +148,8 @@ SIGNATURES = {
     "plyolo_bias_grad": (_i, [_i, _vp, _i, _i, _i, _vp, _vp]),
     "plyolo_pack_weights": (_i, [_vp, _i, _i, _i, _vp]),
     "plyolo_reduce_slabs": (_i, [_vp, _i, _sz, _vp]),
+    "plyolo_reduce_slabs_plan": (_i, [_i, _sz, _P(_i), _P(_i)]),
+    "plyolo_reduce_slabs_multi": (_i, [_vp, _i, _i, _i, _d, _vp]),
     "plyolo_pack_elems": (_i, [_i, _i, _i, _i, _P(_sz), _P(_sz)]),
     "plyolo_unpack_wgrads": (_i, [_vp, _i, _i, _i, _vp]),
     "plyolo_bn_finalize": (_i, [_P(BnStats), _i, _vp, _vp]),

@@ -213,6 +213,8 @@ static hipError_t issue_lanes(Plan* q, hipStream_t s, bool lanes, size_t* failed
     return le;
   }
   while ((int)q->side.size() < q->nlanes - 1) {
+    // (stream priorities were tried for the weight-gradient lane -- hipStreamCreateWithPriority, low or high: ANY non-default
+    // priority on one lane doubled the step, 10.5 -> 22 ms on ROCm 7.2; every lane stays at the default priority)
     hipStream_t st;
     hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
     if (e != hipSuccess) return e;

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(int M, int C, const T* 
 }
 
 // bslots[slot][0][c] += sum du ; bslots[slot][1][c] += sum du * zhat ; one add per block and channel
-template <typename T, int ACTC = -1>
+template <typename T, int ACTC = -1, int UNR = 2>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(int M, int C, const T* __restrict__ dout, int d_ld, const T* __restrict__ z,
                                                                 int z_ld, const float* __restrict__ coef, int act_rt, double* bslots,
                                                                 plyolo_split sp) {
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(int M, int C, co
       const bool second = sp.split > 0 && c >= sp.split;
       const T* db = second ? (const T*)sp.p2 + (c - sp.split) : dout + c;
       const int dl = second ? sp.ld2 : d_ld;
-#pragma unroll 2
+#pragma unroll UNR
       for (int m = blockIdx.x * cm.rpb + cm.trow; m < M; m += step) {
         float d[V], zz[V];
         Vec<T>::load(db + (size_t)m * dl, d);
@@ -559,11 +559,15 @@ int plyolo_bn_act_bwd_reduce(int dtype, int M, int C, const void* dout, int d_ld
   if (const char* e = getenv("PLYOLO_BN_RED_DIV")) { const int v = atoi(e); if (v >= 1) div = v; }
   int rows = M / div;
   if (rows < 1) rows = 1;
-  if (rows > 1024) rows = 1024;
+  static const int cap_env = getenv("PLYOLO_BN_RED_CAP") ? atoi(getenv("PLYOLO_BN_RED_CAP")) : 0;
+  static const int unr = getenv("PLYOLO_BN_RED_UNR") ? atoi(getenv("PLYOLO_BN_RED_UNR")) : 2;
+  const int cap = cap_env > 0 ? cap_env : 1024;
+  if (rows > cap) rows = cap;
   plyolo::annotate("bn_act_bwd_reduce", 0.0, (double)M * C * (dtype == PLYOLO_BF16 ? 2.0 : 4.0) * 2.0);
   return submit(stream, [=](hipStream_t s) -> hipError_t {
     DISPATCH_T(dtype, {
-      auto kern = act == PLYOLO_ACT_SILU ? bn_act_bwd_reduce_kernel<T, PLYOLO_ACT_SILU> : bn_act_bwd_reduce_kernel<T, -1>;
+      auto kern = act == PLYOLO_ACT_SILU ? (unr == 4 ? bn_act_bwd_reduce_kernel<T, PLYOLO_ACT_SILU, 4> : unr == 1 ? bn_act_bwd_reduce_kernel<T, PLYOLO_ACT_SILU, 1> : bn_act_bwd_reduce_kernel<T, PLYOLO_ACT_SILU, 2>)
+                                         : bn_act_bwd_reduce_kernel<T, -1>;
       hipLaunchKernelGGL(kern, dim3(rows), dim3(256), 0, s, M, C, (const T*)dout, d_ld, (const T*)z, z_ld, coef, act, bslots, sp);
     })
     return hipGetLastError();

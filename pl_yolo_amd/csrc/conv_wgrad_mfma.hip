@@ -106,10 +106,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
   constexpr int DV = (TH_ * TW * DZV + 255) / 256;
   constexpr int NXV = ITH_ * ITW_ * XV;
   constexpr int HV = (NXV + 255) / 256;
-  u32x4 dv[DV], hv[HV];
+  // two register sets: two tiles are in flight while a third is being multiplied (one set covered a single HBM round trip per
+  // tile, ~2 us against ~1 us of MFMA work: the loop ran at the memory LATENCY, neither roof in sight)
+  u32x4 dvA[DV], hvA[HV], dvB[DV], hvB[HV];
   // lazy input: a thread always stages the same 8 input channels (256 % XV == 0), so their BatchNorm coefficients sit in
   // registers for the whole kernel; `hmask` remembers which of the prefetched vectors are real pixels (padding stays 0)
-  unsigned hmask = 0u;
+  unsigned hmaskA = 0u, hmaskB = 0u;
   float psc[PRE ? 8 : 1], psh[PRE ? 8 : 1];
   if constexpr (PRE) {
     static_assert(256 % XV == 0 && HV <= 32, "lazy input staging assumes a fixed channel vector per thread");
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
       psh[i] = ci < p.Cin ? p.pre[p.pre_ld + ci + i] : 0.f;
     }
   }
-  auto prefetch = [&](int tile) {
+  auto prefetch = [&](int tile, u32x4 (&dv)[DV], u32x4 (&hv)[HV], unsigned& hmask) {
     const int txi = tile % p.tiles_x;
     const int t2 = tile / p.tiles_x;
     const int tyi = t2 % p.tiles_y;
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
       hv[v] = val;
     }
   };
-  auto commit = [&]() {
+  auto commit = [&](const u32x4 (&dv)[DV], const u32x4 (&hv)[HV], const unsigned hmask) {
 #pragma unroll
     for (int v = 0; v < DV; ++v) {
       const int idx = tid + v * 256;
@@ -187,39 +189,86 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
     }
   };
 
-  if (split < p.ntiles) prefetch(split);
-  for (int tile = split; tile < p.ntiles; tile += p.S) {
-    __syncthreads();  // previous tile fully consumed
-    commit();
-    __syncthreads();
-    if (tile + p.S < p.ntiles && !(p.ablate & 2)) prefetch(tile + p.S);
-    if (!(p.ablate & 4))
-#pragma unroll 2
-    for (int j = wk; j < TH_; j += WK) {
-      // A = dY^T fragments: A[row = co][k = pixel (j, 8h..8h+7)]
-      s16x8 af[MTC];
+  auto multiply = [&]() {
+    if (!(p.ablate & 4)) {
+      // MFMA phase, software-pipelined by hand: the fragments of k-step j+1 are read from LDS (ds_read_b64_tr_b16) while the
+      // MFMAs of k-step j run.  Left to itself the compiler keeps this a rolled loop that reads each B fragment right before
+      // the MFMA using it: with one wave per SIMD (the 3x3 variants hold 144 accumulator registers) every k-step exposed the
+      // LDS latency several times -- ~1000 cycles per 9 MFMAs (288 cycles of matrix-core time).
+      constexpr int NJ = TH_ / WK;                       // k-steps (tile rows) of this wave
+      constexpr int NRD = 2 * (MTC + NTAPS * MTI), NMM = NTAPS * MTI * MTC;
+      s16x8 af0[MTC], af1[MTC], bf0[NTAPS][MTI], bf1[NTAPS][MTI];
+      auto ldfrag = [&](int j, s16x8 (&af)[MTC], s16x8 (&bfv)[NTAPS][MTI]) {
 #pragma unroll
-      for (int a = 0; a < MTC; ++a) {
-        const unsigned char* ap = dz_s + (j * TW + kpix) * DZB + a_col + a * 64;
-        const s16x4 lo = tr_read(ap);
-        const s16x4 hi = tr_read(ap + 4 * DZB);
-        af[a] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-      }
+        for (int a = 0; a < MTC; ++a) {          // A = dY^T fragments: A[row = co][k = pixel (j, 8h..8h+7)]
+          const unsigned char* ap = dz_s + (j * TW + kpix) * DZB + a_col + a * 64;
+          const s16x4 lo = tr_read(ap);
+          const s16x4 hi = tr_read(ap + 4 * DZB);
+          af[a] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
 #pragma unroll
-      for (int t = 0; t < NTAPS; ++t) {
-        const int dy_ = t / KS, dx_ = t % KS;     // dy_ is relative to the staged halo rows (0 under the tap-row split)
+        for (int t = 0; t < NTAPS; ++t) {
+          const int dy_ = t / KS, dx_ = t % KS;     // dy_ is relative to the staged halo rows (0 under the tap-row split)
 #pragma unroll
-        for (int b = 0; b < MTI; ++b) {
-          const unsigned char* bp = x_s + ((j * SI + dy_) * ITW_ + kpix * SI + dx_) * XB + b_col + b * 64;
-          const s16x4 lo = tr_read(bp);
-          const s16x4 hi = tr_read(bp + 4 * SI * XB);
-          const s16x8 bfv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          for (int b = 0; b < MTI; ++b) {
+            const unsigned char* bp = x_s + ((j * SI + dy_) * ITW_ + kpix * SI + dx_) * XB + b_col + b * 64;
+            const s16x4 lo = tr_read(bp);
+            const s16x4 hi = tr_read(bp + 4 * SI * XB);
+            bfv[t][b] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          }
+        }
+      };
+      auto mm = [&](const s16x8 (&af)[MTC], const s16x8 (&bfv)[NTAPS][MTI]) {
 #pragma unroll
-          for (int a = 0; a < MTC; ++a)
-            acc[t][a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&af[a], *(const bf16x8*)&bfv, acc[t][a][b], 0, 0, 0);
+        for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+          for (int b = 0; b < MTI; ++b)
+#pragma unroll
+            for (int a = 0; a < MTC; ++a)
+              acc[t][a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&af[a], *(const bf16x8*)&bfv[t][b], acc[t][a][b], 0, 0, 0);
+      };
+      // every k-step is its own scheduling region: [MFMA, RPM reads] repeated, the reads of the NEXT step front-loaded into the
+      // first half of this step's MFMAs so that they have landed when the next region starts
+      constexpr int RPM = (NRD + (NMM > 1 ? NMM / 2 : 1) - 1) / (NMM > 1 ? NMM / 2 : 1);
+      auto interleave = [&]() {
+#pragma unroll
+        for (int i = 0; i < NMM; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, RPM, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      ldfrag(wk, af0, bf0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int jj = 0; jj < NJ; jj += 2) {
+        const int j = wk + jj * WK;
+        if (jj + 1 < NJ) ldfrag(j + WK, af1, bf1);
+        mm(af0, bf0);
+        interleave();
+        if (jj + 2 < NJ) ldfrag(j + 2 * WK, af0, bf0);
+        if (jj + 1 < NJ) {
+          mm(af1, bf1);
+          interleave();
         }
       }
     }
+  };
+
+  if (split < p.ntiles) prefetch(split, dvA, hvA, hmaskA);
+  if (split + p.S < p.ntiles && !(p.ablate & 2)) prefetch(split + p.S, dvB, hvB, hmaskB);
+  for (int tile = split; tile < p.ntiles; tile += 2 * p.S) {
+    __syncthreads();  // previous tile fully consumed
+    commit(dvA, hvA, hmaskA);
+    __syncthreads();
+    if (tile + 2 * p.S < p.ntiles && !(p.ablate & 2)) prefetch(tile + 2 * p.S, dvA, hvA, hmaskA);
+    multiply();
+    if (tile + p.S >= p.ntiles) break;
+    __syncthreads();
+    commit(dvB, hvB, hmaskB);
+    __syncthreads();
+    if (tile + 3 * p.S < p.ntiles && !(p.ablate & 2)) prefetch(tile + 3 * p.S, dvB, hvB, hmaskB);
+    multiply();
   }
 
   if (p.ablate & 1) { if (acc[0][0][0][0] == 123.456f) p.dw[0] = 1.f; return; }
@@ -322,7 +371,10 @@ static WgPlan plan_wgrad(const plyolo_conv_desc* d) {
   // tap-row split for the 64x64 3x3 variant (PLYOLO_WG_TRS=3): three workgroups per slab tile, one kernel row each
   // Measured (YOLOX-s B=32, same box, 3 alternations): the 64x64 launches 1.53 -> 1.23 ms, all weight-gradient launches
   // 3.37 -> 3.07 ms, step 10.34 -> 10.25 ms.  PLYOLO_WG_TRS=1 restores one workgroup per slab tile; =13 also splits the 128x32 variant.
-  static const int trs_env = getenv("PLYOLO_WG_TRS") ? atoi(getenv("PLYOLO_WG_TRS")) : 3;
+  // Round 2, later: with two tiles in flight and the hand-pipelined MFMA phase the unsplit kernel is the better co-runner again
+  // (a third of the L2 traffic: the three row workgroups each re-read the dY tile): its launches are longer (3.15 vs 2.95 ms per
+  // step) but the step is shorter, 10.32 / 10.36 / 10.37 vs 10.49 / 10.55 / 10.52 ms on one box.  Default 1.
+  static const int trs_env = getenv("PLYOLO_WG_TRS") ? atoi(getenv("PLYOLO_WG_TRS")) : 1;
   w.trs = ((w.id == 0 && trs_env >= 3) || (w.id == 1 && trs_env == 13)) ? 3 : 1;
   int S = target / (nco * p.nci * w.WK * w.trs);
   if (S * w.WK > 1024) S = 1024 / w.WK;
@@ -332,8 +384,11 @@ static WgPlan plan_wgrad(const plyolo_conv_desc* d) {
   // the slabs so that their launches fill the chip (+3 % on YOLOX-x 1280, nothing on YOLOX-s whose widest 3x3 is 256)
   if ((double)d->ksize * d->ksize * d->Cin * d->Cout / (double)(d->Cin + d->Cout) >= 1300.0) budget = 40.0e6;
   if (const char* e = getenv("PLYOLO_WG_BUDGET_MB")) { const double v = atof(e); if (v >= 1.0) budget = v * 1.0e6; }
+  if (w.id == 0 && w.trs == 1) if (const char* e = getenv("PLYOLO_WG_BUDGET0_MB")) { const double v = atof(e); if (v >= 1.0) budget = v * 1.0e6; }
   const int s_budget = (int)(budget / (dw_bytes * w.WK));
   if (S > s_budget) S = s_budget;
+  // the 3x3 variants hold 144 accumulator registers: one workgroup per CU, a 257th would wait for a whole first round
+  if (d->ksize == 3 && w.trs == 1 && S * nco * p.nci > 256) S = 256 / (nco * p.nci);
   if (S < 1) S = 1;
   if (S > p.ntiles) S = p.ntiles;
   if (const char* e = getenv("PLYOLO_WG_S")) { const int v = atoi(e); if (v > 0) S = v < p.ntiles ? v : p.ntiles; }
@@ -365,7 +420,8 @@ int conv_mfma_wgrad(const plyolo_conv_desc* d, const void* x, const void* dy, fl
   return submit(stream, [=](hipStream_t s) -> hipError_t {
     const bool s2 = p.si == 2;
     switch (id) {
-      case 0: return trs == 3 ? launch_wg<64, 64, 3, 1, 1, 1, 8, 1, 3>(p, S, s) : launch_wg<64, 64, 3, 1, 1, 1, 8, 1>(p, S, s);
+      case 0:
+        return trs == 3 ? launch_wg<64, 64, 3, 1, 1, 1, 8, 1, 3>(p, S, s) : launch_wg<64, 64, 3, 1, 1, 1, 8, 1>(p, S, s);
       case 1:
         if (trs == 3) return s2 ? launch_wg<128, 32, 3, 1, 1, 1, 8, 2, 3>(p, S, s) : launch_wg<128, 32, 3, 1, 1, 1, 8, 1, 3>(p, S, s);
         return s2 ? launch_wg<128, 32, 3, 1, 1, 1, 8, 2>(p, S, s) : launch_wg<128, 32, 3, 1, 1, 1, 8, 1>(p, S, s);

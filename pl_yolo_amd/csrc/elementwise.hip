@@ -607,6 +607,28 @@ __global__ void reduce_slabs_kernel(float* dwp, int nslab, size_t elems, int per
   }
 }
 
+// the same fold for SEVERAL weight tensors in one launch (blockIdx.z = job): the per-layer reductions are tiny (a few MB each,
+// 69 of them per YOLOX-s step at ~12 us apiece, mostly launch floor); batched over the layers whose weight gradients finished
+// since the last flush they run as two fat launches.  stage 0: every job's slab groups; stage 1: the group heads.
+__global__ void reduce_slabs_multi_kernel(const plyolo_reduce_job* jobs, int stage) {
+  const plyolo_reduce_job j = jobs[blockIdx.z];
+  const int per = stage == 0 ? j.per : j.groups;
+  const int nsl = stage == 0 ? j.nslab : j.groups;
+  const size_t stride = stage == 0 ? j.elems : j.elems * (size_t)j.per;
+  if (stage == 1 && j.groups <= 1) return;
+  const int first = blockIdx.y * per;
+  if (first >= nsl) return;
+  const int n = nsl - first < per ? nsl - first : per;
+  if (n <= 1 && stage == 0) return;
+  float* base = j.dwp + (size_t)first * stride;
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < j.elems; i += (size_t)gridDim.x * blockDim.x * 4) {
+    f32x4 a = *(const f32x4*)(base + i);
+#pragma unroll 4
+    for (int sl = 1; sl < n; ++sl) a += *(const f32x4*)(base + (size_t)sl * stride + i);
+    *(f32x4*)(base + i) = a;
+  }
+}
+
 __global__ void unpack_wgrads_kernel(const plyolo_pack_entry* table, int accumulate) {
   const plyolo_pack_entry e = table[blockIdx.x];
   if (!e.dw) return;
@@ -963,6 +985,32 @@ int plyolo_reduce_slabs(float* dwp, int nslab, size_t elems, void* stream) {
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cols, groups), dim3(256), 0, s, dwp, nslab, elems, per, elems);
     if (groups > 1)  // fold the group heads (slabs 0, per, 2*per, ...)
       hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cols, 1), dim3(256), 0, s, dwp, groups, elems, groups, elems * (size_t)per);
+    return hipGetLastError();
+  });
+}
+
+/* grouping of one weight tensor's slab fold, identical to plyolo_reduce_slabs (so both give bit-identical sums) */
+int plyolo_reduce_slabs_plan(int nslab, size_t elems, int* per, int* groups) {
+  PLY_CHECK_ARG(nslab >= 1 && elems % 4 == 0 && per && groups, "reduce_slabs_plan: slab length must be a multiple of 4 floats");
+  const int cols = grid_for(elems / 4);
+  int g = 1;
+  if (cols < 512 && nslab >= 16) {
+    g = (1024 + cols - 1) / cols;
+    if (g > nslab / 4) g = nslab / 4;
+  }
+  const int p = (nslab + g - 1) / g;
+  *per = p;
+  *groups = (nslab + p - 1) / p;
+  return 0;
+}
+
+int plyolo_reduce_slabs_multi(const plyolo_reduce_job* jobs_dev, int njobs, int max_cols, int max_groups, double total_bytes, void* stream) {
+  PLY_CHECK_ARG(jobs_dev && njobs > 0 && max_cols > 0 && max_groups > 0, "reduce_slabs_multi: bad arguments");
+  plyolo::annotate("reduce_slabs", 0.0, total_bytes);
+  const int cols = max_cols > 256 ? 256 : max_cols;
+  return submit(stream, [=](hipStream_t s) -> hipError_t {
+    hipLaunchKernelGGL(reduce_slabs_multi_kernel, dim3(cols, max_groups, njobs), dim3(256), 0, s, jobs_dev, 0);
+    if (max_groups > 1) hipLaunchKernelGGL(reduce_slabs_multi_kernel, dim3(cols, 1, njobs), dim3(256), 0, s, jobs_dev, 1);
     return hipGetLastError();
   });
 }

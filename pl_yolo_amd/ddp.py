@@ -162,6 +162,7 @@ class BucketSchedule:
         wl = G.WGRAD_LANE if g.use_lanes else 0
         g.flush_param_grads()
         plan.lane(wl)
+        g.flush_reduce()                 # queued slab folds first: the unpack below reads slab 0
         todo = [i for i in self.entries_left if self.entry_op[i] >= done_idx]
         if todo:
             self.entries_left = [i for i in self.entries_left if self.entry_op[i] < done_idx]

@@ -104,6 +104,8 @@ class Graph:
         # weight gradients on their own lane (PLYOLO_LANES=0 keeps every launch on lane 0)
         self.use_lanes = os.environ.get("PLYOLO_LANES", "1") != "0"
         self.reduce_slabs = os.environ.get("PLYOLO_REDUCE_SLABS", "1") == "1"
+        self.reduce_batch = int(os.environ.get("PLYOLO_REDUCE_BATCH", "16"))   # layers per batched slab-fold launch (1 = one launch per layer)
+        self.reduce_queue = []
         # merge same-input conv pairs (ConvPairOp) in training plans; inference plans fuse BatchNorm + activation
         # into each convolution's epilogue instead (ConvUnitOp.fwd), which needs one output matrix per conv
         self.pair_convs = os.environ.get("PLYOLO_PAIR", "1") == "1" and training
@@ -116,6 +118,33 @@ class Graph:
         # chip sustains ~3.8 T SiLU/s -- the same order as the HBM stream itself -- so inside a loader the work does not
         # disappear, it lengthens every workgroup's load -> stage -> MFMA chain
         self.lazy_acts = os.environ.get("PLYOLO_LAZY", "0") == "1" and training
+
+    # ------------------------------------------------------------------ batched slab folds
+    def queue_reduce(self, pc):
+        """Slab folds are tiny launches (69 per YOLOX-s step, ~12 us each, mostly launch floor): they are queued and run as ONE
+        two-stage launch per `reduce_batch` layers on the weight-gradient lane (and before anything reads slab 0)."""
+        self.reduce_queue.append(pc)
+        if len(self.reduce_queue) >= self.reduce_batch:
+            self.flush_reduce()
+
+    def flush_reduce(self):
+        q, self.reduce_queue = self.reduce_queue, []
+        if not q:
+            return
+        from ._lib import ReduceJob
+        arr = (ReduceJob * len(q))()
+        max_cols = max_groups = 1
+        total = 0.0
+        for i, pc in enumerate(q):
+            per, groups = C.c_int(), C.c_int()
+            call("plyolo_reduce_slabs_plan", pc.nslab, pc.dwp_elems, C.byref(per), C.byref(groups))
+            arr[i].dwp, arr[i].nslab, arr[i].per, arr[i].groups, arr[i].elems = pc.dwp, pc.nslab, per.value, groups.value, pc.dwp_elems
+            max_cols = max(max_cols, (pc.dwp_elems // 4 + 255) // 256)
+            max_groups = max(max_groups, groups.value)
+            total += 4.0 * pc.dwp_elems * pc.nslab
+        t = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+        self.keep.append(t)
+        call("plyolo_reduce_slabs_multi", t.data_ptr(), len(q), max_cols, max_groups, total, None)
 
     # ------------------------------------------------------------------ lazy activations
     def resolve_lazy(self):
@@ -297,8 +326,21 @@ class Graph:
                 self.max_pack_elems = max(self.max_pack_elems, c.ksize * c.ksize * w.shape[0] * c.Cin_p)
         self.pack_entries = entries
 
+    def flush_reduce_on_lane(self):
+        """Run the queued slab folds now, on the lane the weight gradients run on (before anything reads slab 0)."""
+        if not self.reduce_queue:
+            return
+        if self.use_lanes:
+            self.flush_param_grads()
+            self.plan.lane(WGRAD_LANE)
+            self.flush_reduce()
+            self.plan.lane(0)
+        else:
+            self.flush_reduce()
+
     def join_lanes(self):
         """Everything recorded on the weight-gradient lane so far happens before what lane 0 records next."""
+        self.flush_reduce_on_lane()
         if self.use_lanes:
             self.flush_param_grads()
             self.plan.wait(0, self.plan.record(WGRAD_LANE))
@@ -490,7 +532,10 @@ class PackedConv:
         Measured on YOLOX-s B=32: 2356 vs 2327 img/s -- the 80 small reductions are hidden beside the main
         lane, the single slab-summing unpack (0.6 ms) is not."""
         if self.g.reduce_slabs and self.nslab > 1:
-            call("plyolo_reduce_slabs", self.dwp, self.nslab, self.dwp_elems, None)
+            if self.g.reduce_batch > 1:
+                self.g.queue_reduce(self)
+            else:
+                call("plyolo_reduce_slabs", self.dwp, self.nslab, self.dwp_elems, None)
 
     def set_slabs(self, desc):
         """Number of private wgrad slabs the backward launch of `desc` writes."""
