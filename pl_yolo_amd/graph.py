@@ -507,6 +507,7 @@ def record_ops(g, plan, ops, method, lanes=True, after=None):
             after(min(o.index for o in ops[i:j]))
         i = j
     plan.lane(0)
+    g.flush_reduce_on_lane()   # slab folds still queued (backward plans): nothing may read slab 0 before them
 
 
 class PackedConv:
