@@ -179,6 +179,8 @@ def lib_md5():
 
 def kernel_of(label):
     base = label.split("<")[0]
+    if base == "conv_wgrad" and ",k3>" in label and os.environ.get("PLYOLO_WG3", "1") != "0" and os.environ.get("PLYOLO_WG_TRS", "1") == "1":
+        return "conv_wgrad3_kernel"      # the 3x3 weight gradient has its own __global__ function (conv_wgrad_mfma.hip)
     return _KERNEL_OF.get(base, base)
 
 

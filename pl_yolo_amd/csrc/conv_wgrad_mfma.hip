@@ -295,6 +295,252 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 3x3 kernel, round 2: the tile pipeline runs INSIDE the MFMA phase.
+//
+// conv_wgrad_kernel above alternates phases -- wait for the prefetched tile, write it to LDS, barrier, issue the next
+// prefetch (~200 address / bounds instructions), multiply -- and the 3x3 variants run one wave per SIMD (144 accumulator
+// registers), so nothing overlaps: measured per 8x16 tile of the 64x64 variant 1.33 us of MFMA phase + 0.45 us of commit and
+// barriers + 0.37 us of prefetch issue, against 0.96 us of matrix-core time.  Here
+//   * LDS holds TWO tiles: while tile i is multiplied out of one buffer, tile i+1 is written into the other and tile i+2 is
+//     requested from HBM -- vector by vector, spread over the k-steps, in the shadow of the MFMAs (a wave issues ~7 other
+//     instructions per 32-cycle MFMA); one register set, recycled vector by vector; ONE barrier per tile;
+//   * tile loads are raw buffer loads (one descriptor per image): padding, ragged edges, channel tails and "no such tile"
+//     (a zero-record descriptor) all come back as zeros from the range check -- no branches, so every k-step stays one
+//     scheduling region; the per-vector offsets and LDS addresses are computed once per kernel, a tile costs 6 VALU per vector.
+template <int CO_T, int CI_T, int WK, int TH_, int SI, bool PRE>
+__global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WgP p) {
+  constexpr int KS = 3, NTAPS = 9;
+  constexpr int WCO = CO_T / 32, WCI = CI_T / 32;
+  static_assert(WCO * WCI * WK == 4, "four waves per workgroup");
+  constexpr int DZB = pitch_for(CO_T), XB = pitch_for(CI_T);
+  constexpr int DZV = CO_T / 8, XV = CI_T / 8;
+  constexpr int ITH_ = (TH_ - 1) * SI + KS, ITW_ = (TW - 1) * SI + KS;
+  constexpr int DZ_BYTES = TH_ * TW * DZB, BUF = DZ_BYTES + ITH_ * ITW_ * XB;
+  constexpr int NDV = TH_ * TW * DZV, DV = (NDV + 255) / 256;
+  constexpr int NXV = ITH_ * ITW_ * XV, HV = (NXV + 255) / 256;
+  constexpr int NV = DV + HV;
+  constexpr int NJ = TH_ / WK;                       // k-steps (tile rows) of this wave
+  constexpr int DUMP = BUF;             // 4 KB behind each buffer: where the lanes of a partial last vector write
+  constexpr int BUFP = BUF + 4096;
+  static_assert(2 * BUFP <= 160 * 1024, "two tiles must fit in LDS");
+  static_assert(!PRE || 256 % XV == 0, "lazy input staging assumes a fixed channel vector per thread");
+  extern __shared__ __align__(16) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wk = wave / (WCO * WCI), wco = (wave / WCI) % WCO, wci = wave % WCI;
+  const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
+  int wg = (int)blockIdx.x;
+  if (p.xcd) {
+    const int nwg = (int)gridDim.x, qq = nwg >> 3, r8 = nwg & 7, x = wg & 7;
+    wg = (x < r8 ? x * (qq + 1) : r8 * (qq + 1) + (x - r8) * qq) + (wg >> 3);
+  }
+  const int split = p.xcd ? wg / p.nslabt : wg % p.S, slab_tile = p.xcd ? wg % p.nslabt : wg / p.S;
+  const int co_tile = slab_tile / p.nci, ci_tile = slab_tile % p.nci;
+  const int co0 = co_tile * CO_T, ci0 = ci_tile * CI_T;
+
+  const int kpix = 8 * (g >> 1) + q;
+  const int a_off = kpix * DZB + (wco * 32 + 16 * (g & 1) + 4 * pp) * 2;
+  const int b_off = DZ_BYTES + kpix * SI * XB + (wci * 32 + 16 * (g & 1) + 4 * pp) * 2;
+
+  f32x16 acc[NTAPS];
+#pragma unroll
+  for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  // ---- tile-invariant state of the vectors this thread stages (vector v < DV: dY, else X halo)
+  constexpr unsigned NEVER = 0x7fffu;          // a row coordinate no image has: the vector is never loaded
+  int rel[NV], lds[NV];
+  unsigned yx[NV];
+#pragma unroll
+  for (int v = 0; v < DV; ++v) {
+    const int idx = tid + v * 256, m = idx / DZV, vv = idx - m * DZV, co = co0 + vv * 8;
+    const bool live = idx < NDV && co < p.Cout;
+    rel[v] = (((m >> 4) * p.OW + (m & 15)) * p.dy_ld + co) * 2;
+    yx[v] = live ? (unsigned)(m >> 4) | ((unsigned)(m & 15) << 16) : NEVER;
+    lds[v] = idx < NDV ? m * DZB + vv * 16 : DUMP + tid * 16;
+  }
+#pragma unroll
+  for (int v = 0; v < HV; ++v) {
+    const int idx = tid + v * 256, pix = idx / XV, vv = idx - pix * XV, iy = pix / ITW_, ix = pix - iy * ITW_, ci = ci0 + vv * 8;
+    const bool live = idx < NXV && ci < p.Cin;
+    rel[DV + v] = ((iy * p.W + ix) * p.x_ld + ci) * 2;
+    yx[DV + v] = live ? (unsigned)iy | ((unsigned)ix << 16) : NEVER;
+    lds[DV + v] = idx < NXV ? DZ_BYTES + pix * XB + vv * 16 : DUMP + tid * 16;
+  }
+  float psc[PRE ? 8 : 1], psh[PRE ? 8 : 1];
+  if constexpr (PRE) {
+    const int ci = ci0 + (tid % XV) * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      psc[i] = ci < p.Cin ? p.pre[ci + i] : 0.f;
+      psh[i] = ci < p.Cin ? p.pre[p.pre_ld + ci + i] : 0.f;
+    }
+  }
+
+  struct Tile {
+    __amdgpu_buffer_rsrc_t rd, rx;
+    int oy0, ox0, iy0, ix0, dbase, xbase;
+  };
+  const int d_img = ((p.OH * p.OW - 1) * p.dy_ld + ((p.Cout + 7) & ~7)) * 2, x_img = ((p.H * p.W - 1) * p.x_ld + ((p.Cin + 7) & ~7)) * 2;
+  auto tile_at = [&](int tile) {      // wave-uniform (blockIdx and kernel arguments only): lives in SGPRs
+    Tile t;
+    const bool real = tile < p.ntiles;
+    const int tt = real ? tile : 0;
+    const int txi = tt % p.tiles_x, t2 = tt / p.tiles_x, tyi = t2 % p.tiles_y, n = t2 / p.tiles_y;
+    t.oy0 = tyi * TH_; t.ox0 = txi * TW;
+    t.iy0 = t.oy0 * SI - p.pad; t.ix0 = t.ox0 * SI - p.pad;
+    t.dbase = (t.oy0 * p.OW + t.ox0) * p.dy_ld * 2;
+    t.xbase = (t.iy0 * p.W + t.ix0) * p.x_ld * 2;
+    t.rd = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dy + (size_t)n * p.OH * p.OW * p.dy_ld), 0, real ? d_img : 0, 0x00020000);
+    t.rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)n * p.H * p.W * p.x_ld), 0, real ? x_img : 0, 0x00020000);
+    return t;
+  };
+  u32x4 R[NV];
+  unsigned hmask = 0u;                 // lazy input: which X vectors in R are real pixels (padding stays zero)
+  auto request = [&](const Tile& t, int v) {   // v: compile-time after unrolling
+    const bool isx = v >= DV;
+    const int y = (isx ? t.iy0 : t.oy0) + (int)(yx[v] & 0xffffu), x = (isx ? t.ix0 : t.ox0) + (int)(yx[v] >> 16);
+    const bool ok = (unsigned)y < (unsigned)(isx ? p.H : p.OH) && (unsigned)x < (unsigned)(isx ? p.W : p.OW);
+    const int off = ok ? (isx ? t.xbase : t.dbase) + rel[v] : (int)0x80000000;   // past any image: the range check returns zeros
+    R[v] = __builtin_amdgcn_raw_buffer_load_b128(isx ? t.rx : t.rd, off, 0, 0);
+    if constexpr (PRE) { if (isx) hmask = ok ? hmask | (1u << (v - DV)) : hmask & ~(1u << (v - DV)); }
+  };
+  auto stage = [&](unsigned char* buf, int v) {
+    u32x4 t = R[v];
+    if constexpr (PRE) {
+      if (v >= DV) {
+        const bool real = (hmask >> (v - DV)) & 1u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float lo = act_fwd_core(fmaf(__uint_as_float(t[i] << 16), psc[2 * i], psh[2 * i]), p.pre_act);
+          const float hi = act_fwd_core(fmaf(__uint_as_float(t[i] & 0xffff0000u), psc[2 * i + 1], psh[2 * i + 1]), p.pre_act);
+          t[i] = real ? pack2bf(lo, hi) : 0u;
+        }
+      }
+    }
+    *(u32x4*)(buf + lds[v]) = t;     // lanes beyond the tile write to a dump row: no branch inside a k-step
+  };
+
+  // ---- prologue: tile 0 into buffer 0, tile 1 requested
+  {
+    // (requests in the order the main loop re-issues them -- by k-step -- so that its vmcnt waits are exact from the first tile on)
+    const Tile t0 = tile_at(split);
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+      for (int v = jj; v < NV; v += NJ) request(t0, v);
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+      for (int v = jj; v < NV; v += NJ) stage(smem, v);
+    const Tile t1 = tile_at((p.ablate & 2) ? p.ntiles : split + p.S);
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+      for (int v = jj; v < NV; v += NJ) request(t1, v);
+  }
+  __syncthreads();
+
+  int cur = 0;
+  for (int tile = split; tile < p.ntiles; tile += p.S) {
+    const unsigned char* bc = smem + cur * BUFP;
+    unsigned char* bn = smem + (cur ^ 1) * BUFP;
+    const Tile t2 = tile_at((p.ablate & 2) ? p.ntiles : tile + 2 * p.S);
+    const unsigned char* ap = bc + a_off;
+    const unsigned char* bp = bc + b_off;
+    s16x8 af0, af1, bf0[NTAPS], bf1[NTAPS];
+    auto ldfrag = [&](int j, s16x8& af, s16x8 (&bfv)[NTAPS]) {
+      const s16x4 lo = tr_read(ap + j * TW * DZB);
+      const s16x4 hi = tr_read(ap + j * TW * DZB + 4 * DZB);
+      af = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+      for (int t = 0; t < NTAPS; ++t) {
+        const int o = ((j * SI + t / KS) * ITW_ + t % KS) * XB;
+        const s16x4 l2 = tr_read(bp + o);
+        const s16x4 h2 = tr_read(bp + o + 4 * SI * XB);
+        bfv[t] = __builtin_shufflevector(l2, h2, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+    };
+    auto mm = [&](const s16x8& af, const s16x8 (&bfv)[NTAPS]) {
+#pragma unroll
+      for (int t = 0; t < NTAPS; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&af, *(const bf16x8*)&bfv[t], acc[t], 0, 0, 0);
+    };
+    // the vectors of tile i+1 / i+2 handled beside k-step jj: stage R[v] into the other buffer, then re-request it
+    auto side = [&](int jj) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v)
+        if (v % NJ == jj) {
+          stage(bn, v);
+          request(t2, v);
+        }
+    };
+    auto pattern = [&]() {   // [MFMA + 5 LDS reads] x 4: the next k-step's fragments first; then the tile pipeline's share
+      constexpr int SV = (NV + NJ - 1) / NJ;
+#pragma unroll
+      for (int i = 0; i < NTAPS; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (i < 4) __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+        else if (i - 4 < SV) {
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    ldfrag(wk, af0, bf0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int jj = 0; jj < NJ; jj += 2) {
+      const int j = wk + jj * WK;
+      if (jj + 1 < NJ) ldfrag(j + WK, af1, bf1);
+      mm(af0, bf0);
+      side(jj);
+      pattern();
+      if (jj + 2 < NJ) ldfrag(j + 2 * WK, af0, bf0);
+      if (jj + 1 < NJ) {
+        mm(af1, bf1);
+        side(jj + 1);
+        pattern();
+      }
+    }
+    __syncthreads();   // tile i consumed by every wave, tile i+1 complete in the other buffer
+    cur ^= 1;
+  }
+
+  if (p.ablate & 1) { if (acc[0][0] == 123.456f) p.dw[0] = 1.f; return; }
+  float* slab = p.dw + ((size_t)split * WK + wk) * ((size_t)KS * KS * p.Cout * p.Cin);
+  const int r = lane & 31, h = lane >> 5;
+  const int ci = ci0 + wci * 32 + r;
+  if (ci < p.Cin) {
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int co = co0 + wco * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (co < p.Cout) slab[((size_t)t * p.Cout + co) * p.Cin + ci] = acc[t][i];
+      }
+  }
+}
+
+template <int CO_T, int CI_T, int WK, int TH_, int SI>
+hipError_t launch_wg3(const WgP& p, int S, hipStream_t s) {
+  constexpr int DZB = pitch_for(CO_T), XB = pitch_for(CI_T);
+  const size_t lds = 2 * ((size_t)TH_ * TW * DZB + (size_t)((TH_ - 1) * SI + 3) * ((TW - 1) * SI + 3) * XB + 4096);
+  auto kern = p.pre ? conv_wgrad3_kernel<CO_T, CI_T, WK, TH_, SI, true> : conv_wgrad3_kernel<CO_T, CI_T, WK, TH_, SI, false>;
+  if (hipError_t e = plyolo::ensure_dynamic_lds((const void*)kern, 160 * 1024); e != hipSuccess) return e;
+  const int nco = (p.Cout + CO_T - 1) / CO_T;
+  WgP q = p;
+  q.nslabt = nco * p.nci;
+  q.S = S;
+  static const int xcd = getenv("PLYOLO_WG_XCD") ? atoi(getenv("PLYOLO_WG_XCD")) : 1;
+  q.xcd = xcd;
+  hipLaunchKernelGGL(kern, dim3(S * q.nslabt), dim3(256), lds, s, q);
+  return hipGetLastError();
+}
+
 template <int CO_T, int CI_T, int KS, int WK, int MTC, int MTI, int TH_, int SI, int TRS = 1>
 hipError_t launch_wg(const WgP& p, int S, hipStream_t s) {
   constexpr int DZB = pitch_for(CO_T), XB = pitch_for(CI_T);
@@ -378,7 +624,11 @@ static WgPlan plan_wgrad(const plyolo_conv_desc* d) {
   w.trs = ((w.id == 0 && trs_env >= 3) || (w.id == 1 && trs_env == 13)) ? 3 : 1;
   int S = target / (nco * p.nci * w.WK * w.trs);
   if (S * w.WK > 1024) S = 1024 / w.WK;
-  double budget = 20.0e6;  // measured on the whole step (8 / 12 / 16 / 20 / 24 / 32 / 64 MB): slab stores + folds compete with the main lane for HBM
+  // measured on the whole step: slab stores + folds compete with the main lane for HBM, and a lighter weight-gradient launch is
+  // the better co-runner even when it takes longer.  Round 1 (phase-alternating kernels): 20 MB best of 8 .. 64.  Round 2 (tile
+  // pipeline inside the MFMA phase), mean of 4 alternations on one box: 4 MB 14.3 ms, 6 11.5, 8 10.8, 10 10.23, 12 10.25,
+  // 16 10.08, 20 10.22, 28 10.36, 40 10.63 -- flat between 10 and 20.
+  double budget = 16.0e6;
   // wide layers (FLOPs per operand byte k*k*Cin*Cout/(Cin+Cout) >= 1300: 320+ channels at 3x3) are MFMA-bound and sit
   // on the critical lane of the large models (YOLOX-x: the weight-gradient lane is the longer one): they get twice
   // the slabs so that their launches fill the chip (+3 % on YOLOX-x 1280, nothing on YOLOX-s whose widest 3x3 is 256)
@@ -417,8 +667,19 @@ int conv_mfma_wgrad(const plyolo_conv_desc* d, const void* x, const void* dy, fl
     const double Mo = (double)p.N * p.OH * p.OW, Mi = (double)p.N * p.H * p.W;
     annotate(lab, 2.0 * Mo * d->Cout * d->Cin * ks * ks, (Mo * d->Cout + Mi * d->Cin) * 2.0 + 4.0 * ks * ks * d->Cout * d->Cin);
   }
+  // 3x3, unsplit: the round-2 kernel with the tile pipeline inside the MFMA phase (PLYOLO_WG3=0: the phase-alternating kernel);
+  // its buffer descriptors address one image with 31-bit offsets
+  static const int wg3_env = getenv("PLYOLO_WG3") ? atoi(getenv("PLYOLO_WG3")) : 1;
+  const bool wg3 = wg3_env != 0 && ks == 3 && trs == 1 && (double)p.H * p.W * p.x_ld * 2.0 < 2.0e9 && (double)p.OH * p.OW * p.dy_ld * 2.0 < 2.0e9;
   return submit(stream, [=](hipStream_t s) -> hipError_t {
     const bool s2 = p.si == 2;
+    if (wg3) switch (id) {
+      case 0: return launch_wg3<64, 64, 1, 8, 1>(p, S, s);
+      case 1: return s2 ? launch_wg3<128, 32, 1, 8, 2>(p, S, s) : launch_wg3<128, 32, 1, 8, 1>(p, S, s);
+      case 2: return s2 ? launch_wg3<64, 32, 2, 8, 2>(p, S, s) : (th16 ? launch_wg3<64, 32, 2, 16, 1>(p, S, s) : launch_wg3<64, 32, 2, 8, 1>(p, S, s));
+      case 3: return s2 ? launch_wg3<32, 32, 4, 8, 2>(p, S, s) : (th16 ? launch_wg3<32, 32, 4, 16, 1>(p, S, s) : launch_wg3<32, 32, 4, 8, 1>(p, S, s));
+      default: break;
+    }
     switch (id) {
       case 0:
         return trs == 3 ? launch_wg<64, 64, 3, 1, 1, 1, 8, 1, 3>(p, S, s) : launch_wg<64, 64, 3, 1, 1, 1, 8, 1>(p, S, s);
