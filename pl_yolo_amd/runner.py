@@ -167,6 +167,7 @@ class DetectorRunner:
         g.build_pack_table(self.grad_ptr_of)
         # ---- record the forward plan
         s.fwd = G.Plan()
+        s.fwd.is_fwd = True
         with s.fwd:
             g.plan = s.fwd
             call("plyolo_pack_weights", g.pack_table.data_ptr(), g.n_pack, g.dtype, g.max_pack_elems, None)
@@ -240,6 +241,8 @@ class DetectorRunner:
         private stream (capture is not allowed on the legacy default stream) fenced with
         events on both sides."""
         use_graph = self.use_graph if self.use_graph != "auto" else plan.lanes() <= 1
+        if self.use_graph == "auto" and os.environ.get("PLYOLO_GRAPH_FWD") == "1" and getattr(plan, "is_fwd", False):
+            use_graph = True    # experiment: forward plans as hipGraphs, backward plans eagerly
         if use_graph and plan.hooks():
             raise PlyoloError("a data-parallel backward plan issues its gradient buckets from host hooks, which a hipGraph replay "
                               "cannot run: use the eager replay (PLYOLO_GRAPH=0 / auto)")
