@@ -267,6 +267,27 @@ typedef struct plyolo_aug_image {
 } plyolo_aug_image;
 int plyolo_preproc_batch(const plyolo_aug_image* imgs_dev, int B, int out_h, int out_w, float* out, void* stream);
 
+/* Mosaic / random affine / mixup, pixel side (reference models/data/mosaic_detection.py: mosaic :61-118, cv2.warpAffine inside
+ * random_perspective :328-344, mixup :169-247).  uint8 HWC BGR device images; the small descriptors are HOST memory and are
+ * copied into the launch.  The random decisions and the label arithmetic are the host's (pl_yolo_amd/data.py). */
+typedef struct plyolo_mosaic_tile {
+  const unsigned char* src;   /* source image [h, w, 3] */
+  int h, w;
+  int dh, dw;                 /* its size after cv2.resize(..., INTER_LINEAR): int(h * scale), int(w * scale) */
+  int lx1, ly1, lx2, ly2;     /* rectangle of the 2H x 2W canvas it fills (get_mosaic_coordinate :256-274) */
+  int sx1, sy1;               /* top-left of the visible part inside the resized image */
+} plyolo_mosaic_tile;
+/* canvas [canvas_h, canvas_w, 3] = 114, except the four rectangles */
+int plyolo_mosaic4(const plyolo_mosaic_tile* tiles_host, int canvas_h, int canvas_w, unsigned char* canvas, void* stream);
+/* cv2.warpAffine(src, M, dsize=(dw, dh), borderValue=border) with inv6_host = the INVERSE of M (cv::invertAffineTransform, 6 doubles) */
+int plyolo_warp_affine_u8(const unsigned char* src, int sh, int sw, const double* inv6_host, unsigned char* dst, int dh, int dw, int border,
+                          void* stream);
+/* dst [out_h, out_w, 3]: cv2.resize(src, (dw, dh)) in the top-left corner, `pad` elsewhere */
+int plyolo_resize_pad_u8(const unsigned char* src, int h, int w, int dh, int dw, unsigned char* dst, int out_h, int out_w, int pad, void* stream);
+/* out [th, tw, 3] = uint8(0.5 * origin + 0.5 * crop): `other` [bh, bw, 3] (mirrored if flip), zero-padded to >= th x tw, cut at (y_off, x_off) */
+int plyolo_mixup_blend_u8(const unsigned char* origin, int th, int tw, const unsigned char* other, int bh, int bw, int flip, int x_off, int y_off,
+                          unsigned char* out, void* stream);
+
 /* ------------------------------------------------------------ deploy-time folding (inference export)
  * Replaces RepConv._fuse_bn_tensor / get_equivalent_kernel_bias / fuse_conv_bn / fuse_repvgg_block
  * (models/necks/yolov7_neck.py:213-348) and prepares BaseConv.fuseforward (network_blocks.py:39-40): fp32 weights in

@@ -1,0 +1,278 @@
+"""CPU restatement of the mosaic / random-affine / mixup sample builder (TEST ORACLE -- imported by tests only).
+
+Follows /root/reference/models/data/mosaic_detection.py:
+    MosaicDetection.__getitem__ :60-167 (mosaic branch :61-146, plain branch :148-167), mixup :169-247,
+    adjust_box_anns :250-253, get_mosaic_coordinate :256-274, random_perspective :277-371, box_candidates :374-387
+with numpy only.  The control flow, the order of the draws from python's `random` and the label arithmetic are followed line
+by line and ARE pinned: tests/golden/mosaic_samples.npz holds what the reference's own MosaicDetection returns in this
+container (tools/gen_golden.py mosaic) when its `cv2` import is served by the three functions below.  The pixel arithmetic of
+those OpenCV calls is RESTATED from OpenCV's published 8-bit algorithms (cv2 is not installable here): PARITY UNPINNED
+against cv2 itself --
+  * cv2.resize(INTER_LINEAR), uint8: oracle/augment.py resize_linear_u8;
+  * cv2.getRotationMatrix2D: alpha = s cos a, beta = s sin a, [[alpha, beta, (1-alpha) cx - beta cy], [-beta, alpha, beta cx + (1-alpha) cy]];
+  * cv2.warpAffine(INTER_LINEAR, BORDER_CONSTANT), uint8 -- imgproc/imgwarp.cpp: M inverted in double (invertAffineTransform);
+    per column adelta/bdelta = cvRound(M[0] x 2^10), cvRound(M[3] x 2^10); per row X0 = cvRound((M[1] y + M[2]) 2^10) + 16 (same
+    for Y0); X = (X0 + adelta[x]) >> 5: integer part X >> 5 (saturated to int16), 5 fraction bits; bilinear weights from
+    the 32 x 32 table, short(w * 32768) (exact: the products are multiples of 2^-10); pixel = (sum of 4 taps * weights + 2^14) >> 15;
+    a tap outside the source reads the border value.
+Copy-paste / cut-paste / rounding cut-out (probabilities 0 in every shipped config) are not restated: a non-zero probability raises.
+csrc/augment.hip implements the same arithmetic; tests compare the two bit for bit."""
+import math
+import random
+
+import numpy as np
+
+from .augment import resize_linear_u8
+
+
+# ---- the three OpenCV calls ------------------------------------------------------------------------------------------------
+def get_rotation_matrix_2d(center, angle, scale):
+    a = angle * math.pi / 180.0
+    alpha, beta = math.cos(a) * scale, math.sin(a) * scale
+    cx, cy = center
+    return np.array([[alpha, beta, (1 - alpha) * cx - beta * cy], [-beta, alpha, beta * cx + (1 - alpha) * cy]], dtype=np.float64)
+
+
+def invert_affine(M):
+    m = np.asarray(M, dtype=np.float64).reshape(2, 3).copy().ravel()
+    D = m[0] * m[4] - m[1] * m[3]
+    D = 1.0 / D if D != 0 else 0.0
+    A11, A22 = m[4] * D, m[0] * D
+    m[0] = A11
+    m[1] *= -D
+    m[3] *= -D
+    m[4] = A22
+    b1 = -m[0] * m[2] - m[1] * m[5]
+    b2 = -m[3] * m[2] - m[4] * m[5]
+    m[2], m[5] = b1, b2
+    return m
+
+
+def _rint(v):
+    return np.rint(v).astype(np.int64)
+
+
+def warp_affine_u8(img, M, dsize, border_value=(114, 114, 114)):
+    """cv2.warpAffine(img, M, dsize=(width, height), borderValue=...) for uint8 HWC, INTER_LINEAR, BORDER_CONSTANT."""
+    width, height = int(dsize[0]), int(dsize[1])
+    sh, sw = img.shape[:2]
+    m = invert_affine(M)
+    xs = np.arange(width, dtype=np.float64)
+    ys = np.arange(height, dtype=np.float64)
+    adelta = _rint(m[0] * xs * 1024.0)
+    bdelta = _rint(m[3] * xs * 1024.0)
+    X0 = _rint((m[1] * ys + m[2]) * 1024.0) + 16
+    Y0 = _rint((m[4] * ys + m[5]) * 1024.0) + 16
+    X = (X0[:, None] + adelta[None, :]) >> 5
+    Y = (Y0[:, None] + bdelta[None, :]) >> 5
+    sx = np.clip(X >> 5, -32768, 32767)
+    sy = np.clip(Y >> 5, -32768, 32767)
+    fx, fy = X & 31, Y & 31
+    w00 = (32 - fy) * (32 - fx) * 32          # (1 - fy/32)(1 - fx/32) * 32768, exact
+    w01 = (32 - fy) * fx * 32
+    w10 = fy * (32 - fx) * 32
+    w11 = fy * fx * 32
+    src = img.astype(np.int64)
+    cval = np.asarray(border_value, dtype=np.int64)[: img.shape[2]]
+
+    def tap(yy, xx):
+        ok = (yy >= 0) & (yy < sh) & (xx >= 0) & (xx < sw)
+        v = src[np.clip(yy, 0, sh - 1), np.clip(xx, 0, sw - 1)]
+        return np.where(ok[..., None], v, cval[None, None, :])
+
+    acc = (tap(sy, sx) * w00[..., None] + tap(sy, sx + 1) * w01[..., None]
+           + tap(sy + 1, sx) * w10[..., None] + tap(sy + 1, sx + 1) * w11[..., None])
+    out = (acc + (1 << 14)) >> 15
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def resize(img, dsize):
+    """cv2.resize(img, (w, h), interpolation=INTER_LINEAR) for uint8 HWC."""
+    return resize_linear_u8(img, int(dsize[0]), int(dsize[1]))
+
+
+# ---- mosaic_detection.py, line by line -------------------------------------------------------------------------------------
+def adjust_box_anns(bbox, scale_ratio, padw, padh, w_max, h_max):
+    bbox[:, 0::2] = np.clip(bbox[:, 0::2] * scale_ratio + padw, 0, w_max)
+    bbox[:, 1::2] = np.clip(bbox[:, 1::2] * scale_ratio + padh, 0, h_max)
+    return bbox
+
+
+def get_mosaic_coordinate(k, xc, yc, w, h, input_h, input_w):
+    """:256-274.  Quadrant k (0 TL, 1 TR, 2 BL, 3 BR) of the 2H x 2W canvas around the centre (xc, yc): the canvas rectangle the
+    w x h image lands in (clipped to the canvas) and the part of the image that is visible there."""
+    left, top = k in (0, 2), k in (0, 1)
+    x1, x2 = (max(xc - w, 0), xc) if left else (xc, min(xc + w, input_w * 2))
+    y1, y2 = (max(yc - h, 0), yc) if top else (yc, min(input_h * 2, yc + h))
+    sx = (w - (x2 - x1), w) if left else (0, min(w, x2 - x1))      # left quadrants keep the image's right edge at the centre
+    sy = (h - (y2 - y1), h) if top else (0, min(y2 - y1, h))
+    return (x1, y1, x2, y2), (sx[0], sy[0], sx[1], sy[1])
+
+
+def box_candidates(box1, box2, wh_thr=2, ar_thr=20, area_thr=0.2):
+    w1, h1 = box1[2] - box1[0], box1[3] - box1[1]
+    w2, h2 = box2[2] - box2[0], box2[3] - box2[1]
+    ar = np.maximum(w2 / (h2 + 1e-16), h2 / (w2 + 1e-16))
+    return (w2 > wh_thr) & (h2 > wh_thr) & (w2 * h2 / (w1 * h1 + 1e-16) > area_thr) & (ar < ar_thr)
+
+
+def affine_decision(shape_hw, degrees, translate, scale, shear, border):
+    """The draws and the matrix of random_perspective :288-326 (perspective = 0).  Returns (M 3x3, s, width, height)."""
+    height = shape_hw[0] + border[0] * 2
+    width = shape_hw[1] + border[1] * 2
+    C = np.eye(3)
+    C[0, 2] = -shape_hw[1] / 2
+    C[1, 2] = -shape_hw[0] / 2
+    R = np.eye(3)
+    a = random.uniform(-degrees, degrees)
+    s = random.uniform(scale[0], scale[1])
+    R[:2] = get_rotation_matrix_2d((0, 0), a, s)
+    S = np.eye(3)
+    S[0, 1] = math.tan(random.uniform(-shear, shear) * math.pi / 180)
+    S[1, 0] = math.tan(random.uniform(-shear, shear) * math.pi / 180)
+    T = np.eye(3)
+    T[0, 2] = random.uniform(0.5 - translate, 0.5 + translate) * width
+    T[1, 2] = random.uniform(0.5 - translate, 0.5 + translate) * height
+    M = T @ S @ R @ C
+    return M, s, width, height
+
+
+def affine_labels(targets, M, s, width, height):
+    """random_perspective :346-369."""
+    n = len(targets)
+    if n:
+        xy = np.ones((n * 4, 3))
+        xy[:, :2] = targets[:, [0, 1, 2, 3, 0, 3, 2, 1]].reshape(n * 4, 2)
+        xy = xy @ M.T
+        xy = xy[:, :2].reshape(n, 8)
+        x = xy[:, [0, 2, 4, 6]]
+        y = xy[:, [1, 3, 5, 7]]
+        xy = np.concatenate((x.min(1), y.min(1), x.max(1), y.max(1))).reshape(4, n).T
+        xy[:, [0, 2]] = xy[:, [0, 2]].clip(0, width)
+        xy[:, [1, 3]] = xy[:, [1, 3]].clip(0, height)
+        i = box_candidates(box1=targets[:, :4].T * s, box2=xy.T)
+        targets = targets[i]
+        targets[:, :4] = xy[i]
+    return targets
+
+
+def random_perspective(img, targets=(), degrees=10, translate=0.1, scale=(0.5, 1.5), shear=10, perspective=0.0, border=(0, 0)):
+    if perspective:
+        raise NotImplementedError("perspective != 0 (cv2.warpPerspective) is not restated")
+    M, s, width, height = affine_decision(img.shape[:2], degrees, translate, scale, shear, border)
+    if (border[0] != 0) or (border[1] != 0) or (M != np.eye(3)).any():
+        img = warp_affine_u8(img, M[:2], (width, height), (114, 114, 114))
+    return img, affine_labels(targets, M, s, width, height)
+
+
+class MosaicDetection:
+    """mosaic_detection.py:12-247 over a dataset object with `.annotations[i] = (labels [n,5] xyxy+cls, img_hw, resized_info,
+    name)`, `.imgs` (list of uint8 HWC arrays, or None) / `.load_resized_img(i)`, `.img_size`."""
+
+    def __init__(self, dataset, img_size, preprocess=None, mosaic_prob=1.0, mosaic_scale=(0.5, 1.5), degrees=10, translate=0.1,
+                 shear=2.0, perspective=0.0, mixup_prob=1.0, mixup_scale=(0.5, 1.5), copypaste_prob=0.0,
+                 copypaste_scale=(0.5, 1.5), cutpaste_prob=0.0, cutoutR_prob=0.0):
+        if copypaste_prob or cutpaste_prob or cutoutR_prob:
+            raise NotImplementedError("copy-paste / cut-paste / rounding cut-out are not restated")
+        self._dataset, self.img_size, self.preprocess = dataset, img_size, preprocess
+        self.mosaic_prob, self.scale = mosaic_prob, mosaic_scale
+        self.degrees, self.translate, self.shear, self.perspective = degrees, translate, shear, perspective
+        self.mixup_prob, self.mixup_scale = mixup_prob, mixup_scale
+        self.copypaste_scale = copypaste_scale
+        self.off_probs = (copypaste_prob, cutpaste_prob, cutoutR_prob)
+
+    def __len__(self):
+        return len(self._dataset)
+
+    def _img(self, index):
+        ds = self._dataset
+        return ds.imgs[index] if ds.imgs is not None else ds.load_resized_img(index)
+
+    def _unused_draws(self, has_labels, mosaic):
+        """The three per-image augmentations that every shipped config leaves at probability 0 still consume draws (:86-91,
+        :156-161); in the mosaic branch the first one is skipped for an image without labels (short-circuit `and`)."""
+        for k, prob in enumerate(self.off_probs):
+            if k == 0 and mosaic and not has_labels:
+                continue
+            if random.random() < prob:
+                raise NotImplementedError
+
+    def __getitem__(self, idx):
+        ds = self._dataset
+        if not random.random() < self.mosaic_prob:                                    # plain branch :148-167
+            res, img_hw, _, img_name = ds.annotations[idx]
+            ds.img_size = self.img_size
+            img = self._img(idx).copy()
+            self._unused_draws(True, mosaic=False)
+            target = res
+            if self.preprocess is not None:
+                img, target = self.preprocess(img, res, self.img_size)
+            return img, target, img_hw, np.array([idx]), img_name
+        H, W = ds.img_size[0], ds.img_size[1]                                         # mosaic branch :61-146
+        yc = int(random.uniform(0.5 * H, 1.5 * H))
+        xc = int(random.uniform(0.5 * W, 1.5 * W))
+        members = [idx] + [random.randint(0, len(ds) - 1) for _ in range(3)]
+        canvas = np.full((2 * H, 2 * W, 3), 114, dtype=np.uint8)
+        parts = []
+        for k, index in enumerate(members):
+            boxes, _, _, img_name = ds.annotations[index]
+            img = self._img(index).copy()
+            self._unused_draws(len(boxes) != 0, mosaic=True)
+            h0, w0 = img.shape[:2]
+            scale = min(1. * H / h0, 1. * W / w0)
+            img = resize(img, (int(w0 * scale), int(h0 * scale)))
+            h, w = img.shape[:2]
+            (lx1, ly1, lx2, ly2), (sx1, sy1, sx2, sy2) = get_mosaic_coordinate(k, xc, yc, w, h, H, W)
+            canvas[ly1:ly2, lx1:lx2] = img[sy1:sy2, sx1:sx2]
+            moved = boxes.copy()
+            if boxes.size > 0:
+                moved[:, 0] = scale * boxes[:, 0] + (lx1 - sx1)
+                moved[:, 1] = scale * boxes[:, 1] + (ly1 - sy1)
+                moved[:, 2] = scale * boxes[:, 2] + (lx1 - sx1)
+                moved[:, 3] = scale * boxes[:, 3] + (ly1 - sy1)
+            parts.append(moved)
+        labels = np.concatenate(parts, 0)
+        for col, hi in ((0, 2 * W), (1, 2 * H), (2, 2 * W), (3, 2 * H)):
+            np.clip(labels[:, col], 0, hi, out=labels[:, col])
+        canvas, labels = random_perspective(canvas, labels, degrees=self.degrees, translate=self.translate, scale=self.scale,
+                                            shear=self.shear, perspective=self.perspective, border=[-H // 2, -W // 2])
+        if not len(labels) == 0 and random.random() < self.mixup_prob:
+            canvas, labels = self.mixup(canvas, labels, self.img_size)
+        mix_img, padded_labels = self.preprocess(canvas, labels, self.img_size)
+        return mix_img, padded_labels, (mix_img.shape[1], mix_img.shape[2]), np.array([idx]), img_name
+
+    def mixup(self, origin_img, origin_labels, input_dim):
+        """:169-247."""
+        jit = random.uniform(*self.copypaste_scale)             # sic: the reference jitters by copypaste_scale (:170)
+        flip = random.uniform(0, 1) > 0.5
+        other = []
+        while len(other) == 0:                                  # an image WITH labels
+            k = random.randint(0, len(self) - 1)
+            other = self._dataset.annotations[k][0]
+        img = self._img(k)
+        # letterbox into input_dim (pad 114), then rescale the WHOLE padded image by the jitter factor
+        r = min(input_dim[0] / img.shape[0], input_dim[1] / img.shape[1])
+        boxed = np.ones((input_dim[0], input_dim[1], 3), dtype=np.uint8) * 114
+        boxed[:int(img.shape[0] * r), :int(img.shape[1] * r)] = resize(img, (int(img.shape[1] * r), int(img.shape[0] * r)))
+        boxed = resize(boxed, (int(boxed.shape[1] * jit), int(boxed.shape[0] * jit)))
+        r *= jit
+        if flip:
+            boxed = boxed[:, ::-1, :]
+        bh, bw = boxed.shape[:2]
+        th, tw = origin_img.shape[:2]
+        pad = np.zeros((max(bh, th), max(bw, tw), 3), dtype=np.uint8)       # zeros, not 114 (:206-209)
+        pad[:bh, :bw] = boxed
+        x_off = y_off = 0
+        if pad.shape[0] > th:
+            y_off = random.randint(0, pad.shape[0] - th - 1)
+        if pad.shape[1] > tw:
+            x_off = random.randint(0, pad.shape[1] - tw - 1)
+        crop = pad[y_off:y_off + th, x_off:x_off + tw]
+        b = adjust_box_anns(other[:, :4].copy(), r, 0, 0, bw, bh)
+        if flip:
+            b[:, 0::2] = bw - b[:, 0::2][:, ::-1]
+        b[:, 0::2] = np.clip(b[:, 0::2] - x_off, 0, tw)
+        b[:, 1::2] = np.clip(b[:, 1::2] - y_off, 0, th)
+        origin_labels = np.vstack((origin_labels, np.hstack((b, other[:, 4:5].copy()))))
+        blend = 0.5 * origin_img.astype(np.float32) + 0.5 * crop.astype(np.float32)
+        return blend.astype(np.uint8), origin_labels

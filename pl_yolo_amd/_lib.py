@@ -104,6 +104,11 @@ class AugImage(C.Structure):   # plyolo_aug_image
                 ("hgain", C.c_double), ("sgain", C.c_double), ("vgain", C.c_double)]
 
 
+class MosaicTile(C.Structure):   # plyolo_mosaic_tile
+    _fields_ = [("src", C.c_void_p), ("h", C.c_int), ("w", C.c_int), ("dh", C.c_int), ("dw", C.c_int), ("lx1", C.c_int), ("ly1", C.c_int),
+                ("lx2", C.c_int), ("ly2", C.c_int), ("sx1", C.c_int), ("sy1", C.c_int)]
+
+
 class ReduceJob(C.Structure):   # plyolo_reduce_job
     _fields_ = [("dwp", C.c_void_p), ("nslab", C.c_int), ("per", C.c_int), ("groups", C.c_int), ("elems", C.c_size_t)]
 
@@ -148,6 +153,10 @@ SIGNATURES = {
     "plyolo_bias_grad": (_i, [_i, _vp, _i, _i, _i, _vp, _vp]),
     "plyolo_pack_weights": (_i, [_vp, _i, _i, _i, _vp]),
     "plyolo_reduce_slabs": (_i, [_vp, _i, _sz, _vp]),
+    "plyolo_mosaic4": (_i, [_vp, _i, _i, _vp, _vp]),
+    "plyolo_warp_affine_u8": (_i, [_vp, _i, _i, _P(_d), _vp, _i, _i, _i, _vp]),
+    "plyolo_resize_pad_u8": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
+    "plyolo_mixup_blend_u8": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "plyolo_reduce_slabs_plan": (_i, [_i, _sz, _P(_i), _P(_i)]),
     "plyolo_reduce_slabs_multi": (_i, [_vp, _i, _i, _i, _d, _vp]),
     "plyolo_pack_elems": (_i, [_i, _i, _i, _i, _P(_sz), _P(_sz)]),

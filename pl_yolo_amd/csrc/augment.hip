@@ -13,6 +13,12 @@
 //   the jitter itself: lut_hue = ((x * r0) % 180), lut_sat = clip(x * r1, 0, 255), lut_val = clip(x * r2, 0, 255), truncated
 //     to uint8 (data_augments.py:118-121).
 // The HIP kernel and oracle/augment.py implement exactly the same integer arithmetic: their outputs are compared bit for bit.
+//
+// Second half of the file: the pixel work of mosaic / random affine / mixup (reference models/data/mosaic_detection.py:60-247,
+// 277-344; oracle/mosaic.py) -- four letterboxed images pasted around a random centre of a 2H x 2W canvas (k_mosaic4),
+// cv2.warpAffine(INTER_LINEAR, BORDER_CONSTANT) with OpenCV's fixed-point coordinates (10 fraction bits per matrix product,
+// 5-bit bilinear weights, (sum + 2^14) >> 15; imgproc/imgwarp.cpp, restated), letterbox + pad, and the 0.5 / 0.5 blend with a
+// mirrored, zero-padded, cropped second image.  The random decisions and the label arithmetic stay on the host (data.py).
 #include "common.h"
 
 namespace {
@@ -116,6 +122,109 @@ __global__ void k_preproc(const plyolo_aug_image* imgs, int B, int OH, int OW, f
   }
 }
 
+// cv2.resize(INTER_LINEAR) of a plain uint8 HWC image, one output pixel (the arithmetic of k_preproc without jitter / mirror)
+DEVINL void resize_px(const unsigned char* src, int h, int w, double sx_scale, double sy_scale, int oy, int ox, int* bgr) {
+#pragma clang fp contract(off)
+  float fx = (float)((ox + 0.5) * sx_scale - 0.5), fy = (float)((oy + 0.5) * sy_scale - 0.5);
+  int x0 = (int)floorf(fx), y0 = (int)floorf(fy);
+  fx -= x0; fy -= y0;
+  if (x0 < 0) { x0 = 0; fx = 0.f; }
+  if (x0 >= w - 1) { x0 = w - 1; fx = 0.f; }
+  if (y0 < 0) { y0 = 0; fy = 0.f; }
+  if (y0 >= h - 1) { y0 = h - 1; fy = 0.f; }
+  const int x1 = x0 + 1 < w ? x0 + 1 : x0, y1 = y0 + 1 < h ? y0 + 1 : y0;
+  const int ax1 = __float2int_rn(fx * 2048.f), ax0 = __float2int_rn((1.f - fx) * 2048.f);
+  const int by1 = __float2int_rn(fy * 2048.f), by0 = __float2int_rn((1.f - fy) * 2048.f);
+  const unsigned char* p00 = src + ((size_t)y0 * w + x0) * 3;
+  const unsigned char* p01 = src + ((size_t)y0 * w + x1) * 3;
+  const unsigned char* p10 = src + ((size_t)y1 * w + x0) * 3;
+  const unsigned char* p11 = src + ((size_t)y1 * w + x1) * 3;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int r0 = p00[c] * ax0 + p01[c] * ax1, r1 = p10[c] * ax0 + p11[c] * ax1;
+    const int q = (r0 * by0 + r1 * by1 + (1 << 21)) >> 22;
+    bgr[c] = q < 0 ? 0 : (q > 255 ? 255 : q);
+  }
+}
+
+struct Mosaic4 { plyolo_mosaic_tile t[4]; };
+
+// one thread per canvas pixel: 114 outside the four quadrant rectangles, the letterboxed source pixel inside
+__global__ void k_mosaic4(const Mosaic4 m, int CH, int CW, unsigned char* canvas) {
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < CH * CW; idx += gridDim.x * blockDim.x) {
+    const int y = idx / CW, x = idx - y * CW;
+    int v[3] = {114, 114, 114};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const plyolo_mosaic_tile& t = m.t[k];
+      if (x >= t.lx1 && x < t.lx2 && y >= t.ly1 && y < t.ly2)
+        resize_px(t.src, t.h, t.w, (double)t.w / t.dw, (double)t.h / t.dh, t.sy1 + (y - t.ly1), t.sx1 + (x - t.lx1), v);
+    }
+    unsigned char* o = canvas + (size_t)idx * 3;
+    o[0] = (unsigned char)v[0]; o[1] = (unsigned char)v[1]; o[2] = (unsigned char)v[2];
+  }
+}
+
+struct Affine6 { double m[6]; };   // the INVERTED matrix (dst -> src), as cv::warpAffine uses it
+
+__global__ void k_warp_affine(const unsigned char* src, int SH, int SW, const Affine6 a, unsigned char* dst, int DH, int DW, int border) {
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < DH * DW; idx += gridDim.x * blockDim.x) {
+    const int y = idx / DW, x = idx - y * DW;
+    long long X, Y;
+    {
+#pragma clang fp contract(off)   // every product and sum rounded, as in OpenCV's scalar code and in the numpy oracle
+      const long long adelta = __double2ll_rn(a.m[0] * (double)x * 1024.0), bdelta = __double2ll_rn(a.m[3] * (double)x * 1024.0);
+      const long long X0 = __double2ll_rn((a.m[1] * (double)y + a.m[2]) * 1024.0) + 16, Y0 = __double2ll_rn((a.m[4] * (double)y + a.m[5]) * 1024.0) + 16;
+      X = (X0 + adelta) >> 5;
+      Y = (Y0 + bdelta) >> 5;
+    }
+    long long sxl = X >> 5, syl = Y >> 5;
+    sxl = sxl < -32768 ? -32768 : (sxl > 32767 ? 32767 : sxl);     // saturate_cast<short>
+    syl = syl < -32768 ? -32768 : (syl > 32767 ? 32767 : syl);
+    const int sx = (int)sxl, sy = (int)syl, fx = (int)(X & 31), fy = (int)(Y & 31);
+    const int w00 = (32 - fy) * (32 - fx) * 32, w01 = (32 - fy) * fx * 32, w10 = fy * (32 - fx) * 32, w11 = fy * fx * 32;
+    const bool y0ok = sy >= 0 && sy < SH, y1ok = sy + 1 >= 0 && sy + 1 < SH, x0ok = sx >= 0 && sx < SW, x1ok = sx + 1 >= 0 && sx + 1 < SW;
+    const unsigned char* p00 = src + ((size_t)(y0ok ? sy : 0) * SW + (x0ok ? sx : 0)) * 3;
+    const unsigned char* p01 = src + ((size_t)(y0ok ? sy : 0) * SW + (x1ok ? sx + 1 : 0)) * 3;
+    const unsigned char* p10 = src + ((size_t)(y1ok ? sy + 1 : 0) * SW + (x0ok ? sx : 0)) * 3;
+    const unsigned char* p11 = src + ((size_t)(y1ok ? sy + 1 : 0) * SW + (x1ok ? sx + 1 : 0)) * 3;
+    unsigned char* o = dst + (size_t)idx * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int v00 = y0ok && x0ok ? p00[c] : border, v01 = y0ok && x1ok ? p01[c] : border;
+      const int v10 = y1ok && x0ok ? p10[c] : border, v11 = y1ok && x1ok ? p11[c] : border;
+      const int q = (v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11 + (1 << 14)) >> 15;
+      o[c] = (unsigned char)(q < 0 ? 0 : (q > 255 ? 255 : q));
+    }
+  }
+}
+
+// dst [OH, OW, 3]: the resized image in the top-left dh x dw, `pad` elsewhere
+__global__ void k_resize_pad(const unsigned char* src, int h, int w, int dh, int dw, unsigned char* dst, int OH, int OW, int pad) {
+  const double sx_scale = (double)w / dw, sy_scale = (double)h / dh;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < OH * OW; idx += gridDim.x * blockDim.x) {
+    const int y = idx / OW, x = idx - y * OW;
+    int v[3] = {pad, pad, pad};
+    if (y < dh && x < dw) resize_px(src, h, w, sx_scale, sy_scale, y, x, v);
+    unsigned char* o = dst + (size_t)idx * 3;
+    o[0] = (unsigned char)v[0]; o[1] = (unsigned char)v[1]; o[2] = (unsigned char)v[2];
+  }
+}
+
+// out = uint8(0.5 * origin + 0.5 * crop), crop = the (mirrored) other image padded with ZEROS to at least th x tw, cut at (y_off, x_off)
+__global__ void k_mixup_blend(const unsigned char* origin, int th, int tw, const unsigned char* other, int bh, int bw, int flip, int x_off,
+                              int y_off, unsigned char* out) {
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < th * tw; idx += gridDim.x * blockDim.x) {
+    const int y = idx / tw, x = idx - y * tw;
+    const int py = y + y_off, px = x + x_off;
+    const bool in = py < bh && px < bw;
+    const unsigned char* q = other + ((size_t)(in ? py : 0) * bw + (in ? (flip ? bw - 1 - px : px) : 0)) * 3;
+    const unsigned char* o = origin + (size_t)idx * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[(size_t)idx * 3 + c] = (unsigned char)(int)(0.5f * (float)o[c] + 0.5f * (float)(in ? q[c] : 0));
+  }
+}
+
 }  // namespace
 
 using plyolo::submit;
@@ -127,6 +236,57 @@ int plyolo_preproc_batch(const plyolo_aug_image* imgs_dev, int B, int out_h, int
   plyolo::annotate("preproc_batch", 0.0, (double)B * out_h * out_w * 3 * 5.0);
   return submit(stream, [=](hipStream_t s) -> hipError_t {
     hipLaunchKernelGGL(k_preproc, dim3((unsigned)cdiv(out_h * out_w, 256), B), dim3(256), 0, s, imgs_dev, B, out_h, out_w, out);
+    return hipGetLastError();
+  });
+}
+
+int plyolo_mosaic4(const plyolo_mosaic_tile* tiles_host, int canvas_h, int canvas_w, unsigned char* canvas, void* stream) {
+  PLY_CHECK_ARG(tiles_host && canvas && canvas_h > 0 && canvas_w > 0, "mosaic4: bad arguments");
+  Mosaic4 m;
+  for (int k = 0; k < 4; ++k) {
+    const plyolo_mosaic_tile& t = tiles_host[k];
+    PLY_CHECK_ARG(t.src && t.h > 0 && t.w > 0 && t.dh > 0 && t.dw > 0, "mosaic4: tile %d has no image", k);
+    PLY_CHECK_ARG(t.lx1 >= 0 && t.ly1 >= 0 && t.lx2 <= canvas_w && t.ly2 <= canvas_h && t.lx1 <= t.lx2 && t.ly1 <= t.ly2,
+                  "mosaic4: tile %d leaves the canvas", k);
+    PLY_CHECK_ARG(t.sx1 >= 0 && t.sy1 >= 0 && t.sx1 + (t.lx2 - t.lx1) <= t.dw && t.sy1 + (t.ly2 - t.ly1) <= t.dh,
+                  "mosaic4: tile %d shows more than its resized image holds", k);
+    m.t[k] = t;
+  }
+  plyolo::annotate("mosaic4", 0.0, (double)canvas_h * canvas_w * 3 * 2.0);
+  return submit(stream, [=](hipStream_t s) -> hipError_t {
+    hipLaunchKernelGGL(k_mosaic4, dim3((unsigned)cdiv(canvas_h * canvas_w, 256)), dim3(256), 0, s, m, canvas_h, canvas_w, canvas);
+    return hipGetLastError();
+  });
+}
+
+int plyolo_warp_affine_u8(const unsigned char* src, int sh, int sw, const double* inv6_host, unsigned char* dst, int dh, int dw, int border,
+                          void* stream) {
+  PLY_CHECK_ARG(src && dst && inv6_host && sh > 0 && sw > 0 && dh > 0 && dw > 0 && border >= 0 && border <= 255, "warp_affine_u8: bad arguments");
+  Affine6 a;
+  for (int i = 0; i < 6; ++i) a.m[i] = inv6_host[i];
+  plyolo::annotate("warp_affine_u8", 0.0, (double)dh * dw * 3 * 5.0);
+  return submit(stream, [=](hipStream_t s) -> hipError_t {
+    hipLaunchKernelGGL(k_warp_affine, dim3((unsigned)cdiv(dh * dw, 256)), dim3(256), 0, s, src, sh, sw, a, dst, dh, dw, border);
+    return hipGetLastError();
+  });
+}
+
+int plyolo_resize_pad_u8(const unsigned char* src, int h, int w, int dh, int dw, unsigned char* dst, int out_h, int out_w, int pad, void* stream) {
+  PLY_CHECK_ARG(src && dst && h > 0 && w > 0 && dh > 0 && dw > 0 && dh <= out_h && dw <= out_w && pad >= 0 && pad <= 255,
+                "resize_pad_u8: bad arguments");
+  plyolo::annotate("resize_pad_u8", 0.0, (double)out_h * out_w * 3 * 5.0);
+  return submit(stream, [=](hipStream_t s) -> hipError_t {
+    hipLaunchKernelGGL(k_resize_pad, dim3((unsigned)cdiv(out_h * out_w, 256)), dim3(256), 0, s, src, h, w, dh, dw, dst, out_h, out_w, pad);
+    return hipGetLastError();
+  });
+}
+
+int plyolo_mixup_blend_u8(const unsigned char* origin, int th, int tw, const unsigned char* other, int bh, int bw, int flip, int x_off, int y_off,
+                          unsigned char* out, void* stream) {
+  PLY_CHECK_ARG(origin && other && out && th > 0 && tw > 0 && bh > 0 && bw > 0 && x_off >= 0 && y_off >= 0, "mixup_blend_u8: bad arguments");
+  plyolo::annotate("mixup_blend_u8", 0.0, (double)th * tw * 3 * 3.0);
+  return submit(stream, [=](hipStream_t s) -> hipError_t {
+    hipLaunchKernelGGL(k_mixup_blend, dim3((unsigned)cdiv(th * tw, 256)), dim3(256), 0, s, origin, th, tw, other, bh, bw, flip, x_off, y_off, out);
     return hipGetLastError();
   });
 }

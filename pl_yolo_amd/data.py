@@ -10,14 +10,17 @@ Images are uint8 HWC BGR DEVICE tensors (decode / upload them however the host l
 mirror, letterbox resize, pad with 114, HWC->CHW fp32 -- runs in csrc/augment.hip (plyolo_preproc_batch).  The label
 arithmetic (a few dozen floats per image) stays on the host in numpy, line by line as in the reference, and draws from
 python's `random` / numpy's global RNG in the reference's order, so the same seeds take the same decisions.
-Mosaic / random-affine / mixup (models/data/mosaic_detection.py) are not built yet."""
+`MosaicDetection` (models/data/mosaic_detection.py:12-247) builds mosaic / random-affine / mixup samples the same way: four
+launches for the pixels (paste four letterboxed images on the 2H x 2W canvas, warpAffine, letterbox + jitter-rescale the
+mixup partner, blend), the decisions and the box arithmetic on the host."""
 import ctypes as C
+import math
 import random
 
 import numpy as np
 import torch
 
-from ._lib import AugImage, PlyoloError, call
+from ._lib import AugImage, MosaicTile, PlyoloError, call
 
 
 def _check_image(img):
@@ -147,3 +150,242 @@ class ValTransform:
     def __call__(self, img, targets, input_size):
         out, labels = self.batch([img], [targets], input_size)
         return out[0], labels[0]
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# mosaic / random affine / mixup
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def mosaic_coordinate(k, xc, yc, w, h, input_h, input_w):
+    """get_mosaic_coordinate, mosaic_detection.py:256-274: quadrant k (0 top-left, 1 top-right, 2 bottom-left, 3 bottom-right)
+    around the centre (xc, yc) -> (canvas rectangle, visible rectangle of the w x h image)."""
+    if k in (0, 2):
+        x1, x2 = max(xc - w, 0), xc
+        sx1, sx2 = w - (x2 - x1), w
+    else:
+        x1, x2 = xc, min(xc + w, input_w * 2)
+        sx1, sx2 = 0, min(w, x2 - x1)
+    if k in (0, 1):
+        y1, y2 = max(yc - h, 0), yc
+        sy1, sy2 = h - (y2 - y1), h
+    else:
+        y1, y2 = yc, min(input_h * 2, yc + h)
+        sy1, sy2 = 0, min(y2 - y1, h)
+    return (x1, y1, x2, y2), (sx1, sy1, sx2, sy2)
+
+
+def invert_affine(M):
+    """cv::invertAffineTransform on a 2x3 matrix, in float64 (what cv2.warpAffine does to M before sampling)."""
+    a, b, c, d, e, f = [float(v) for v in np.asarray(M, dtype=np.float64).reshape(6)]
+    det = a * e - b * d
+    det = 1.0 / det if det != 0 else 0.0
+    ia, ie = e * det, a * det
+    ib, id_ = b * -det, d * -det
+    return [ia, ib, -ia * c - ib * f, id_, ie, -id_ * c - ie * f]
+
+
+def warp_affine(img, M, dsize, border_value=114):
+    """cv2.warpAffine(img, M, dsize=(width, height), borderValue=(v, v, v)) on a uint8 HWC device tensor."""
+    img = _check_image(img)
+    width, height = int(dsize[0]), int(dsize[1])
+    out = torch.empty(height, width, 3, dtype=torch.uint8, device=img.device)
+    inv = (C.c_double * 6)(*invert_affine(M))
+    call("plyolo_warp_affine_u8", img.data_ptr(), int(img.shape[0]), int(img.shape[1]), inv, out.data_ptr(), height, width, int(border_value), _stream())
+    return out
+
+
+def resize_pad(img, dsize, out_hw=None, pad=114):
+    """cv2.resize(img, (w, h)) into the top-left corner of a [out_h, out_w, 3] image filled with `pad` (default: no padding)."""
+    img = _check_image(img)
+    dw, dh = int(dsize[0]), int(dsize[1])
+    oh, ow = (dh, dw) if out_hw is None else (int(out_hw[0]), int(out_hw[1]))
+    out = torch.empty(oh, ow, 3, dtype=torch.uint8, device=img.device)
+    call("plyolo_resize_pad_u8", img.data_ptr(), int(img.shape[0]), int(img.shape[1]), dh, dw, out.data_ptr(), oh, ow, int(pad), _stream())
+    return out
+
+
+def _box_candidates(box1, box2, wh_thr=2, ar_thr=20, area_thr=0.2):   # mosaic_detection.py:374-387
+    w1, h1 = box1[2] - box1[0], box1[3] - box1[1]
+    w2, h2 = box2[2] - box2[0], box2[3] - box2[1]
+    ar = np.maximum(w2 / (h2 + 1e-16), h2 / (w2 + 1e-16))
+    return (w2 > wh_thr) & (h2 > wh_thr) & (w2 * h2 / (w1 * h1 + 1e-16) > area_thr) & (ar < ar_thr)
+
+
+def random_perspective(img, targets=(), degrees=10, translate=0.1, scale=(0.5, 1.5), shear=10, perspective=0.0, border=(0, 0)):
+    """mosaic_detection.py:277-371 with perspective = 0: five draws, M = T S R C, warpAffine with border 114, boxes through M,
+    clipped, filtered by box_candidates."""
+    if perspective:
+        raise NotImplementedError("perspective != 0 (cv2.warpPerspective) is not built")
+    sh, sw = int(img.shape[0]), int(img.shape[1])
+    height, width = sh + border[0] * 2, sw + border[1] * 2
+    Cm = np.eye(3)
+    Cm[0, 2], Cm[1, 2] = -sw / 2, -sh / 2
+    a = random.uniform(-degrees, degrees)
+    s = random.uniform(scale[0], scale[1])
+    ang = a * math.pi / 180.0                                  # cv2.getRotationMatrix2D(angle=a, center=(0, 0), scale=s)
+    alpha, beta = math.cos(ang) * s, math.sin(ang) * s
+    R = np.array([[alpha, beta, 0.0], [-beta, alpha, 0.0], [0.0, 0.0, 1.0]])
+    S = np.eye(3)
+    S[0, 1] = math.tan(random.uniform(-shear, shear) * math.pi / 180)
+    S[1, 0] = math.tan(random.uniform(-shear, shear) * math.pi / 180)
+    T = np.eye(3)
+    T[0, 2] = random.uniform(0.5 - translate, 0.5 + translate) * width
+    T[1, 2] = random.uniform(0.5 - translate, 0.5 + translate) * height
+    M = T @ S @ R @ Cm
+    if (border[0] != 0) or (border[1] != 0) or (M != np.eye(3)).any():
+        img = warp_affine(img, M[:2], (width, height), 114)
+    n = len(targets)
+    if n:
+        xy = np.ones((n * 4, 3))
+        xy[:, :2] = targets[:, [0, 1, 2, 3, 0, 3, 2, 1]].reshape(n * 4, 2)     # the four corners of every box
+        xy = (xy @ M.T)[:, :2].reshape(n, 8)
+        x, y = xy[:, [0, 2, 4, 6]], xy[:, [1, 3, 5, 7]]
+        xy = np.concatenate((x.min(1), y.min(1), x.max(1), y.max(1))).reshape(4, n).T
+        xy[:, [0, 2]] = xy[:, [0, 2]].clip(0, width)
+        xy[:, [1, 3]] = xy[:, [1, 3]].clip(0, height)
+        keep = _box_candidates(box1=targets[:, :4].T * s, box2=xy.T)
+        targets = targets[keep]
+        targets[:, :4] = xy[keep]
+    return img, targets
+
+
+class MosaicDetection:
+    """mosaic_detection.py:12-247 on the device.  `dataset` has the reference's shape -- `.annotations[i] = (labels [n,5]
+    xyxy + class, img_hw, resized_info, name)`, `.img_size`, `.imgs` (list, or None) / `.load_resized_img(i)` -- with uint8
+    HWC BGR DEVICE tensors as images; `preprocess` is a pl_yolo_amd.data.TrainTransform.  `md[idx]` returns the reference's
+    tuple (image [3,H,W] fp32 device tensor, padded labels, (H, W), array([idx]), name) and draws from `random` /
+    `numpy.random` in the reference's order; `md.batch(indices)` builds the samples in that same order and runs the final
+    transform of the whole batch as one launch."""
+
+    def __init__(self, dataset, img_size, preprocess=None, mosaic_prob=1.0, mosaic_scale=(0.5, 1.5), degrees=10, translate=0.1,
+                 shear=2.0, perspective=0.0, mixup_prob=1.0, mixup_scale=(0.5, 1.5), copypaste_prob=0.0,
+                 copypaste_scale=(0.5, 1.5), cutpaste_prob=0.0, cutoutR_prob=0.0):
+        if copypaste_prob or cutpaste_prob or cutoutR_prob:
+            raise NotImplementedError("copy-paste / cut-paste / rounding cut-out (probability 0 in every shipped config) are not built")
+        if perspective:
+            raise NotImplementedError("perspective != 0 (cv2.warpPerspective) is not built")
+        self._dataset, self.img_size, self.preprocess = dataset, img_size, preprocess
+        self.mosaic_prob, self.scale = mosaic_prob, mosaic_scale
+        self.degrees, self.translate, self.shear, self.perspective = degrees, translate, shear, perspective
+        self.mixup_prob, self.mixup_scale = mixup_prob, mixup_scale
+        self.copypaste_prob, self.copypaste_scale = copypaste_prob, copypaste_scale
+        self.cutpaste_prob, self.cutoutR_prob = cutpaste_prob, cutoutR_prob
+
+    def __len__(self):
+        return len(self._dataset)
+
+    def _img(self, index):
+        ds = self._dataset
+        return _check_image(ds.imgs[index] if ds.imgs is not None else ds.load_resized_img(index))
+
+    def _spend_draws(self, has_labels, mosaic):
+        # the per-image augmentations left at probability 0 still draw (:86-91, :156-161); the copy-paste draw of the mosaic
+        # branch sits behind `not len(_labels) == 0 and`, so an image without labels skips it
+        if has_labels or not mosaic:
+            random.random()
+        random.random()
+        random.random()
+
+    # ---- one sample up to (and excluding) the final transform: (uint8 HWC device image, labels [n,5] xyxy+cls, extra)
+    def _build(self, idx):
+        ds = self._dataset
+        if not random.random() < self.mosaic_prob:
+            res, img_hw, _, name = ds.annotations[idx]
+            ds.img_size = self.img_size
+            img = self._img(idx)
+            self._spend_draws(True, mosaic=False)
+            return img, res, img_hw, name, False
+        H, W = int(ds.img_size[0]), int(ds.img_size[1])
+        yc = int(random.uniform(0.5 * H, 1.5 * H))
+        xc = int(random.uniform(0.5 * W, 1.5 * W))
+        members = [idx] + [random.randint(0, len(ds) - 1) for _ in range(3)]
+        tiles = (MosaicTile * 4)()
+        keep, parts, name = [], [], None
+        for k, index in enumerate(members):
+            boxes, _, _, name = ds.annotations[index]
+            img = self._img(index)
+            keep.append(img)
+            self._spend_draws(len(boxes) != 0, mosaic=True)
+            h0, w0 = int(img.shape[0]), int(img.shape[1])
+            scale = min(1. * H / h0, 1. * W / w0)
+            w, h = int(w0 * scale), int(h0 * scale)
+            (lx1, ly1, lx2, ly2), (sx1, sy1, _, _) = mosaic_coordinate(k, xc, yc, w, h, H, W)
+            t = tiles[k]
+            t.src, t.h, t.w, t.dh, t.dw = img.data_ptr(), h0, w0, h, w
+            t.lx1, t.ly1, t.lx2, t.ly2, t.sx1, t.sy1 = lx1, ly1, lx2, ly2, sx1, sy1
+            moved = boxes.copy()
+            if boxes.size > 0:
+                moved[:, 0] = scale * boxes[:, 0] + (lx1 - sx1)
+                moved[:, 1] = scale * boxes[:, 1] + (ly1 - sy1)
+                moved[:, 2] = scale * boxes[:, 2] + (lx1 - sx1)
+                moved[:, 3] = scale * boxes[:, 3] + (ly1 - sy1)
+            parts.append(moved)
+        canvas = torch.empty(2 * H, 2 * W, 3, dtype=torch.uint8, device=keep[0].device)
+        call("plyolo_mosaic4", tiles, 2 * H, 2 * W, canvas.data_ptr(), _stream())
+        labels = np.concatenate(parts, 0)
+        for col, hi in ((0, 2 * W), (1, 2 * H), (2, 2 * W), (3, 2 * H)):
+            np.clip(labels[:, col], 0, hi, out=labels[:, col])
+        canvas, labels = random_perspective(canvas, labels, degrees=self.degrees, translate=self.translate, scale=self.scale,
+                                            shear=self.shear, perspective=self.perspective, border=[-H // 2, -W // 2])
+        if not len(labels) == 0 and random.random() < self.mixup_prob:
+            canvas, labels = self.mixup(canvas, labels, self.img_size)
+        return canvas, labels, None, name, True
+
+    def mixup(self, origin_img, origin_labels, input_dim):
+        """:169-247.  The partner image is letterboxed into input_dim (pad 114), the whole padded image rescaled by the jitter
+        factor, mirrored on a coin flip, padded with zeros up to the target, cropped at a random offset and blended 0.5 / 0.5."""
+        jit = random.uniform(*self.copypaste_scale)             # sic (:170): the reference's mixup jitters by copypaste_scale
+        flip = random.uniform(0, 1) > 0.5
+        other = []
+        while len(other) == 0:
+            k = random.randint(0, len(self) - 1)
+            other = self._dataset.annotations[k][0]
+        img = self._img(k)
+        ih, iw = int(img.shape[0]), int(img.shape[1])
+        r = min(input_dim[0] / ih, input_dim[1] / iw)
+        boxed = resize_pad(img, (int(iw * r), int(ih * r)), (int(input_dim[0]), int(input_dim[1])), 114)
+        bw, bh = int(boxed.shape[1] * jit), int(boxed.shape[0] * jit)
+        boxed = resize_pad(boxed, (bw, bh))
+        r *= jit
+        th, tw = int(origin_img.shape[0]), int(origin_img.shape[1])
+        x_off = y_off = 0
+        if max(bh, th) > th:
+            y_off = random.randint(0, max(bh, th) - th - 1)
+        if max(bw, tw) > tw:
+            x_off = random.randint(0, max(bw, tw) - tw - 1)
+        out = torch.empty_like(origin_img)
+        call("plyolo_mixup_blend_u8", origin_img.data_ptr(), th, tw, boxed.data_ptr(), bh, bw, int(flip), x_off, y_off, out.data_ptr(), _stream())
+        b = other[:, :4].copy()
+        b[:, 0::2] = np.clip(b[:, 0::2] * r, 0, bw)             # adjust_box_anns :250-253 (no padding offsets)
+        b[:, 1::2] = np.clip(b[:, 1::2] * r, 0, bh)
+        if flip:
+            b[:, 0::2] = bw - b[:, 0::2][:, ::-1]
+        b[:, 0::2] = np.clip(b[:, 0::2] - x_off, 0, tw)
+        b[:, 1::2] = np.clip(b[:, 1::2] - y_off, 0, th)
+        return out, np.vstack((origin_labels, np.hstack((b, other[:, 4:5].copy()))))
+
+    def __getitem__(self, idx):
+        img, labels, img_hw, name, mosaic = self._build(idx)
+        if mosaic:
+            mix_img, padded = self.preprocess(img, labels, self.img_size)
+            return mix_img, padded, (int(mix_img.shape[1]), int(mix_img.shape[2])), np.array([idx]), name
+        if self.preprocess is not None:
+            img, labels = self.preprocess(img, labels, self.img_size)
+        return img, labels, img_hw, np.array([idx]), name
+
+    def batch(self, indices):
+        """The samples `[self[i] for i in indices]` with ONE final-transform launch: (images [B,3,H,W] fp32, labels
+        [B,max_labels,5], [info], indices, [names]).  Needs a TrainTransform as `preprocess`."""
+        if not isinstance(self.preprocess, TrainTransform):
+            raise PlyoloError("MosaicDetection.batch needs preprocess=TrainTransform(...)")
+        imgs, decided, infos, names = [], [], [], []
+        for idx in indices:
+            img, labels, img_hw, name, mosaic = self._build(idx)
+            decided.append(self.preprocess._decide(img, labels, self.img_size))    # its draws come right after the sample's
+            imgs.append(img)
+            infos.append((int(self.img_size[0]), int(self.img_size[1])) if mosaic else img_hw)
+            names.append(name)
+        out, _ = preproc_batch(imgs, self.img_size, flips=[d[0] for d in decided], gains=[d[1] for d in decided])
+        return out, np.stack([d[2] for d in decided], 0), infos, np.asarray(list(indices)), names

@@ -1,0 +1,130 @@
+"""Mosaic / random-affine / mixup on the device (pl_yolo_amd.data.MosaicDetection, csrc/augment.hip) -- bit for bit against
+  * tests/golden/mosaic_samples.npz: what the reference's own MosaicDetection + TrainTransform return (tools/gen_golden.py mosaic;
+    OpenCV's calls served by the oracle's restatements), including the position of the `random` stream afterwards;
+  * oracle/mosaic.py on random matrices / sizes the fixture does not hold."""
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import augment as oa, mosaic as om  # noqa: E402
+from pl_yolo_amd import data as pdata  # noqa: E402
+from pl_yolo_amd._lib import PlyoloError  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+FIX = np.load(os.path.join(ROOT, "tests", "golden", "mosaic_samples.npz"))
+CASES = {"mix": dict(mosaic_prob=1.0, mixup_prob=1.0), "nomix": dict(mosaic_prob=1.0, mixup_prob=0.0),
+         "plain": dict(mosaic_prob=0.0, mixup_prob=1.0), "coin": dict(mosaic_prob=0.5, mixup_prob=0.5)}
+
+
+class ToyDataset:
+    def __init__(self, device=None, size=(48, 64)):
+        n = len([k for k in FIX.files if k.startswith("ds_img")])
+        host = [FIX["ds_img%d" % i].copy() for i in range(n)]
+        self.imgs = [torch.from_numpy(h).to(device) for h in host] if device else host
+        self.annotations = [(FIX["ds_lab%d" % i].copy(), host[i].shape[:2], host[i].shape[:2], "img%d" % i) for i in range(n)]
+        self.img_size = size
+
+    def __len__(self):
+        return len(self.imgs)
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+@pytest.mark.parametrize("tag", sorted(CASES))
+def test_device_samples_match_reference_fixture(tag):
+    md = pdata.MosaicDetection(ToyDataset(DEV), (48, 64), preprocess=pdata.TrainTransform(max_labels=20, flip_prob=0.5, hsv_prob=1.0), **CASES[tag])
+    seed = int(FIX["%s_seed" % tag])
+    random.seed(seed)
+    np.random.seed(seed)
+    for k, idx in enumerate(FIX["%s_idx" % tag]):
+        img, lab, info, ids, name = md[int(idx)]
+        assert img.is_cuda and img.dtype == torch.float32
+        assert np.array_equal(img.cpu().numpy(), FIX["%s_%d_img" % (tag, k)]), (tag, k)
+        assert np.array_equal(np.asarray(lab, dtype=np.float32), FIX["%s_%d_labels" % (tag, k)]), (tag, k)
+        assert tuple(info) == tuple(FIX["%s_%d_info" % (tag, k)]) and int(ids[0]) == int(idx)
+    assert random.random() == float(FIX["%s_state" % tag])
+
+
+def test_batch_equals_sequential_items():
+    kw = dict(mosaic_prob=0.7, mixup_prob=0.6)
+    tt = pdata.TrainTransform(max_labels=20, flip_prob=0.5, hsv_prob=1.0)
+    idxs = [1, 4, 0, 6, 2, 5]
+    random.seed(3); np.random.seed(3)
+    md = pdata.MosaicDetection(ToyDataset(DEV), (48, 64), preprocess=tt, **kw)
+    seq = [md[i] for i in idxs]
+    random.seed(3); np.random.seed(3)
+    md = pdata.MosaicDetection(ToyDataset(DEV), (48, 64), preprocess=tt, **kw)
+    imgs, labels, infos, ids, names = md.batch(idxs)
+    assert imgs.shape == (len(idxs), 3, 48, 64)
+    for k, s in enumerate(seq):
+        assert torch.equal(imgs[k], s[0]) and np.array_equal(labels[k], s[1]) and names[k] == s[4]
+    # and the oracle agrees on the same seeds (a case the fixture does not hold)
+    random.seed(3); np.random.seed(3)
+    mo = om.MosaicDetection(ToyDataset(None), (48, 64), preprocess=oa.TrainTransform(max_labels=20, flip_prob=0.5, hsv_prob=1.0), **kw)
+    for k, i in enumerate(idxs):
+        want = mo[i]
+        assert np.array_equal(imgs[k].cpu().numpy(), np.asarray(want[0], dtype=np.float32)), k
+        assert np.array_equal(labels[k], np.asarray(want[1], dtype=np.float32)), k
+
+
+@pytest.mark.parametrize("shape,dsize", [((37, 53), (64, 48)), ((96, 128), (64, 48)), ((20, 20), (31, 57)), ((640, 480), (320, 320))])
+def test_warp_affine_vs_oracle_random_matrices(shape, dsize):
+    rng = np.random.RandomState(shape[0] * 7 + dsize[0])
+    img = rng.randint(0, 256, shape + (3,)).astype(np.uint8)
+    random.seed(shape[1])
+    for rep in range(6):
+        M, s, width, height = om.affine_decision(shape, degrees=25, translate=0.2, scale=(0.4, 1.8), shear=8, border=(0, 0))
+        got = pdata.warp_affine(dev(img), M[:2], dsize, 114).cpu().numpy()
+        want = om.warp_affine_u8(img, M[:2], dsize, (114, 114, 114))
+        assert np.array_equal(got, want), (rep, np.abs(got.astype(int) - want.astype(int)).max())
+    ident = np.array([[1.0, 0, 0], [0, 1.0, 0]])
+    assert np.array_equal(pdata.warp_affine(dev(img), ident, (shape[1], shape[0]), 0).cpu().numpy(), img)
+    far = np.array([[1.0, 0, 1.0e6], [0, 1.0, -1.0e6]])          # everything maps outside: border only (int16 saturation path)
+    assert (pdata.warp_affine(dev(img), far, dsize, 9).cpu().numpy() == 9).all()
+    assert pdata.invert_affine(M[:2]) == list(om.invert_affine(M[:2]))
+
+
+@pytest.mark.parametrize("shape,dsize,out_hw", [((40, 60), (30, 20), (48, 64)), ((17, 91), (91, 17), None), ((50, 50), (125, 124), (130, 130))])
+def test_resize_pad_vs_oracle(shape, dsize, out_hw):
+    rng = np.random.RandomState(shape[0])
+    img = rng.randint(0, 256, shape + (3,)).astype(np.uint8)
+    got = pdata.resize_pad(dev(img), dsize, out_hw, 114).cpu().numpy()
+    rs = om.resize(img, dsize)
+    want = rs if out_hw is None else np.full(out_hw + (3,), 114, dtype=np.uint8)
+    if out_hw is not None:
+        want[:dsize[1], :dsize[0]] = rs
+    assert np.array_equal(got, want)
+
+
+def test_mixup_offsets_flip_and_zero_padding():
+    """mixup on its own against the oracle's, with a partner both larger and smaller than the target."""
+    for seed in range(8):
+        ds_d, ds_h = ToyDataset(DEV), ToyDataset(None)
+        origin = np.random.RandomState(seed).randint(0, 256, (48, 64, 3)).astype(np.uint8)
+        lab = np.array([[3.0, 4, 30, 40, 7]])
+        md = pdata.MosaicDetection(ds_d, (48, 64), copypaste_scale=(0.4, 1.9))
+        mo = om.MosaicDetection(ds_h, (48, 64), copypaste_scale=(0.4, 1.9))
+        random.seed(seed)
+        got_img, got_lab = md.mixup(dev(origin), lab.copy(), (48, 64))
+        random.seed(seed)
+        want_img, want_lab = mo.mixup(origin.copy(), lab.copy(), (48, 64))
+        assert np.array_equal(got_img.cpu().numpy(), want_img) and np.array_equal(got_lab, want_lab)
+
+
+def test_refusals():
+    with pytest.raises(NotImplementedError):
+        pdata.MosaicDetection(ToyDataset(DEV), (48, 64), cutpaste_prob=0.1)
+    with pytest.raises(NotImplementedError):
+        pdata.MosaicDetection(ToyDataset(DEV), (48, 64), perspective=0.001)
+    md = pdata.MosaicDetection(ToyDataset(None), (48, 64), preprocess=pdata.TrainTransform())   # host arrays: no CPU path
+    with pytest.raises(PlyoloError):
+        md[0]

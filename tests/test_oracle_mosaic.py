@@ -1,0 +1,96 @@
+"""oracle/mosaic.py (mosaic + random affine + mixup) against tests/golden/mosaic_samples.npz: what the reference's own
+MosaicDetection / TrainTransform return in the build container when OpenCV's calls are served by the oracle's restatements
+(tools/gen_golden.py mosaic).  Pins control flow, draw order from `random` / `numpy.random`, label arithmetic, padding and
+blending; the OpenCV pixel primitives themselves are unpinned and get structural checks here."""
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import augment as oa, mosaic as om  # noqa: E402
+
+FIX = np.load(os.path.join(ROOT, "tests", "golden", "mosaic_samples.npz"))
+CASES = {"mix": dict(mosaic_prob=1.0, mixup_prob=1.0), "nomix": dict(mosaic_prob=1.0, mixup_prob=0.0),
+         "plain": dict(mosaic_prob=0.0, mixup_prob=1.0), "coin": dict(mosaic_prob=0.5, mixup_prob=0.5)}
+
+
+class ToyDataset:
+    """The data set stored in the fixture, in the shape MosaicDetection reads."""
+
+    def __init__(self, size=(48, 64)):
+        n = len([k for k in FIX.files if k.startswith("ds_img")])
+        self.imgs = [FIX["ds_img%d" % i].copy() for i in range(n)]
+        self.annotations = [(FIX["ds_lab%d" % i].copy(), self.imgs[i].shape[:2], self.imgs[i].shape[:2], "img%d" % i) for i in range(n)]
+        self.img_size = size
+
+    def __len__(self):
+        return len(self.imgs)
+
+
+@pytest.mark.parametrize("tag", sorted(CASES))
+def test_oracle_matches_reference_samples(tag):
+    md = om.MosaicDetection(ToyDataset(), (48, 64), preprocess=oa.TrainTransform(max_labels=20, flip_prob=0.5, hsv_prob=1.0), **CASES[tag])
+    seed = int(FIX["%s_seed" % tag])
+    random.seed(seed)
+    np.random.seed(seed)
+    for k, idx in enumerate(FIX["%s_idx" % tag]):
+        img, lab, info, ids, name = md[int(idx)]
+        assert np.array_equal(np.asarray(img, dtype=np.float32), FIX["%s_%d_img" % (tag, k)]), (tag, k)
+        assert np.array_equal(np.asarray(lab, dtype=np.float32), FIX["%s_%d_labels" % (tag, k)]), (tag, k)
+        assert tuple(info) == tuple(FIX["%s_%d_info" % (tag, k)])
+        assert int(ids[0]) == int(idx)
+    assert random.random() == float(FIX["%s_state" % tag])      # same number of draws as the reference
+
+
+def test_unbuilt_augmentations_raise():
+    with pytest.raises(NotImplementedError):
+        om.MosaicDetection(ToyDataset(), (48, 64), copypaste_prob=0.5)
+
+
+def test_mosaic_coordinates_tile_the_canvas():
+    """The four quadrants meet at (xc, yc), never overlap, and each shows the part of its image nearest the centre."""
+    H, W = 48, 64
+    for (xc, yc, w, h) in [(40, 30, 64, 40), (90, 70, 30, 48), (64, 48, 64, 48), (33, 71, 50, 20)]:
+        seen = np.zeros((2 * H, 2 * W), dtype=np.int32)
+        for k in range(4):
+            (x1, y1, x2, y2), (sx1, sy1, sx2, sy2) = om.get_mosaic_coordinate(k, xc, yc, w, h, H, W)
+            assert x2 - x1 == sx2 - sx1 and y2 - y1 == sy2 - sy1
+            assert 0 <= x1 <= x2 <= 2 * W and 0 <= y1 <= y2 <= 2 * H and 0 <= sx1 <= sx2 <= w and 0 <= sy1 <= sy2 <= h
+            assert (x2 == xc if k in (0, 2) else x1 == xc) and (y2 == yc if k in (0, 1) else y1 == yc)
+            seen[y1:y2, x1:x2] += 1
+        assert seen.max() <= 1
+
+
+def test_warp_affine_structure():
+    rng = np.random.RandomState(0)
+    img = rng.randint(0, 256, (20, 30, 3)).astype(np.uint8)
+    ident = np.array([[1.0, 0, 0], [0, 1.0, 0]])
+    assert np.array_equal(om.warp_affine_u8(img, ident, (30, 20)), img)
+    # integer translation: a shifted copy, the uncovered part filled with the border value
+    out = om.warp_affine_u8(img, np.array([[1.0, 0, 5], [0, 1.0, 3]]), (30, 20), (114, 114, 114))
+    assert np.array_equal(out[3:, 5:], img[:-3, :-5]) and (out[:3] == 114).all() and (out[:, :5] == 114).all()
+    # half-pixel shift: the rounded mean of neighbouring columns (weights 16/32 each)
+    out = om.warp_affine_u8(img, np.array([[1.0, 0, 0.5], [0, 1.0, 0]]), (30, 20), (0, 0, 0))
+    want = (img[:, :-1].astype(np.int64) * 16384 + img[:, 1:].astype(np.int64) * 16384 + (1 << 14)) >> 15
+    assert np.array_equal(out[:, 1:], want.astype(np.uint8))
+    # an output larger than the source is border outside the source
+    out = om.warp_affine_u8(img, ident, (40, 25), (7, 8, 9))
+    assert np.array_equal(out[:20, :30], img) and (out[22:, :, 0] == 7).all() and (out[:, 32:, 2] == 9).all()
+    # inverse of the inverse
+    M = np.array([[0.9, -0.2, 3.0], [0.15, 1.1, -2.0]])
+    inv = om.invert_affine(M).reshape(2, 3)
+    assert np.allclose(om.invert_affine(inv).reshape(2, 3), M, atol=1e-12)
+    R = om.get_rotation_matrix_2d((0, 0), 90.0, 2.0)
+    assert np.allclose(R, [[0, 2, 0], [-2, 0, 0]], atol=1e-12)
+
+
+def test_affine_labels_keep_boxes_under_identity_and_drop_slivers():
+    t = np.array([[10.0, 10, 30, 40, 3], [5, 5, 6, 30, 1]])
+    out = om.affine_labels(t.copy(), np.eye(3), 1.0, 64, 48)
+    assert np.array_equal(out, t[:1])                        # the 1-px-wide box fails the 2-px test of box_candidates
+    M = np.eye(3); M[0, 2] = 100.0
+    assert len(om.affine_labels(t.copy(), M, 1.0, 64, 48)) == 0   # pushed out of the frame: clipped to zero width

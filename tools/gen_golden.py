@@ -692,7 +692,90 @@ def gen_cfg1():
     save("cfg1_nano416", d)
 
 
+def toy_detection_dataset(seed=5, n=7, size=(48, 64)):
+    """A tiny in-memory data set in the shape MosaicDetection reads (cocoDataset: annotations / imgs / img_size): images of
+    assorted sizes and aspect ratios, one of them without labels."""
+    rng = np.random.RandomState(seed)
+
+    class Toy:
+        pass
+    ds = Toy()
+    ds.img_size = size
+    ds.imgs, ds.annotations = [], []
+    for i in range(n):
+        h, w = int(rng.randint(24, 80)), int(rng.randint(24, 96))
+        ds.imgs.append(rng.randint(0, 256, (h, w, 3)).astype(np.uint8))
+        k = 0 if i == 3 else int(rng.randint(1, 5))
+        x1 = rng.uniform(0, w * 0.6, k); y1 = rng.uniform(0, h * 0.6, k)
+        bw = rng.uniform(4, w * 0.4, k); bh = rng.uniform(4, h * 0.4, k)
+        lab = np.stack([x1, y1, np.minimum(x1 + bw, w), np.minimum(y1 + bh, h), rng.randint(0, 80, k).astype(np.float64)], 1) if k else np.zeros((0, 5))
+        ds.annotations.append((lab.astype(np.float64), (h, w), (h, w), "img%d" % i))
+    ds.__class__.__len__ = lambda self: len(self.imgs)
+    ds.object_cls, ds.back_cls = None, None
+    return ds
+
+
+def gen_mosaic():
+    """Mosaic / random-affine / mixup samples from the REFERENCE's own MosaicDetection + TrainTransform
+    (models/data/mosaic_detection.py, models/data/augmentation/data_augments.py).  Both files `import cv2`, which cannot be
+    installed here: the import is served by a module whose resize / warpAffine / getRotationMatrix2D / cvtColor / LUT are the
+    oracle's restatements of OpenCV's 8-bit algorithms (oracle/augment.py, oracle/mosaic.py).  What the fixture therefore PINS
+    is everything the reference itself decides -- control flow, the order of the draws from `random` / `numpy.random`, label
+    arithmetic, padding, blending -- given those pixel primitives; the primitives themselves stay unpinned against cv2."""
+    import random
+    import types
+    sys.path.insert(0, ROOT)
+    from oracle import augment as oa, mosaic as om
+    cv2 = types.ModuleType("cv2")
+    cv2.INTER_LINEAR, cv2.COLOR_BGR2HSV, cv2.COLOR_HSV2BGR = 1, 40, 54
+    cv2.resize = lambda img, dsize, interpolation=1: om.resize(img, dsize)
+    cv2.warpAffine = lambda img, M, dsize=None, borderValue=(0, 0, 0): om.warp_affine_u8(img, M, dsize, borderValue)
+    cv2.getRotationMatrix2D = lambda angle=0, center=(0, 0), scale=1: om.get_rotation_matrix_2d(center, angle, scale)
+    cv2.split = lambda a: [a[..., i] for i in range(a.shape[-1])]
+    cv2.merge = lambda chans: np.stack(chans, -1)
+    cv2.LUT = lambda a, lut: lut[a]
+
+    def cvt(img, code, dst=None):
+        if code == cv2.COLOR_BGR2HSV:
+            h, s_, v = oa.bgr2hsv_u8(img)
+            return np.stack([h, s_, v], -1).astype(np.uint8)
+        out = oa.hsv2bgr_u8(img[..., 0].astype(np.int64), img[..., 1].astype(np.int64), img[..., 2].astype(np.int64))
+        if dst is not None:
+            dst[...] = out
+        return out
+    cv2.cvtColor = cvt
+    sys.modules["cv2"] = cv2
+    from models.data.mosaic_detection import MosaicDetection
+    from models.data.augmentation.data_augments import TrainTransform
+    d = {}
+    cases = [("mix", dict(mosaic_prob=1.0, mixup_prob=1.0), 11), ("nomix", dict(mosaic_prob=1.0, mixup_prob=0.0), 12),
+             ("plain", dict(mosaic_prob=0.0, mixup_prob=1.0), 13), ("coin", dict(mosaic_prob=0.5, mixup_prob=0.5), 14)]
+    for tag, kw, seed in cases:
+        ds = toy_detection_dataset()
+        md = MosaicDetection(ds, (48, 64), preprocess=TrainTransform(max_labels=20, flip_prob=0.5, hsv_prob=1.0), **kw)
+        random.seed(seed)
+        np.random.seed(seed)
+        idxs = [0, 3, 5, 2]
+        for k, idx in enumerate(idxs):
+            img, lab, info, ids, name = md[idx]
+            d["%s_%d_img" % (tag, k)] = np.asarray(img, dtype=np.float32)
+            d["%s_%d_labels" % (tag, k)] = np.asarray(lab, dtype=np.float32)
+            d["%s_%d_info" % (tag, k)] = np.asarray(info)
+        d["%s_idx" % tag] = np.asarray(idxs)
+        d["%s_seed" % tag] = np.asarray(seed)
+        d["%s_state" % tag] = np.asarray(random.random())       # the position of the `random` stream after the four samples
+    ds = toy_detection_dataset()
+    for i, (im, an) in enumerate(zip(ds.imgs, ds.annotations)):
+        d["ds_img%d" % i] = im
+        d["ds_lab%d" % i] = an[0]
+    save("mosaic_samples", d)
+    del sys.modules["cv2"]
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "mosaic":
+        gen_mosaic()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "format":
         gen_format_outputs()
         sys.exit(0)
@@ -725,4 +808,5 @@ if __name__ == "__main__":
     gen_format_outputs()
     gen_deploy()
     gen_cfg1()
+    gen_mosaic()
     gen_schedule()
