@@ -25,6 +25,10 @@
 namespace plyolo {
 // lazy-input instances (conv_mfma_pre.hip); `convp` is a ConvP
 hipError_t conv_mfma_launch_pre(const void* convp, int BN, int CK, int TH, bool out_f32, hipStream_t s);
+// weights-stationary 3x3 stride-1 kernel (conv3ws.hip)
+int conv3ws_accepts(int N, int H, int W, int Cin, int Cout, int x_ld, int y_ld, const void* y);
+hipError_t conv3ws_launch(const void* x, const void* w, void* y, double* stats, int N, int H, int W, int Cin, int Cout, int x_ld, int y_ld,
+                          int nkb, int nnb, int accumulate, unsigned long long taps_lo, unsigned taps_hi, hipStream_t s);
 }
 
 namespace {
@@ -219,6 +223,16 @@ int conv_mfma_fwd(const plyolo_conv_desc* d, const void* x, const void* wp, cons
   int BN, CK, TH;
   setup_fwd(d, p, &BN, &CK, &TH);
   const bool f32 = d->y_f32 != 0;
+  if (d->ksize == 3 && d->stride == 1 && !f32 && !p.pre && !bias && !ep_coef && !ep_res && !p.ablate &&
+      conv3ws_accepts(p.N, p.H, p.W, p.Cin, p.Cout, p.x_ld, p.y_ld, y)) {
+    char lab[64];
+    snprintf(lab, sizeof(lab), "conv3ws_fwd<Cin%d,Cout%d>", p.Cin, p.Cout);
+    const double M = (double)p.N * p.OHf * p.OWf;
+    annotate(lab, 2.0 * M * d->Cout * d->Cin * 9.0, M * d->Cout * 2.0 + (double)d->N * d->H * d->W * d->Cin * 2.0);
+    return submit(stream, [=](hipStream_t s) {
+      return conv3ws_launch(p.x, p.w, p.y, p.stats, p.N, p.H, p.W, p.Cin, p.Cout, p.x_ld, p.y_ld, p.nkb, p.nnb, 0, p.taps_lo, p.taps_hi, s);
+    });
+  }
   {
     char lab[64];
     snprintf(lab, sizeof(lab), "conv_mfma_fwd<BN%d,CK%d,TH%d>%s%s", BN, CK, TH, f32 ? "f32out" : "", p.pre ? "+bnact" : "");
@@ -267,6 +281,15 @@ int conv_mfma_dgrad(const plyolo_conv_desc* d, const void* dy, const void* wpd, 
         p.tap_w[t] = (signed char)((d->ksize - 1 - dy_) * d->ksize + (d->ksize - 1 - dx_));
       }
     finish(p, d->ksize, d->ksize, false, &BN, &CK, &TH);
+    if (d->ksize == 3 && !p.ablate && conv3ws_accepts(p.N, p.H, p.W, p.Cin, p.Cout, p.x_ld, p.y_ld, dx)) {
+      char lab[64];
+      snprintf(lab, sizeof(lab), "conv3ws_dgrad<Cin%d,Cout%d>", p.Cin, p.Cout);
+      const double Mo = (double)d->N * OH * OW, Mi = (double)d->N * d->H * d->W;
+      annotate(lab, 2.0 * Mo * d->Cout * d->Cin * 9.0, (Mo * Kc + Mi * d->Cin * (accumulate ? 2.0 : 1.0)) * 2.0);
+      return submit(stream, [=](hipStream_t s) {
+        return conv3ws_launch(p.x, p.w, p.y, nullptr, p.N, p.H, p.W, p.Cin, p.Cout, p.x_ld, p.y_ld, p.nkb, p.nnb, p.accumulate, p.taps_lo, p.taps_hi, s);
+      });
+    }
     {
       char lab[64];
       snprintf(lab, sizeof(lab), "conv_mfma_dgrad<BN%d,CK%d,TH%d>", BN, CK, TH);

@@ -233,3 +233,12 @@ def test_conv_fwd_fused_bn_act_inference(shape, with_res):
     err = hu.relerr(hu.from_nhwc(y, N, OH, OW, Cout), ref)
     assert err <= 2.0 ** -6, err
     assert torch.all(y[:, Cout:].float() == 3.0)
+
+
+@pytest.mark.parametrize("shape", [s for s in SHAPES if s[5] == 3 and s[6] == 1 and s[3] % 16 == 0 and s[3] <= 128] + [(3, 20, 20, 128, 40, 3, 1), (2, 13, 29, 16, 104, 3, 1)], ids=str)
+def test_conv3ws_opt_in_kernel(shape, monkeypatch):
+    """The weights-stationary 3x3 kernel (csrc/conv3ws.hip, PLYOLO_CONV3WS=1, off by default): forward + BatchNorm statistics
+    and the data gradient (overwrite and accumulate) on every 3x3 stride-1 shape it accepts, ragged maps included."""
+    monkeypatch.setenv("PLYOLO_CONV3WS", "1")
+    test_conv_fwd_stats(BF16, shape)
+    test_conv_dgrad(BF16, shape)
