@@ -347,6 +347,17 @@ int plyolo_bn_act_bwd_dz(int dtype, int M, int C, const void* dout, int d_ld, co
                          float* dbeta, int accumulate, int act, void* dz, int dz_ld,
                          const plyolo_split* dout_split, const plyolo_bn_bwd_split* par2, void* stream);
 
+/* norm = "ln" of BaseConv (reference models/layers/normalization.py:9-10): nn.LayerNorm(out_channels) on an NCHW tensor
+ * normalises the last axis, the image WIDTH, with affine parameters gamma[W], beta[W] (torch requires W == out_channels), eps
+ * inside the square root, biased variance; the activation of BaseConv follows.  x / out / dout / dx are [N*H*W, ld] NHWC
+ * matrices of C channels; stats [N*H*C][2] fp32 (mean, 1/std of every line) is written by the forward and read by the backward.
+ * The backward writes (or accumulates into) dx and the fp32 parameter gradients; its sums run in a fixed order. */
+int plyolo_lnw_act_fwd(int dtype, int N, int H, int W, int C, const void* x, int x_ld, const float* gamma, const float* beta, float eps, int act,
+                       void* out, int o_ld, float* stats, void* stream);
+int plyolo_lnw_act_bwd(int dtype, int N, int H, int W, int C, const void* dout, int d_ld, const void* x, int x_ld, const float* stats,
+                       const float* gamma, const float* beta, int act, void* dx, int dx_ld, int accumulate_dx, float* dgamma, float* dbeta,
+                       int accumulate_params, void* stream);
+
 /* -------------------------------------------------- data movement kernels */
 /* Focus space-to-depth (network_blocks.py:50-65): NCHW fp32 image ->
  * NHWC [N,H/2,W/2,Cp] with channel blocks TL,BL,TR,BR (3 each) then zero pad. */

@@ -153,6 +153,8 @@ SIGNATURES = {
     "plyolo_bias_grad": (_i, [_i, _vp, _i, _i, _i, _vp, _vp]),
     "plyolo_pack_weights": (_i, [_vp, _i, _i, _i, _vp]),
     "plyolo_reduce_slabs": (_i, [_vp, _i, _sz, _vp]),
+    "plyolo_lnw_act_fwd": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _f, _i, _vp, _i, _vp, _vp]),
+    "plyolo_lnw_act_bwd": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _vp]),
     "plyolo_mosaic4": (_i, [_vp, _i, _i, _vp, _vp]),
     "plyolo_warp_affine_u8": (_i, [_vp, _i, _i, _P(_d), _vp, _i, _i, _i, _vp]),
     "plyolo_resize_pad_u8": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),

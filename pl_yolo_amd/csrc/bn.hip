@@ -403,6 +403,11 @@ __global__ void bias_coef_kernel(int C, const float* bias, float* coef) {
 }
 
 // 256 CUs x 4 workgroups; every workgroup re-reads the stat slots, so keep the grid bounded
+inline unsigned grid_lines(size_t lines) {
+  size_t g = (lines + 255) / 256;
+  return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
 inline int stream_grid(int M, int cvn) {
   const int cols = cvn < 256 ? cvn : 256, rpb = 256 / cols;
   int g = (M + rpb - 1) / rpb;
@@ -412,6 +417,97 @@ inline int stream_grid(int M, int cvn) {
   const int cap = cap_env > 0 ? cap_env : ((double)M * cvn * 16.0 >= 48.0e6 ? 2048 : 1024);
   if (g > cap) g = cap;
   return g < 1 ? 1 : g;
+}
+
+// ---- norm = "ln" of BaseConv: nn.LayerNorm(out_channels) applied to an NCHW tensor (reference models/layers/normalization.py:9-10)
+// normalises the LAST axis -- the image WIDTH -- with affine parameters indexed by the column x (torch requires
+// W == out_channels).  In the NHWC storage of this library: for every (image, row, channel) the W values x[n, y, :, c].
+// One thread per (n, y, c) line (adjacent threads = adjacent channels: coalesced), fp32 statistics kept for the backward.
+template <typename T>
+__global__ void lnw_act_fwd_kernel(int N, int H, int W, int C, const T* __restrict__ x, int x_ld, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float eps, int act, T* __restrict__ out, int o_ld, float* __restrict__ stats) {
+  const size_t lines = (size_t)N * H * C;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < lines; idx += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % C);
+    const size_t row = idx / C;               // n * H + y
+    const T* xp = x + row * W * (size_t)x_ld + c;
+    float s = 0.f;
+    for (int w = 0; w < W; ++w) s += ActT<T>::ld(xp + (size_t)w * x_ld);
+    const float mean = s / (float)W;
+    float v = 0.f;
+    for (int w = 0; w < W; ++w) { const float d = ActT<T>::ld(xp + (size_t)w * x_ld) - mean; v = fmaf(d, d, v); }
+    const float rstd = 1.0f / sqrtf(v / (float)W + eps);
+    stats[2 * idx] = mean;
+    stats[2 * idx + 1] = rstd;
+    T* op = out + row * W * (size_t)o_ld + c;
+    for (int w = 0; w < W; ++w) {
+      const float u = fmaf((ActT<T>::ld(xp + (size_t)w * x_ld) - mean) * rstd, gamma[w], beta[w]);
+      ActT<T>::st(op + (size_t)w * o_ld, act_fwd_precise(u, act));
+    }
+  }
+}
+
+// dx of the same lines: du = dout * act'(u); g = du * gamma[w]; dx = rstd * (g - mean_w(g) - xhat * mean_w(g * xhat))
+template <typename T>
+__global__ void lnw_act_bwd_dx_kernel(int N, int H, int W, int C, const T* __restrict__ dout, int d_ld, const T* __restrict__ x, int x_ld,
+                                      const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta, int act,
+                                      T* __restrict__ dx, int dx_ld, int accumulate) {
+  const size_t lines = (size_t)N * H * C;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < lines; idx += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % C);
+    const size_t row = idx / C;
+    const T* xp = x + row * W * (size_t)x_ld + c;
+    const T* dp = dout + row * W * (size_t)d_ld + c;
+    const float mean = stats[2 * idx], rstd = stats[2 * idx + 1];
+    float s1 = 0.f, s2 = 0.f;
+    for (int w = 0; w < W; ++w) {
+      const float xh = (ActT<T>::ld(xp + (size_t)w * x_ld) - mean) * rstd;
+      const float g = ActT<T>::ld(dp + (size_t)w * d_ld) * act_grad<true>(fmaf(xh, gamma[w], beta[w]), act) * gamma[w];
+      s1 += g;
+      s2 = fmaf(g, xh, s2);
+    }
+    s1 /= (float)W;
+    s2 /= (float)W;
+    T* op = dx + row * W * (size_t)dx_ld + c;
+    for (int w = 0; w < W; ++w) {
+      const float xh = (ActT<T>::ld(xp + (size_t)w * x_ld) - mean) * rstd;
+      const float g = ActT<T>::ld(dp + (size_t)w * d_ld) * act_grad<true>(fmaf(xh, gamma[w], beta[w]), act) * gamma[w];
+      float r = rstd * (g - s1 - xh * s2);
+      if (accumulate) r += ActT<T>::ld(op + (size_t)w * dx_ld);
+      ActT<T>::st(op + (size_t)w * dx_ld, r);
+    }
+  }
+}
+
+// dgamma[w] = sum over lines of du * xhat, dbeta[w] = sum of du: one workgroup per column w, fixed summation order (deterministic)
+template <typename T>
+__global__ __launch_bounds__(256) void lnw_act_bwd_params_kernel(int N, int H, int W, int C, const T* __restrict__ dout, int d_ld,
+                                                                const T* __restrict__ x, int x_ld, const float* __restrict__ stats,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta, int act,
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
+  const int w = blockIdx.x;
+  const size_t lines = (size_t)N * H * C;
+  const float gw = gamma[w], bw = beta[w];
+  double a = 0.0, b = 0.0;
+  for (size_t idx = threadIdx.x; idx < lines; idx += 256) {
+    const int c = (int)(idx % C);
+    const size_t row = idx / C;
+    const float xh = (ActT<T>::ld(x + (row * W + w) * (size_t)x_ld + c) - stats[2 * idx]) * stats[2 * idx + 1];
+    const float du = ActT<T>::ld(dout + (row * W + w) * (size_t)d_ld + c) * act_grad<true>(fmaf(xh, gw, bw), act);
+    a += (double)du * xh;
+    b += (double)du;
+  }
+  __shared__ double ra[256], rb[256];
+  ra[threadIdx.x] = a; rb[threadIdx.x] = b;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) { ra[threadIdx.x] += ra[threadIdx.x + st]; rb[threadIdx.x] += rb[threadIdx.x + st]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    dgamma[w] = (accumulate ? dgamma[w] : 0.f) + (float)ra[0];
+    dbeta[w] = (accumulate ? dbeta[w] : 0.f) + (float)rb[0];
+  }
 }
 
 }  // namespace
@@ -593,6 +689,35 @@ int plyolo_bn_act_bwd_dz(int dtype, int M, int C, const void* dout, int d_ld, co
       auto kern = act == PLYOLO_ACT_SILU ? bn_act_bwd_dz_kernel<T, PLYOLO_ACT_SILU> : bn_act_bwd_dz_kernel<T, -1>;
       hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, M, C, (const T*)dout, d_ld, (const T*)z, z_ld, coef, bslots, count, gamma, dgamma,
                          dbeta, accumulate, act, (T*)dz, dz_ld, sp, p2);
+    })
+    return hipGetLastError();
+  });
+}
+
+int plyolo_lnw_act_fwd(int dtype, int N, int H, int W, int C, const void* x, int x_ld, const float* gamma, const float* beta, float eps, int act,
+                       void* out, int o_ld, float* stats, void* stream) {
+  PLY_CHECK_ARG(x && out && gamma && beta && stats && N > 0 && H > 0 && W > 0 && C > 0 && x_ld >= C && o_ld >= C, "lnw_act_fwd: bad arguments");
+  const size_t lines = (size_t)N * H * C;
+  plyolo::annotate("lnw_act_fwd", 0.0, (double)lines * W * (dtype == PLYOLO_BF16 ? 2.0 : 4.0) * 2.0);
+  return submit(stream, [=](hipStream_t s) -> hipError_t {
+    DISPATCH_T(dtype, hipLaunchKernelGGL(lnw_act_fwd_kernel<T>, dim3(grid_lines(lines)), dim3(256), 0, s, N, H, W, C, (const T*)x, x_ld, gamma, beta, eps,
+                                         act, (T*)out, o_ld, stats);)
+    return hipGetLastError();
+  });
+}
+
+int plyolo_lnw_act_bwd(int dtype, int N, int H, int W, int C, const void* dout, int d_ld, const void* x, int x_ld, const float* stats,
+                       const float* gamma, const float* beta, int act, void* dx, int dx_ld, int accumulate_dx, float* dgamma, float* dbeta,
+                       int accumulate_params, void* stream) {
+  PLY_CHECK_ARG(dout && x && stats && gamma && beta && dx && dgamma && dbeta && N > 0 && H > 0 && W > 0 && C > 0, "lnw_act_bwd: bad arguments");
+  const size_t lines = (size_t)N * H * C;
+  plyolo::annotate("lnw_act_bwd", 0.0, (double)lines * W * (dtype == PLYOLO_BF16 ? 2.0 : 4.0) * 5.0);
+  return submit(stream, [=](hipStream_t s) -> hipError_t {
+    DISPATCH_T(dtype, {
+      hipLaunchKernelGGL(lnw_act_bwd_params_kernel<T>, dim3(W), dim3(256), 0, s, N, H, W, C, (const T*)dout, d_ld, (const T*)x, x_ld, stats, gamma, beta,
+                         act, dgamma, dbeta, accumulate_params);
+      hipLaunchKernelGGL(lnw_act_bwd_dx_kernel<T>, dim3(grid_lines(lines)), dim3(256), 0, s, N, H, W, C, (const T*)dout, d_ld, (const T*)x, x_ld, stats,
+                         gamma, beta, act, (T*)dx, dx_ld, accumulate_dx);
     })
     return hipGetLastError();
   });

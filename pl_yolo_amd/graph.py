@@ -987,6 +987,37 @@ class BnOnlyOp:
         call("plyolo_copy_add", g.dtype, M, Cc, dz, Cc, g.gptr(x), x.ld, acc, None)
 
 
+class LnWidthOp:
+    """norm = "ln" of BaseConv: nn.LayerNorm(out_channels) over the WIDTH of the conv output, then the activation
+    (reference models/layers/normalization.py:9-10, network_blocks.py:36-37).  torch applies LayerNorm((C,)) to the last axis of
+    an NCHW tensor, so it only runs when W == C; the same condition is checked here with torch's error."""
+
+    def __init__(self, g, x, ln, act):
+        if x.W != ln.normalized_shape[0] or len(ln.normalized_shape) != 1:
+            raise RuntimeError("Given normalized_shape=%s, expected input with shape [*, %d], but got input of size [%d, %d, %d, %d]"
+                               % (list(ln.normalized_shape), ln.normalized_shape[0], x.N, x.C, x.H, x.W))
+        self.g, self.x, self.ln, self.act = g, x, ln, ACT[act]
+        self.bn = ln            # the attribute the runner / the bucket schedule read the affine parameters from
+        x.needs_tensor = True
+        self.out = g.new_act(x.N, x.H, x.W, x.C, "ln")
+        g.add_op(self)
+
+    def fwd(self):
+        g, x, ln = self.g, self.x, self.ln
+        if not hasattr(self, "stats"):
+            self.stats = torch.empty(x.N * x.H * x.C * 2, dtype=torch.float32, device=g.device)
+        call("plyolo_lnw_act_fwd", g.dtype, x.N, x.H, x.W, x.C, g.aptr(x), x.ld, ptr(ln.weight), ptr(ln.bias), float(ln.eps), self.act,
+             g.aptr(self.out), self.out.ld, self.stats.data_ptr(), None)
+
+    def bwd(self):
+        g, x, ln = self.g, self.x, self.ln
+        if not g.grad_ready(self.out):
+            return
+        acc = g.grad_mode(x)
+        call("plyolo_lnw_act_bwd", g.dtype, x.N, x.H, x.W, x.C, g.gptr(self.out), self.out.ld, g.aptr(x), x.ld, self.stats.data_ptr(),
+             ptr(ln.weight), ptr(ln.bias), self.act, g.gptr(x), x.ld, acc, g.grad_ptr_of(ln.weight), g.grad_ptr_of(ln.bias), 0, None)
+
+
 class UpsampleOp:
     def __init__(self, g, x):
         self.g, self.x = g, x

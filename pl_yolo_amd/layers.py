@@ -33,7 +33,7 @@ def get_normalization(name, out_channels):
     if name == "bn":
         return nn.BatchNorm2d(out_channels, eps=1e-3, momentum=0.03)
     if name == "ln":
-        raise NotImplementedError("norm 'ln' has no HIP kernel (unused by the YOLOX/YOLOv7 configs)")
+        return nn.LayerNorm(out_channels)     # over the LAST axis of the NCHW tensor, i.e. the width (G.LnWidthOp)
     raise AttributeError("Unsupported normalization function type: {}".format(name))
 
 
@@ -69,6 +69,11 @@ class BaseConv(HipModule):
             if self.norm is None:
                 raise NotImplementedError("depthwise BaseConv without BatchNorm (fold it back or keep norm='bn')")
             return G.DwConvUnitOp(g, x, self.conv.weight, self.norm, act, residual).out
+        if isinstance(self.norm, nn.LayerNorm):
+            if residual is not None:
+                raise NotImplementedError("a shortcut on a BaseConv with norm='ln'")
+            z = G.ConvUnitOp(g, x, self.conv.weight, None, None, self.stride, None, need_dgrad, cin_pad, conv_b=self.conv.bias).out
+            return G.LnWidthOp(g, z, self.norm, act).out
         op = G.ConvUnitOp(g, x, self.conv.weight, self.norm, act, self.stride, residual, need_dgrad, cin_pad, conv_b=self.conv.bias)
         return op.out
 

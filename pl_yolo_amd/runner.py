@@ -205,7 +205,7 @@ class DetectorRunner:
                 s.sched.install(s.bwd)
             seen = set()
             for op in g.ops:
-                bns = [op.bn] if isinstance(op, (G.ConvUnitOp, G.BnOnlyOp, G.DwConvUnitOp)) else ([op.bn_a, op.bn_b] if isinstance(op, G.ConvPairOp) else [])
+                bns = [op.bn] if isinstance(op, (G.ConvUnitOp, G.BnOnlyOp, G.DwConvUnitOp, G.LnWidthOp)) else ([op.bn_a, op.bn_b] if isinstance(op, G.ConvPairOp) else [])
                 if isinstance(op, G.DwConvUnitOp) and id(op.w) not in seen:    # depthwise weights: no pack entry, gradient written directly
                     seen.add(id(op.w))
                     s.used_params.append(op.w)

@@ -190,3 +190,40 @@ def test_baseconv_hswish_gelu_vs_torch(act, dtype):
     assert hu.relerr(grads["conv.weight"], w.grad) <= (6e-2 if dtype == "bf16" else 5e-4)
     assert hu.relerr(grads["norm.weight"], gw.grad) <= (6e-2 if dtype == "bf16" else 5e-4)
     assert hu.relerr(grads["norm.bias"], gb.grad) <= (6e-2 if dtype == "bf16" else 5e-4)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("act", ["silu", "lrelu"])
+def test_baseconv_layernorm_over_width_vs_torch(act, dtype):
+    """norm="ln" (models/layers/normalization.py:9-10): nn.LayerNorm(out_channels) on the NCHW conv output normalises the WIDTH axis
+    (torch requires W == out_channels).  BaseConv(norm="ln") forward + backward through the launch plans against
+    conv2d -> F.layer_norm -> activation in plain PyTorch fp32; a width != out_channels raises torch's error."""
+    from pl_yolo_amd.layers import BaseConv
+    torch.manual_seed(9)
+    Cout, Wd = 24, 24
+    m = BaseConv(16, Cout, 3, 1, norm="ln", act=act).to(hu.DEV).train()
+    with torch.no_grad():
+        m.norm.weight.uniform_(0.5, 1.5)
+        m.norm.bias.uniform_(-0.5, 0.5)
+    gen = torch.Generator().manual_seed(10)
+    x = (torch.randn(2, 16, 10, Wd, generator=gen) * 2).to(hu.DEV)
+    r = torch.randn(2, Cout, 10, Wd, generator=gen).to(hu.DEV)
+    if dtype == "bf16":
+        x = hu.rnd_bf16(x)
+    w = m.conv.weight.detach().clone().requires_grad_(True)
+    gw = m.norm.weight.detach().clone().requires_grad_(True)
+    gb = m.norm.bias.detach().clone().requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    z = F.conv2d(xr, hu.rnd_bf16(w) if dtype == "bf16" else w, None, 1, 1)
+    u = F.layer_norm(z, (Wd,), gw, gb, 1e-5)
+    y_ref = F.silu(u) if act == "silu" else F.leaky_relu(u, 0.1)
+    (y_ref * r).sum().backward()
+    y, dx, grads = run_block(m, x, dtype, training=True, r=r)
+    e = [hu.relerr(y, y_ref), hu.relerr(dx, xr.grad), hu.relerr(grads["conv.weight"], w.grad), hu.relerr(grads["norm.weight"], gw.grad),
+         hu.relerr(grads["norm.bias"], gb.grad)]
+    print("ln", act, dtype, " ".join("%.3g" % v for v in e))
+    tol = [2e-2, 6e-2, 6e-2, 3e-2, 3e-2] if dtype == "bf16" else [2e-5, 2e-4, 5e-4, 2e-4, 2e-4]
+    assert all(a <= b for a, b in zip(e, tol)), e
+    bad = BaseConv(16, 20, 3, 1, norm="ln", act=act).to(hu.DEV)
+    with pytest.raises(RuntimeError):
+        run_block(bad, x, dtype)
