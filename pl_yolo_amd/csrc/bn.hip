@@ -109,7 +109,7 @@ struct ColMap {
 // ACTC: the activation as a compile-time constant (SiLU, the one every shipped config uses) or -1 = the runtime `act`.
 // The runtime switch makes the compiler budget registers for its heaviest branch (GELU: erff + expf) in EVERY launch:
 // with hswish / gelu added, bn_act_bwd_dz went from 79 to 85 VGPRs and lost a wave per SIMD until SiLU got its own instance.
-template <typename T, bool FUSED, int ACTC = -1>
+template <typename T, bool FUSED, int ACTC = -1, int UNR = 2>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(int M, int C, const T* __restrict__ z, int z_ld, float* coef, int act_rt,
                                                          const T* __restrict__ res, int r_ld, T* __restrict__ out, int o_ld,
                                                          plyolo_bn_stats st, plyolo_split sp) {
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(int M, int C, const T* 
       if (FUSED) { sc[i] = s_co[c + i]; sh[i] = s_co[C + c + i]; }
       else { sc[i] = coef ? coef[c + i] : 1.f; sh[i] = coef ? coef[C + c + i] : 0.f; }
     }
-#pragma unroll 2
+#pragma unroll UNR
     for (int m = blockIdx.x * cm.rpb + cm.trow; m < M; m += step) {
       float f[V], r[V];
       Vec<T>::load(z + (size_t)m * z_ld + c, f);
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(int M, int C, co
   }
 }
 
-template <typename T, int ACTC = -1>
+template <typename T, int ACTC = -1, int UNR = 2>
 __global__ __launch_bounds__(256) void bn_act_bwd_dz_kernel(int M, int C, const T* __restrict__ dout, int d_ld, const T* __restrict__ z,
                                                             int z_ld, const float* __restrict__ coef, const double* __restrict__ bslots,
                                                             double count, const float* gamma, float* dgamma, float* dbeta,
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_dz_kernel(int M, int C, const 
     const bool second = sp.split > 0 && c >= sp.split;
     const T* db = second ? (const T*)sp.p2 + (c - sp.split) : dout + c;
     const int dl = second ? sp.ld2 : d_ld;
-#pragma unroll 2
+#pragma unroll UNR
     for (int m = blockIdx.x * cm.rpb + cm.trow; m < M; m += step) {
       float d[V], zz[V];
       Vec<T>::load(db + (size_t)m * dl, d);
@@ -403,6 +403,11 @@ __global__ void bias_coef_kernel(int C, const float* bias, float* coef) {
 }
 
 // 256 CUs x 4 workgroups; every workgroup re-reads the stat slots, so keep the grid bounded
+inline int bn_unr() {
+  static const int u = getenv("PLYOLO_BN_UNR") ? atoi(getenv("PLYOLO_BN_UNR")) : 2;
+  return u;
+}
+
 inline unsigned grid_lines(size_t lines) {
   size_t g = (lines + 255) / 256;
   return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
@@ -610,7 +615,8 @@ int plyolo_bn_act_fwd(int dtype, int M, int C, const void* z, int z_ld, float* c
   plyolo::annotate("bn_act_fwd", 0.0, (double)M * C * (dtype == PLYOLO_BF16 ? 2.0 : 4.0) * (res ? 3.0 : 2.0));
   return submit(stream, [=](hipStream_t s) -> hipError_t {
     DISPATCH_T(dtype, {
-      auto kern = fused ? (act == PLYOLO_ACT_SILU ? bn_act_fwd_kernel<T, true, PLYOLO_ACT_SILU> : bn_act_fwd_kernel<T, true, -1>)
+      auto kern = fused ? (act == PLYOLO_ACT_SILU ? (bn_unr() == 4 ? bn_act_fwd_kernel<T, true, PLYOLO_ACT_SILU, 4> : bn_act_fwd_kernel<T, true, PLYOLO_ACT_SILU>)
+                                                  : bn_act_fwd_kernel<T, true, -1>)
                         : (act == PLYOLO_ACT_SILU ? bn_act_fwd_kernel<T, false, PLYOLO_ACT_SILU> : bn_act_fwd_kernel<T, false, -1>);
       hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, M, C, (const T*)z, z_ld, coef, act, (const T*)res, r_ld, (T*)out, o_ld, st, sp);
     })
@@ -688,7 +694,8 @@ int plyolo_bn_act_bwd_dz(int dtype, int M, int C, const void* dout, int d_ld, co
   plyolo::annotate("bn_act_bwd_dz", 0.0, (double)M * C * (dtype == PLYOLO_BF16 ? 2.0 : 4.0) * 3.0);
   return submit(stream, [=](hipStream_t s) -> hipError_t {
     DISPATCH_T(dtype, {
-      auto kern = act == PLYOLO_ACT_SILU ? bn_act_bwd_dz_kernel<T, PLYOLO_ACT_SILU> : bn_act_bwd_dz_kernel<T, -1>;
+      auto kern = act == PLYOLO_ACT_SILU ? (bn_unr() == 4 ? bn_act_bwd_dz_kernel<T, PLYOLO_ACT_SILU, 4> : bn_act_bwd_dz_kernel<T, PLYOLO_ACT_SILU>)
+                                         : bn_act_bwd_dz_kernel<T, -1>;
       hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, M, C, (const T*)dout, d_ld, (const T*)z, z_ld, coef, bslots, count, gamma, dgamma,
                          dbeta, accumulate, act, (T*)dz, dz_ld, sp, p2);
     })
