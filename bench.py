@@ -320,7 +320,7 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
-    loss = float(out["loss"])
+    loss = float(out["loss"].detach())
     ms_step = dt * 1e3 / args.steps
     value = world * args.batch * args.steps / dt
 
