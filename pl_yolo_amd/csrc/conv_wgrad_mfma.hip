@@ -635,6 +635,7 @@ static WgPlan plan_wgrad(const plyolo_conv_desc* d) {
   if ((double)d->ksize * d->ksize * d->Cin * d->Cout / (double)(d->Cin + d->Cout) >= 1300.0) budget = 40.0e6;
   if (const char* e = getenv("PLYOLO_WG_BUDGET_MB")) { const double v = atof(e); if (v >= 1.0) budget = v * 1.0e6; }
   if (w.id == 0 && w.trs == 1) if (const char* e = getenv("PLYOLO_WG_BUDGET0_MB")) { const double v = atof(e); if (v >= 1.0) budget = v * 1.0e6; }
+  if (d->ksize == 1) if (const char* e = getenv("PLYOLO_WG_BUDGET1_MB")) { const double v = atof(e); if (v >= 1.0) budget = v * 1.0e6; }   // 1x1 layers only
   const int s_budget = (int)(budget / (dw_bytes * w.WK));
   if (S > s_budget) S = s_budget;
   // the 3x3 variants hold 144 accumulator registers: one workgroup per CU, a 257th would wait for a whole first round
