@@ -124,3 +124,59 @@ def test_rccl_allreduce_bucket_through_the_c_abi():
     assert b"null communicator" in lib.plyolo_last_error()
     rccl.ncclCommDestroy.argtypes = [C.c_void_p]
     rccl.ncclCommDestroy(comm)
+
+
+def test_two_processes_one_gpu_gloo(tmp_path, monkeypatch):
+    """TWO ranks (two processes sharing cuda:0, gloo for the exchange): the only multi-process run of the bucketed backward
+    this pool allows.  Ranks start from different weights and see different batches; after attach() + two steps both must
+    hold rank 0's weights and bit-identical gradients equal to the mean of the two single-process gradients."""
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", PLYOLO_BUCKET_MB="0.02")
+    procs = []
+    for r in range(2):
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ddp_two_rank_worker.py"), str(tmp_path / ("r%d.npz" % r)), "2"],
+                                      env=dict(env, RANK=str(r)), cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=240)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("the two-rank run did not finish in 240 s (a rank is waiting for a collective the other never issued)")
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-2000:] for o in outs)
+    a, b = np.load(tmp_path / "r0.npz"), np.load(tmp_path / "r1.npz")
+    assert int(a["buckets"]) >= 3 and int(a["hooks"]) == int(a["buckets"]) == int(b["buckets"])
+    gkeys = [k for k in a.files if k.startswith("g/")]
+    assert gkeys and set(a.files) == set(b.files)
+    for k in a.files:
+        if k.startswith("w/") or k.startswith("g/"):
+            assert np.array_equal(a[k], b[k]), k                      # same weights (rank 0's), same averaged gradients
+    # the single-process gradients of the two batches, from rank 0's initial weights
+    monkeypatch.setenv("PLYOLO_BUCKET_MB", "0.02")
+    with open(os.path.join(ROOT, "configs", "model", "yolox", "yolox_test.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    grads = []
+    for r in range(2):
+        torch.manual_seed(96)
+        model = pl_yolo_amd.build_model(cfg, 3)
+        model.compute_dtype = "bf16"
+        model = model.to(hu.DEV).train()
+        imgs, labels = odet.synthetic_batch(2, 64, 3, num_gt=3, max_gt=6, seed=5 + r)
+        for _ in range(2):
+            out = model(imgs.to(hu.DEV), labels.to(hu.DEV))
+            model.zero_grad(set_to_none=True)
+            out["loss"].backward()
+        torch.cuda.synchronize()
+        grads.append({n: p.grad.detach().float().cpu().numpy() for n, p in model.named_parameters() if p.grad is not None})
+        if r == 0:
+            for n, p in model.named_parameters():
+                assert np.array_equal(a["w/" + n], p.detach().float().cpu().numpy()), n
+    for n in grads[0]:
+        want = (grads[0][n] + grads[1][n]) * np.float32(0.5)
+        assert np.array_equal(a["g/" + n], want), n
