@@ -171,9 +171,10 @@ class BucketSchedule:
         for op in [o for o in self.post_left if (o.index if o.region is None else min(q.index for q in o.region.ops)) >= done_idx]:
             op.post_unpack()
             self.post_left.remove(op)
-        if ready:
+        dbg = int(os.environ.get("PLYOLO_DDP_DBG", "0"))   # diagnostics: 1 no comm lane at all, 2 comm lane waits only for the wgrad lane
+        if ready and dbg != 1:
             evs = [plan.record(wl)]
-            if wl != 0:
+            if wl != 0 and dbg != 2:
                 evs.append(plan.record(0))       # BatchNorm / bias gradients are written on the main lane
             plan.lane(COMM_LANE)
             for ev in evs:

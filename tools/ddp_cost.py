@@ -44,7 +44,7 @@ def run(mode):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 40 * 1e3
     nb = len(host) // 40 if host else 0
-    print("%-6s %.3f ms/step  buckets %d  host time inside the hooks %.3f ms/step" % (mode, dt, nb, sum(host) / 40 * 1e3))
+    print("DBG=%s " % os.environ.get("PLYOLO_DDP_DBG", "0") + "%-6s %.3f ms/step  buckets %d  host time inside the hooks %.3f ms/step" % (mode, dt, nb, sum(host) / 40 * 1e3))
     r = model.runner()
     sess = [v for k, v in r.sessions.items() if k[4] == "train"][0]
     st = torch.cuda.current_stream().cuda_stream
@@ -66,5 +66,9 @@ COMM = C.c_void_p()
 rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
 assert rccl.ncclCommInitRank(C.byref(COMM), 1, uid, 0) == 0
 assert _lib.lib().plyolo_rccl_set_library(path.encode()) == 0
-run("plain"); run("noop"); run("real"); run("native"); run("plain"); run("real"); run("native")
+for rep in range(2):
+    os.environ["PLYOLO_DDP_DBG"] = "0"; run("plain"); run("noop")
+    os.environ["PLYOLO_DDP_DBG"] = "1"; run("noop")
+    os.environ["PLYOLO_DDP_DBG"] = "2"; run("noop")
+os.environ["PLYOLO_DDP_DBG"] = "0"
 dist.destroy_process_group()
