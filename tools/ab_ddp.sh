@@ -6,5 +6,4 @@ for i in 1 2 3; do
   python bench.py --no-cpu-baseline --steps 60 2>/dev/null | run "plain                                   "
   ddp "one-rank DDP                            "
   PLYOLO_DDP_DBG=1 ddp "DBG=1: no communication lane            "
-  PLYOLO_DDP_DBG=3 ddp "DBG=3: + one unpack at the end          "
 done
