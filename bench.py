@@ -289,7 +289,7 @@ def main():
     model = model.to(dev).train()
     runner = model.runner()
     runner.use_graph = True if args.graph else (False if args.no_graph else "auto")
-    if ddp_on:
+    if ddp_on and os.environ.get("PLYOLO_BENCH_PG_ONLY", "0") != "1":   # PG_ONLY: process group up, no data-parallel schedule (diagnostics)
         from pl_yolo_amd import ddp
         ddp.FORCE_COLLECTIVE = world == 1
         ddp.attach(model)
