@@ -21,7 +21,9 @@ import os
 import sys
 import time
 
-import torch
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")   # before the HIP runtime starts: see pl_yolo_amd/__init__.py (3 hardware queues: -2.5 % step time)
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

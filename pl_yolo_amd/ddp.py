@@ -6,7 +6,8 @@ over xGMI (torch.distributed backend "nccl" is RCCL on ROCm; "gloo" is used by t
 The exchange is bucketed and overlapped with the backward plan:
   * the flat gradient buffer holds the live parameters in `model.parameters()` order (dead Bottleneck.bn pairs behind
     them, never exchanged); it is cut from the END -- the head, whose gradients are complete first -- into buckets of
-    ~25 MB (PLYOLO_BUCKET_MB).  xGMI is point-to-point: few large collectives beat many small ones;
+    ~25 MB (PLYOLO_BUCKET_MB), plus one small bucket (PLYOLO_BUCKET_TAIL_MB, 1 MB) for the first backbone layers, the last to
+    finish.  xGMI is point-to-point: few large collectives beat many small ones;
   * a bucket is READY when the backward of every layer owning one of its parameters has been recorded.  At that point
     the backward plan hands the weight-gradient work queued so far to its lane, unpacks the finished weight-gradient
     slabs into the flat buffer there, and records a HOST HOOK on a communication lane that waits for both lanes
@@ -24,34 +25,60 @@ from . import graph as G
 from ._lib import call, PlyoloError
 
 FORCE_COLLECTIVE = False   # self-test: issue the collectives even in a one-rank group (bench.py PLYOLO_BENCH_FORCE_DDP)
-COMM_LANE = 5              # plan lane of the exchange (0 main, 1 weight gradients, 2.. head levels)
+DEFER = os.environ.get("PLYOLO_DDP_DEFER", "1") == "1"   # 1: collectives are started from the hooks and awaited once, after the plan; 0: the hook's lane waits for each
+COMM_LANE = int(os.environ.get("PLYOLO_COMM_LANE", "1"))   # plan lane of the exchange (0 main, 1 weight gradients, 2.. head levels); 1 = on the weight-gradient lane itself
 
 
 def bucket_bytes():
     return int(float(os.environ.get("PLYOLO_BUCKET_MB", "25")) * 1e6)
 
 
-def plan_buckets(offs, sizes, ready, n_live, target_bytes):
+def plan_buckets(offs, sizes, ready, n_live, target_bytes, tail_bytes=0):
     """Cut the live range [0, n_live) of the flat gradient buffer into buckets, last parameters first.
 
     offs / sizes: element offset and (aligned) element count of every live parameter in flat order; ready[i]: forward
     index of the layer that owns parameter i (its gradient is final once the backward has passed that layer), None for
     a parameter no layer uses.  Returns [(start, end, ready)] in emission order (end of the buffer first), `ready`
-    non-increasing -- bucket k never leaves before bucket k-1."""
-    buckets, end, acc, rdy = [], n_live, 0, None
+    non-increasing -- bucket k never leaves before bucket k-1.
+
+    tail_bytes > 0: the FRONT of the buffer -- the first layers of the backbone, whose gradients are final only when the
+    backward ends -- gets a bucket of its own of about that size.  Those layers (large maps, a few thousand parameters) take a
+    large share of the backward's time and hold almost none of the gradient bytes: the exposed collective at the end of the
+    step shrinks from "whatever was left over" (11 MB for YOLOX-s at 25 MB buckets) to that tail, and the bucket before it
+    leaves while the large-map layers are still running."""
+    cuts = []                                   # parameter indices where a bucket starts
+    acc = 0
+    front = 0
+    if tail_bytes > 0:
+        t = 0
+        for i in range(len(offs)):
+            t += sizes[i] * 4
+            if t >= tail_bytes:
+                front = i + 1                   # parameters [0, front) form the tail bucket
+                break
+        if front >= len(offs):
+            front = 0                           # the whole buffer is smaller than the tail: no split
     for i in range(len(offs) - 1, -1, -1):
         acc += sizes[i] * 4
-        if ready[i] is not None:
-            rdy = ready[i] if rdy is None else min(rdy, ready[i])
-        if acc >= target_bytes or i == 0:
-            buckets.append([offs[i], end, rdy])
-            end, acc, rdy = offs[i], 0, None
+        if acc >= target_bytes or i == 0 or i == front:
+            cuts.append(i)
+            acc = 0
+    buckets, end = [], n_live
+    for i in cuts:
+        hi = len(offs) if end == n_live else next(k for k in range(len(offs)) if offs[k] == end)
+        rs = [ready[k] for k in range(i, hi) if ready[k] is not None]
+        buckets.append([offs[i], end, min(rs) if rs else None])
+        end = offs[i]
     inf = max([b[2] for b in buckets if b[2] is not None] + [0])
     prev = inf
     for b in buckets:   # unused-only buckets are ready from the start; enforce emission order
         b[2] = prev if b[2] is None else min(b[2], prev)
         prev = b[2]
     return [tuple(b) for b in buckets]
+
+
+def tail_bytes():
+    return int(float(os.environ.get("PLYOLO_BUCKET_TAIL_MB", "0")) * 1e6)
 
 
 class GradAllReduce:
@@ -64,18 +91,30 @@ class GradAllReduce:
     def active(self):
         return self.world > 1 or FORCE_COLLECTIVE
 
-    def all_reduce_(self, flat, start=0, end=None):
-        """In-place mean of flat[start:end] over the ranks, on the current stream (the collective is ordered after the
-        work already queued there, and the stream waits for its result)."""
+    def all_reduce_(self, flat, start=0, end=None, defer=False):
+        """In-place mean of flat[start:end] over the ranks, ordered after the work already queued on the current stream.
+        defer=False: the current stream also waits for the result (returns flat).  defer=True: the collective is only
+        STARTED (it runs on the process group's own stream); returns finish(), to be called once with the stream that
+        consumes the gradients current -- nothing else on the launching stream waits for the exchange."""
         if not self.active():
-            return flat
+            return (lambda: None) if defer else flat
         view = flat[start:end if end is not None else flat.numel()]
         if dist.get_backend(self.group) == "nccl":   # RCCL averages inside the collective: no second pass over the buffer
             work = dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
-            work.wait()                               # a stream-side wait, the host does not block
-        else:                                        # gloo (CPU tests) has no AVG
-            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
-            view.mul_(1.0 / self.world)
+            if defer:
+                return work.wait                      # a stream-side wait, the host does not block
+            work.wait()
+            return flat
+        # gloo (CPU tests, two processes on one GPU) has no AVG
+        if defer:
+            work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+            def finish():
+                work.wait()
+                view.mul_(1.0 / self.world)
+            return finish
+        dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+        view.mul_(1.0 / self.world)
         return flat
 
     def all_reduce_buckets_(self, flat, buckets):
@@ -121,7 +160,7 @@ class BucketSchedule:
         offs = [o for _, o in live]
         sizes = [(offs[i + 1] if i + 1 < len(offs) else flat["n_live"]) - offs[i] for i in range(len(offs))]
         ready = [ready_of.get(id(p)) for p, _ in live]
-        self.buckets = plan_buckets(offs, sizes, ready, flat["n_live"], bucket_bytes())
+        self.buckets = plan_buckets(offs, sizes, ready, flat["n_live"], bucket_bytes(), tail_bytes())
         self.next_bucket = 0
         # weight-gradient slabs are unpacked (and the ImplicitHead extras run) as soon as their layer is done
         self.entry_op = []
@@ -140,6 +179,7 @@ class BucketSchedule:
         self.entries_left = list(range(len(g.pack_entries)))
         self.post_left = list(g.post_unpack)
         self.errors = []
+        self.pending = []
 
     # ---- recording
     def after(self, done_idx):
@@ -190,6 +230,9 @@ class BucketSchedule:
         self.plan = plan
 
     def _exchange(self, k, stream_ptr):
+        """Host hook of bucket k (called by the replay when it reaches the hook, the GPU far behind): START the collective,
+        ordered after the lane's work so far.  Nothing in the plan waits for it -- the buckets are disjoint ranges of the flat
+        buffer and no later launch touches a bucket that has left -- the consumer's stream does, in wait_all()."""
         a, b, _ = self.buckets[k]
         flat = self.runner.flat["g"]
         if flat.is_cuda:
@@ -197,9 +240,16 @@ class BucketSchedule:
             if st is None:
                 st = self._streams[stream_ptr] = torch.cuda.ExternalStream(stream_ptr)
             with torch.cuda.stream(st):
-                self.ddp.all_reduce_(flat, a, b)
+                self.pending.append(self.ddp.all_reduce_(flat, a, b, defer=DEFER))
         else:
-            self.ddp.all_reduce_(flat, a, b)
+            self.pending.append(self.ddp.all_reduce_(flat, a, b, defer=DEFER))
+
+    def wait_all(self):
+        """After the backward plan has been issued: the caller's current stream waits for every started collective."""
+        pend, self.pending = self.pending, []
+        for fin in pend:
+            if callable(fin):
+                fin()
 
     def check(self):
         e = getattr(self.plan, "hook_error", None)

@@ -293,6 +293,7 @@ class DetectorRunner:
         s.head.gout[:gout.numel()].copy_(gout.reshape(-1))
         self._run_plan(s.bwd)
         if s.sched is not None:
+            s.sched.wait_all()
             s.sched.check()
 
     def forward_eval(self, x):
@@ -322,6 +323,7 @@ class DetectorRunner:
         s.head.set_map_grads(grads)
         self._run_plan(s.bwd)
         if s.sched is not None:
+            s.sched.wait_all()
             s.sched.check()
 
 

@@ -1,6 +1,8 @@
 import os
 import sys
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")   # as the package does on import (pl_yolo_amd/__init__.py): before the HIP runtime starts
+
 import numpy as np
 import pytest
 

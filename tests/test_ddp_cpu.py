@@ -43,6 +43,15 @@ def test_plan_buckets_covers_live_range_in_reverse_order():
         assert not owners or rdy <= min(owners)
     one = plan_buckets(offs, sizes, ready, n_live, target_bytes=1 << 40)
     assert one == [(0, n_live, 0)]
+    # tail bucket: the first parameters (the last to be ready) get a small bucket of their own, the rest is cut as before
+    t = plan_buckets(offs, sizes, ready, n_live, target_bytes=1 << 40, tail_bytes=700)
+    assert t == [(offs[2], n_live, 1), (0, offs[2], 0)]              # 64 + 128 elements = 768 bytes >= 700
+    t2 = plan_buckets(offs, sizes, ready, n_live, target_bytes=4096, tail_bytes=700)
+    assert t2[-1] == (0, offs[2], 0) and t2[0][1] == n_live
+    for (s0, e0, _), (s1, e1, _) in zip(t2, t2[1:]):
+        assert e1 == s0 and s1 < e1
+    assert [x[2] for x in t2] == sorted([x[2] for x in t2], reverse=True)
+    assert plan_buckets(offs, sizes, ready, n_live, target_bytes=1 << 40, tail_bytes=1 << 30) == one   # tail >= everything: no split
 
 
 def _worker(rank, world, port, out):

@@ -58,7 +58,7 @@ def test_bucketed_exchange_inside_the_backward_plan(one_rank_rccl, family, name,
         calls = []
         if with_ddp:
             orig = model.runner().ddp.all_reduce_
-            model.runner().ddp.all_reduce_ = lambda flat, a=0, b=None: (calls.append((a, b)), orig(flat, a, b))[1]
+            model.runner().ddp.all_reduce_ = lambda flat, a=0, b=None, **kw: (calls.append((a, b)), orig(flat, a, b, **kw))[1]
         for _ in range(2):                       # second step: the hooks fire on every replay
             out = model(imgs, labels)
             model.zero_grad(set_to_none=True)

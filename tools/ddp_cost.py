@@ -24,14 +24,14 @@ def run(mode):
         ddp.attach(model)
         r = model.runner()
         orig = r.ddp.all_reduce_
-        def timed(flat, a=0, b=None):
+        def timed(flat, a=0, b=None, **kw):
             t0 = time.perf_counter()
             if mode == "native":
                 b_ = flat.numel() if b is None else b
                 _lib.call("plyolo_rccl_allreduce_bucket", COMM, flat.data_ptr() + 4 * a, b_ - a, 1, torch.cuda.current_stream().cuda_stream)
                 out = flat
             else:
-                out = flat if mode == "noop" else orig(flat, a, b)
+                out = flat if mode == "noop" else orig(flat, a, b, **kw)
             host.append(time.perf_counter() - t0)
             return out
         r.ddp.all_reduce_ = timed
