@@ -8,6 +8,9 @@ from . import graph as G
 from .layers import emit_pair, BaseConv, HipModule
 
 
+_ONE_SIDE_LANE = __import__("os").environ.get("PLYOLO_HEAD_ONE_LANE", "1") == "1"   # levels 1 and 2 share lane 2: three streams in all = one per hardware queue (GPU_MAX_HW_QUEUES=3); 0: a lane per level
+
+
 class DecoupledHead(HipModule):
     def __init__(self, num_classes=80, n_anchors=1, in_channels=None, norm="bn", act="silu"):
         super().__init__()
@@ -46,10 +49,11 @@ class DecoupledHead(HipModule):
         """Writes the raw predictions of every level into `head_buffers.raw`
         (channel order reg(4), obj(1), cls(C) -- decoupled_head.py:93)."""
         # the levels are independent from the stem conv to the prediction convs (and back, in the backward
-        # plan): level 0 stays on the main lane, the smaller levels run beside it on lanes 2, 3, ...
+        # plan): level 0 stays on the main lane, the two smaller levels run beside it on lane 2, one after the other (with a lane
+        # each the step is 0.9 % slower: four streams on three hardware queues, see pl_yolo_amd/__init__.py)
         with g.fork() as region:
             for k, x in enumerate(inputs):
-                with region.branch(0 if k == 0 else 1 + k):
+                with region.branch(0 if k == 0 else (2 if _ONE_SIDE_LANE else 1 + k)):
                     x = self.stems[k].emit(g, x)
                     # the first conv of the cls and of the reg branch read the same stem output: one merged conv
                     cls_feat, reg_feat = emit_pair(g, x, self.cls_convs[k][0], self.reg_convs[k][0])

@@ -1,7 +1,7 @@
-run() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); f=[x for x in d['roofline']['families'] if x['kernel']=='conv_wgrad_kernel']; print('$1', round(d['value']), round(d['ms_per_step'],3), round(f[0]['avg_ms']*f[0]['launches_per_step'],3) if f else None)"; }
+run() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', round(d['value']), round(d['ms_per_step'],3))"; }
 for i in 1 2 3 4; do
-  python bench.py --no-cpu-baseline --steps 100 2>/dev/null | run "1x1 budget 16"
-  PLYOLO_WG_BUDGET1_MB=8 python bench.py --no-cpu-baseline --steps 100 2>/dev/null | run "1x1 budget 8 "
-  PLYOLO_WG_BUDGET1_MB=32 python bench.py --no-cpu-baseline --steps 100 2>/dev/null | run "1x1 budget 32"
-  PLYOLO_WG_BUDGET1_MB=64 python bench.py --no-cpu-baseline --steps 100 2>/dev/null | run "1x1 budget 64"
+  python bench.py --no-cpu-baseline --steps 80 2>/dev/null | run "q=3, head levels on lanes 0/2/3"
+  PLYOLO_HEAD_ONE_LANE=1 python bench.py --no-cpu-baseline --steps 80 2>/dev/null | run "q=3, head levels on lanes 0/2/2"
+  PLYOLO_HEAD_ONE_LANE=1 GPU_MAX_HW_QUEUES=4 python bench.py --no-cpu-baseline --steps 80 2>/dev/null | run "q=4, head levels on lanes 0/2/2"
+  PLYOLO_HEAD_ONE_LANE=1 GPU_MAX_HW_QUEUES=2 python bench.py --no-cpu-baseline --steps 80 2>/dev/null | run "q=2, head levels on lanes 0/2/2"
 done
