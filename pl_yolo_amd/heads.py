@@ -8,6 +8,7 @@ from . import graph as G
 from .layers import emit_pair, BaseConv, HipModule
 
 
+_NO_SIDE_LANE = __import__("os").environ.get("PLYOLO_HEAD_ONE_LANE", "1") == "2"   # 2: every level on the main lane (two streams in all)
 _ONE_SIDE_LANE = __import__("os").environ.get("PLYOLO_HEAD_ONE_LANE", "1") == "1"   # levels 1 and 2 share lane 2: three streams in all = one per hardware queue (GPU_MAX_HW_QUEUES=3); 0: a lane per level
 
 
@@ -53,7 +54,7 @@ class DecoupledHead(HipModule):
         # each the step is 0.9 % slower: four streams on three hardware queues, see pl_yolo_amd/__init__.py)
         with g.fork() as region:
             for k, x in enumerate(inputs):
-                with region.branch(0 if k == 0 else (2 if _ONE_SIDE_LANE else 1 + k)):
+                with region.branch(0 if (k == 0 or _NO_SIDE_LANE) else (2 if _ONE_SIDE_LANE else 1 + k)):
                     x = self.stems[k].emit(g, x)
                     # the first conv of the cls and of the reg branch read the same stem output: one merged conv
                     cls_feat, reg_feat = emit_pair(g, x, self.cls_convs[k][0], self.reg_convs[k][0])
