@@ -9,11 +9,16 @@ import os as _os
 #   * single process: the launch plans use three streams (the default stream as the main lane, the weight-gradient lane, one
 #     lane for the two smaller head levels) -> 3 queues;
 #   * under torch.distributed (RANK / WORLD_SIZE in the environment) the process group owns a stream of its own, created
-#     before the lanes: with 3 queues the weight-gradient lane then shares a queue with the main lane and the step takes
-#     11.8 ms instead of 9.5 (tools/ab_ddp.sh) -> 4 queues, and a lane per head level again (pl_yolo_amd/heads.py).
-# The variable is read when the HIP runtime initialises, so it must be in the environment BEFORE the first HIP call of the
-# process: importing this package first (or exporting it in the shell) is enough; an explicit setting of the user is respected.
+#     before the lanes, and which stream shares a queue with which is decided by creation order (round-robin): with 3 queues
+#     the weight-gradient lane then lands on the main lane's queue and the step takes 11.9 ms instead of 9.6 (tools/ab_ddp.sh).
+#     There every plan runs its main lane on a stream of its OWN, created back to back with its side streams
+#     (PLYOLO_OWN_MAIN=1, csrc/api.hip): consecutive streams sit on distinct queues whatever was created before them.  With 4
+#     queues that is as fast as the single-process setup (9.60 vs 9.62 ms, one-rank group, tools/ab_own.sh) and does not depend
+#     on what else the application created; in a single process the caller's stream as main lane is 1 % faster still.
+# The variables are read when the HIP runtime / the library initialise, so they must be in the environment BEFORE the first HIP
+# call of the process: importing this package first (or exporting them in the shell) is enough; explicit settings are respected.
 DISTRIBUTED_LAUNCH = "RANK" in _os.environ or int(_os.environ.get("WORLD_SIZE", "1") or 1) > 1
+_os.environ.setdefault("PLYOLO_OWN_MAIN", "1" if DISTRIBUTED_LAUNCH else "0")
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "4" if DISTRIBUTED_LAUNCH else "3")
 from .build_detection import build_model, OneStageD  # noqa: F401
 from ._lib import PlyoloError  # noqa: F401

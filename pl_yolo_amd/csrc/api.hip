@@ -127,6 +127,7 @@ void plyolo_plan_destroy(plyolo_plan* p) {
   if (q->graph) (void)hipGraphDestroy(q->graph);
   for (auto e : q->events) (void)hipEventDestroy(e);
   for (auto st : q->side) (void)hipStreamDestroy(st);
+  for (auto e : q->io_events) (void)hipEventDestroy(e);
   if (g_rec == q) g_rec = nullptr;
   delete q;
 }
@@ -212,13 +213,33 @@ static hipError_t issue_lanes(Plan* q, hipStream_t s, bool lanes, size_t* failed
     }
     return le;
   }
-  while ((int)q->side.size() < q->nlanes - 1) {
+  // PLYOLO_OWN_MAIN=1: lane 0 runs on a stream of the plan's own, created in one go with the side streams.  The runtime hands
+  // hardware queues to streams round-robin in creation order, so streams created back to back sit on distinct queues
+  // whatever the application created before -- the caller's stream only forks into and joins from the plan.
+  static const int own_main = getenv("PLYOLO_OWN_MAIN") ? atoi(getenv("PLYOLO_OWN_MAIN")) : 0;
+  const int want = q->nlanes - 1 + (own_main ? 1 : 0);
+  while ((int)q->side.size() < want) {
     // (stream priorities were tried for the weight-gradient lane -- hipStreamCreateWithPriority, low or high: ANY non-default
     // priority on one lane doubled the step, 10.5 -> 22 ms on ROCm 7.2; every lane stays at the default priority)
     hipStream_t st;
     hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
     if (e != hipSuccess) return e;
     q->side.push_back(st);
+  }
+  hipStream_t caller = s;
+  hipEvent_t ev_io[2] = {nullptr, nullptr};
+  if (own_main) {
+    while (q->io_events.size() < 2) {
+      hipEvent_t ev;
+      hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+      if (e != hipSuccess) return e;
+      q->io_events.push_back(ev);
+    }
+    ev_io[0] = q->io_events[0]; ev_io[1] = q->io_events[1];
+    s = q->side[(size_t)q->nlanes - 1];           // the plan's main stream (last of the set)
+    hipError_t e = hipEventRecord(ev_io[0], caller);
+    if (e == hipSuccess) e = hipStreamWaitEvent(s, ev_io[0], 0);
+    if (e != hipSuccess) return e;
   }
   const size_t need_ev = (size_t)q->nevents + 2 * (size_t)q->nlanes;
   while (q->events.size() < need_ev) {
@@ -248,6 +269,10 @@ static hipError_t issue_lanes(Plan* q, hipStream_t s, bool lanes, size_t* failed
   for (int l = 1; l < q->nlanes && le == hipSuccess; ++l) {
     le = hipEventRecord(fork_ev[q->nlanes + l], lane_stream(l));
     if (le == hipSuccess) le = hipStreamWaitEvent(s, fork_ev[q->nlanes + l], 0);
+  }
+  if (own_main && le == hipSuccess) {
+    le = hipEventRecord(ev_io[1], s);
+    if (le == hipSuccess) le = hipStreamWaitEvent(caller, ev_io[1], 0);
   }
   return le;
 }

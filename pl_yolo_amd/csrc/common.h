@@ -145,7 +145,8 @@ struct Plan {
   std::vector<PlanOp> ops;
   int cur_lane = 0;    // lane of the launches being recorded
   int nlanes = 1, nevents = 0;
-  std::vector<hipStream_t> side;   // capture streams of lanes 1.. (created on first instantiate)
+  std::vector<hipStream_t> side;   // streams of lanes 1.. (created on first replay) [+ the plan's own main stream, PLYOLO_OWN_MAIN]
+  std::vector<hipEvent_t> io_events;  // fork from / join into the caller's stream (PLYOLO_OWN_MAIN)
   std::vector<hipEvent_t> events;  // fork/join + recorded events
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;

@@ -9,10 +9,9 @@ from . import graph as G
 from .layers import emit_pair, BaseConv, HipModule
 
 
-# Lanes of the head levels.  PLYOLO_HEAD_ONE_LANE: 0 a lane per level (lanes 2, 3), 1 levels 1 and 2 share lane 2 (three streams in
-# all: one per hardware queue when GPU_MAX_HW_QUEUES=3), 2 every level on the main lane.  Default: 1 in a single process, 0 under a
-# distributed launch, where the package asks for four queues (pl_yolo_amd/__init__.py has the measurements).
-_HEAD_LANES = os.environ.get("PLYOLO_HEAD_ONE_LANE", "0" if ("RANK" in os.environ or int(os.environ.get("WORLD_SIZE", "1") or 1) > 1) else "1")
+# Lanes of the head levels.  PLYOLO_HEAD_ONE_LANE: 0 a lane per level (lanes 2, 3), 1 levels 1 and 2 share lane 2 (three streams per
+# plan, the default: one per hardware queue), 2 every level on the main lane.  pl_yolo_amd/__init__.py has the measurements.
+_HEAD_LANES = os.environ.get("PLYOLO_HEAD_ONE_LANE", "1")
 _NO_SIDE_LANE = _HEAD_LANES == "2"
 _ONE_SIDE_LANE = _HEAD_LANES == "1"
 
