@@ -21,7 +21,7 @@ import os
 import sys
 import time
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "4" if ("RANK" in os.environ or int(os.environ.get("WORLD_SIZE", "1") or 1) > 1) else "3")   # before the HIP runtime starts: see pl_yolo_amd/__init__.py (3 hardware queues: -2.5 % step time)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "4"); os.environ.setdefault("PLYOLO_OWN_MAIN", "1")   # before the HIP runtime starts: see pl_yolo_amd/__init__.py
 
 import torch  # noqa: E402
 

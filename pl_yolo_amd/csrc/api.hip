@@ -213,10 +213,10 @@ static hipError_t issue_lanes(Plan* q, hipStream_t s, bool lanes, size_t* failed
     }
     return le;
   }
-  // PLYOLO_OWN_MAIN=1: lane 0 runs on a stream of the plan's own, created in one go with the side streams.  The runtime hands
-  // hardware queues to streams round-robin in creation order, so streams created back to back sit on distinct queues
-  // whatever the application created before -- the caller's stream only forks into and joins from the plan.
-  static const int own_main = getenv("PLYOLO_OWN_MAIN") ? atoi(getenv("PLYOLO_OWN_MAIN")) : 0;
+  // Lane 0 runs on a stream of the plan's own, created in one go with the side streams (PLYOLO_OWN_MAIN=0: on the caller's stream).
+  // The runtime hands hardware queues to streams round-robin in creation order, so streams created back to back sit
+  // on distinct queues whatever the application created before -- the caller's stream only forks into and joins from the plan.
+  static const int own_main = getenv("PLYOLO_OWN_MAIN") ? atoi(getenv("PLYOLO_OWN_MAIN")) : 1;
   const int want = q->nlanes - 1 + (own_main ? 1 : 0);
   while ((int)q->side.size() < want) {
     // (stream priorities were tried for the weight-gradient lane -- hipStreamCreateWithPriority, low or high: ANY non-default

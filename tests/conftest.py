@@ -1,7 +1,7 @@
 import os
 import sys
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "4" if ("RANK" in os.environ or int(os.environ.get("WORLD_SIZE", "1") or 1) > 1) else "3")   # as the package does on import (pl_yolo_amd/__init__.py): before the HIP runtime starts
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "4"); os.environ.setdefault("PLYOLO_OWN_MAIN", "1")   # before the HIP runtime starts: see pl_yolo_amd/__init__.py
 
 import numpy as np
 import pytest
