@@ -47,6 +47,14 @@ class BnBwdSplit(C.Structure):     # plyolo_bn_bwd_split
     _fields_ = [("split", C.c_int), ("gamma2", C.c_void_p), ("dgamma2", C.c_void_p), ("dbeta2", C.c_void_p)]
 
 
+class BnBwdFuse(C.Structure):      # plyolo_bn_bwd_fuse
+    _fields_ = [("dout", C.c_void_p), ("dout_ld", C.c_int), ("dout2", C.c_void_p), ("dout2_ld", C.c_int), ("dout_split", C.c_int),
+                ("z", C.c_void_p), ("z_ld", C.c_int), ("coef", C.c_void_p), ("bslots", C.c_void_p),
+                ("gamma", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("par_split", C.c_int),
+                ("gamma2", C.c_void_p), ("dgamma2", C.c_void_p), ("dbeta2", C.c_void_p), ("act", C.c_int),
+                ("dz", C.c_void_p), ("dz_ld", C.c_int)]
+
+
 class PackEntry(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("w", "wp", "wpd", "dwp", "dw", "b", "bp", "dbp", "db")] + [
         (n, C.c_int) for n in ("Cout", "Cin", "Cin_p", "ksize", "Cout_total", "Cout_p8", "co_off", "nslab")
@@ -149,6 +157,8 @@ SIGNATURES = {
     "plyolo_conv2d_fwd_bn_act": (_i, [_P(ConvDesc), _vp, _vp, _vp, _i, _vp, _i, _vp, _vp]),
     "plyolo_conv2d_dgrad": (_i, [_P(ConvDesc), _vp, _vp, _vp, _i, _vp]),
     "plyolo_conv2d_wgrad": (_i, [_P(ConvDesc), _vp, _vp, _vp, _vp]),
+    "plyolo_conv2d_dgrad_bn_fits": (_i, [_P(ConvDesc), _i]),
+    "plyolo_conv2d_dgrad_bn": (_i, [_P(ConvDesc), _P(BnBwdFuse), _vp, _vp, _i, _vp]),
     "plyolo_conv2d_wgrad_slabs": (_i, [_P(ConvDesc)]),
     "plyolo_bias_grad": (_i, [_i, _vp, _i, _i, _i, _vp, _vp]),
     "plyolo_pack_weights": (_i, [_vp, _i, _i, _i, _vp]),

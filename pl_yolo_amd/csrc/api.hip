@@ -60,6 +60,8 @@ int conv_mfma_wgrad_slabs(const plyolo_conv_desc*);
 bool conv_pw_enabled();
 int conv_pw_fwd(const plyolo_conv_desc*, const void*, const void*, const float*, void*, double*, const float*, int, const void*, int, void*);
 int conv_pw_dgrad(const plyolo_conv_desc*, const void*, const void*, void*, int, void*);
+int conv_pw_dgrad_bn_fits(const plyolo_conv_desc*, int);
+int conv_pw_dgrad_bn(const plyolo_conv_desc*, const plyolo_bn_bwd_fuse*, const void*, void*, int, void*);
 int conv_ref_fwd(const plyolo_conv_desc*, const void*, const void*, const float*, void*, double*, void*);
 int conv_ref_dgrad(const plyolo_conv_desc*, const void*, const void*, void*, int, void*);
 int conv_ref_wgrad(const plyolo_conv_desc*, const void*, const void*, float*, void*);
@@ -266,15 +268,23 @@ static hipError_t issue_lanes(Plan* q, hipStream_t s, bool lanes, size_t* failed
   }
   if (tev)
     for (int l = 0; l < q->nlanes && le == hipSuccess; ++l) le = hipEventRecord(tev[1 + l], lane_stream(l));
-  for (int l = 1; l < q->nlanes && le == hipSuccess; ++l) {
-    le = hipEventRecord(fork_ev[q->nlanes + l], lane_stream(l));
-    if (le == hipSuccess) le = hipStreamWaitEvent(s, fork_ev[q->nlanes + l], 0);
+  // The joins run on the error path too: work already enqueued on the plan's private streams must stay ordered before whatever
+  // the caller does next on ITS stream (release or reuse the buffers while Python raises) -- the first error is what is returned.
+  hipError_t je = hipSuccess;
+  for (int l = 1; l < q->nlanes; ++l) {
+    hipError_t e = hipEventRecord(fork_ev[q->nlanes + l], lane_stream(l));
+    if (e == hipSuccess) e = hipStreamWaitEvent(s, fork_ev[q->nlanes + l], 0);
+    if (e != hipSuccess && je == hipSuccess) je = e;
   }
-  if (own_main && le == hipSuccess) {
-    le = hipEventRecord(ev_io[1], s);
-    if (le == hipSuccess) le = hipStreamWaitEvent(caller, ev_io[1], 0);
+  if (own_main) {
+    hipError_t e = hipEventRecord(ev_io[1], s);
+    if (e == hipSuccess) e = hipStreamWaitEvent(caller, ev_io[1], 0);
+    if (e != hipSuccess && je == hipSuccess) je = e;
   }
-  return le;
+  if (le != hipSuccess && je != hipSuccess) {   // the joins failed as well: drain the plan's streams before handing the error back
+    for (auto st : q->side) (void)hipStreamSynchronize(st);
+  }
+  return le != hipSuccess ? le : je;
 }
 
 int plyolo_plan_run(plyolo_plan* p, void* stream) {
@@ -292,6 +302,8 @@ int plyolo_plan_run(plyolo_plan* p, void* stream) {
 int plyolo_plan_graph_instantiate(plyolo_plan* p, void* stream) {
   PLY_CHECK_ARG(p != nullptr, "plan_graph_instantiate: null plan");
   Plan* q = (Plan*)p;
+  // a captured replay cannot run host hooks: a data-parallel plan graphed through the C ABI would silently lose its gradient exchange
+  PLY_CHECK_ARG(q->nhooks == 0, "plan_graph_instantiate: the plan has %d host hook(s) (plyolo_plan_hook), which a hipGraph replay cannot run; replay it with plyolo_plan_run", q->nhooks);
   hipStream_t s = (hipStream_t)stream;
   if (q->exec) { (void)hipGraphExecDestroy(q->exec); q->exec = nullptr; }
   if (q->graph) { (void)hipGraphDestroy(q->graph); q->graph = nullptr; }
@@ -432,6 +444,19 @@ int plyolo_conv2d_dgrad(const plyolo_conv_desc* d, const void* dy, const void* w
   if (d->dtype != PLYOLO_BF16) return conv_ref_dgrad(d, dy, wpd, dx, accumulate, stream);
   if (is_pointwise(d)) return conv_pw_dgrad(d, dy, wpd, dx, accumulate, stream);
   return conv_mfma_dgrad(d, dy, wpd, dx, accumulate, stream);
+}
+int plyolo_conv2d_dgrad_bn_fits(const plyolo_conv_desc* d, int act) {
+  if (check_conv(d, "conv2d_dgrad_bn_fits", false)) return -1;
+  return conv_pw_dgrad_bn_fits(d, act);
+}
+int plyolo_conv2d_dgrad_bn(const plyolo_conv_desc* d, const plyolo_bn_bwd_fuse* f, const void* wpd, void* dx, int accumulate, void* stream) {
+  if (check_conv(d, "conv2d_dgrad_bn", false)) return -1;
+  PLY_CHECK_ARG(f && f->dout && f->z && f->coef && f->bslots && f->dz, "conv2d_dgrad_bn: incomplete plyolo_bn_bwd_fuse");
+  PLY_CHECK_ARG(conv_pw_dgrad_bn_fits(d, f->act) == 1, "conv2d_dgrad_bn: this unit is not covered (ask plyolo_conv2d_dgrad_bn_fits; use plyolo_bn_act_bwd_dz + plyolo_conv2d_dgrad)");
+  PLY_CHECK_ARG(f->dout_ld % 8 == 0 && f->z_ld % 8 == 0 && f->dz_ld % 8 == 0 && f->dz_ld >= d->Cout && f->z_ld >= d->Cout, "conv2d_dgrad_bn: pitches must be multiples of 8 and hold Cout channels");
+  PLY_CHECK_ARG(!f->dout2 || (f->dout_split > 0 && f->dout_split < d->Cout && f->dout_split % 8 == 0 && f->dout2_ld % 8 == 0), "conv2d_dgrad_bn: bad output-gradient split");
+  PLY_CHECK_ARG(f->par_split == 0 || (f->par_split > 0 && f->par_split < d->Cout), "conv2d_dgrad_bn: bad parameter split");
+  return conv_pw_dgrad_bn(d, f, wpd, dx, accumulate, stream);
 }
 int plyolo_conv2d_wgrad_slabs(const plyolo_conv_desc* d) {
   if (check_conv(d, "conv2d_wgrad_slabs", false)) return -1;

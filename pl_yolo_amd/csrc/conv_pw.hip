@@ -44,7 +44,34 @@ struct PwP {
   int accumulate;
   int pf;                // 1: requests of chunk i+1 before the MFMAs of chunk i (PLYOLO_PW_PF, A/B switch)
   int pipe;              // 1: the software-pipelined chunk loop, 0: the plain one (PLYOLO_PW_LOOP, A/B switch)
+  // BNB instances (plyolo_conv2d_dgrad_bn): x is the gradient of the unit's ACTIVATED output (channels >= bsplit in a second
+  // matrix for merged pairs); the rows are staged as dz = A*du + B*z + Cc, du = x * act'(z*sc + sh)  -- exactly bn_act_bwd_dz
+  // (bn.hip) -- and the workgroups of BN block 0 also write dz for the weight gradient
+  const bf16_t* bz;      // raw conv output z of the unit [M][K], pitch bz_ld
+  int bz_ld;
+  const bf16_t* bx2;
+  int bx2_ld, bsplit;
+  const float* bcoef;    // (scale | shift | mean | invstd) [4][K] of the forward
+  const double* bslots;  // fp64 backward stat slots [PLYOLO_STAT_SLOTS][2][K] (sum du, sum du*zhat)
+  const float *bgamma, *bgamma2;
+  float *bdgamma, *bdbeta, *bdgamma2, *bdbeta2;
+  int bpsplit, bact;
+  bf16_t* bdz;
+  int bdz_ld;
 };
+
+// derivative of the three cheap activations (the BNB loader; hswish / gelu units keep the separate bn_act_bwd_dz launch)
+DEVINL float pw_act_grad(float u, int act) {
+  switch (act) {
+    case PLYOLO_ACT_SILU: {
+      const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-u));
+      return s * (1.0f + u * (1.0f - s));
+    }
+    case PLYOLO_ACT_RELU: return u > 0.f ? 1.f : 0.f;
+    case PLYOLO_ACT_LRELU: return u > 0.f ? 1.f : 0.1f;
+    default: return 1.f;
+  }
+}
 
 DEVINL u32x4 pw_add_bf16x8(u32x4 a, u32x4 b) {
   u32x4 r;
@@ -59,9 +86,13 @@ DEVINL u32x4 pw_add_bf16x8(u32x4 a, u32x4 b) {
 
 constexpr int PW_BM = 128;
 
-template <int BN, int KC, bool OUT_F32, bool PRE, bool PIPE>
-__global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwP p) {
-  constexpr int BM = PW_BM;
+// BNB instances run 64-row tiles where the wave layout allows (BN >= 64): half the accumulators and half the rows in flight per
+// thread pay for the loader's second operand and its coefficient registers (207 -> 3 waves per SIMD without spilling)
+template <int BN, bool BNB> constexpr int pw_bm() { return (BNB && BN >= 64) ? 64 : PW_BM; }
+
+template <int BN, int KC, bool OUT_F32, bool PRE, bool PIPE, bool BNB = false>
+__global__ __launch_bounds__(256, BNB ? 3 : 2) void conv_pw_kernel(const PwP p) {
+  constexpr int BM = pw_bm<BN, BNB>();
   constexpr int WN = BN / 32, WM = 4 / WN, MT = BM / (32 * WM);
   constexpr int ROWB = KC * 2 + 16;   // LDS row pitch (bytes)
   constexpr int CV = KC / 8;          // 16-byte vectors per row
@@ -114,13 +145,90 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwP p) {
     const int c = c0 + cvt * 8;
     const bool cok = c < p.K;
     u32x4 av[NV];
+    [[maybe_unused]] u32x4 zv[NV];
+    if constexpr (BNB) {
+      // this thread's channel vector of the output gradient lives in one of the two matrices of a merged pair
+      const bool second = p.bsplit > 0 && c >= p.bsplit;
+      const bf16_t* dsrc = second ? p.bx2 + (c - p.bsplit) : p.x + c;
+      const int dld = second ? p.bx2_ld : p.x_ld;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int m = m0 + row0 + v * RPP;
+        const bool ok = cok && m < p.M;
+        av[v] = *(const u32x4*)(ok ? dsrc + (size_t)m * dld : p.x);
+        zv[v] = *(const u32x4*)(p.bz + (ok ? (size_t)m * p.bz_ld + c : 0));
+      }
+      if (chunk == 0) {
+        // per-channel table (scale, shift, A, B, Cc) behind the row tile, built while the first rows are in flight
+        float* tab = (float*)(smem + BM * ROWB);
+        const int Kp = p.K;
+        for (int ch = tid; ch < Kp; ch += 256) {
+          double su = 0.0, suz = 0.0;
+#pragma unroll
+          for (int sl = 0; sl < PLYOLO_STAT_SLOTS; ++sl) {
+            su += p.bslots[((size_t)sl * 2 + 0) * Kp + ch];
+            suz += p.bslots[((size_t)sl * 2 + 1) * Kp + ch];
+          }
+          const float mean = p.bcoef[2 * Kp + ch], invstd = p.bcoef[3 * Kp + ch];
+          const bool sec = p.bpsplit > 0 && ch >= p.bpsplit;
+          const int cp = sec ? ch - p.bpsplit : ch;
+          const float* gam = sec ? p.bgamma2 : p.bgamma;
+          const double cnt = (double)p.M;
+          const float A = (gam ? gam[cp] : 1.f) * invstd;
+          const float B = (float)(-(double)A * (suz / cnt) * (double)invstd);
+          tab[ch] = p.bcoef[ch];
+          tab[Kp + ch] = p.bcoef[Kp + ch];
+          tab[2 * Kp + ch] = A;
+          tab[3 * Kp + ch] = B;
+          tab[4 * Kp + ch] = (float)(-(double)A * (su / cnt) - (double)B * (double)mean);
+          if (tile == 0) {   // dbeta = sum du, dgamma = sum du*zhat (bn_act_bwd_dz publishes them from its workgroup 0)
+            float* db_ = sec ? p.bdbeta2 : p.bdbeta;
+            float* dg_ = sec ? p.bdgamma2 : p.bdgamma;
+            if (db_) db_[cp] = (float)su;
+            if (dg_) dg_[cp] = (float)suz;
+          }
+        }
+        __syncthreads();
+      }
+    } else {
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       const int m = m0 + row0 + v * RPP;
       const bool ok = cok && m < p.M;
       av[v] = *(const u32x4*)(p.x + (ok ? (size_t)m * p.x_ld + c : 0));
     }
+    }
     if (chunk) __syncthreads();   // every wave is done with the previous chunk's rows
+    if constexpr (BNB) {
+      const float* tab = (const float*)(smem + BM * ROWB);
+      const int Kp = p.K, cc = cok ? c : 0;
+      float sc[8], sh[8], A[8], B[8], Cc[8];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const f32x4 a0 = *(const f32x4*)(tab + cc + 4 * q), a1 = *(const f32x4*)(tab + Kp + cc + 4 * q);
+        const f32x4 a2 = *(const f32x4*)(tab + 2 * Kp + cc + 4 * q), a3 = *(const f32x4*)(tab + 3 * Kp + cc + 4 * q);
+        const f32x4 a4 = *(const f32x4*)(tab + 4 * Kp + cc + 4 * q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { sc[4 * q + i] = a0[i]; sh[4 * q + i] = a1[i]; A[4 * q + i] = a2[i]; B[4 * q + i] = a3[i]; Cc[4 * q + i] = a4[i]; }
+      }
+      const bool wr = nblk == 0;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        u32x4 t = av[v];
+        const u32x4 zz = zv[v];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float zl = __uint_as_float(zz[i] << 16), zh = __uint_as_float(zz[i] & 0xffff0000u);
+          const float dl = __uint_as_float(t[i] << 16), dh = __uint_as_float(t[i] & 0xffff0000u);
+          const float dul = dl * pw_act_grad(fmaf(zl, sc[2 * i], sh[2 * i]), p.bact);
+          const float duh = dh * pw_act_grad(fmaf(zh, sc[2 * i + 1], sh[2 * i + 1]), p.bact);
+          t[i] = pack2bf(fmaf(A[2 * i], dul, fmaf(B[2 * i], zl, Cc[2 * i])), fmaf(A[2 * i + 1], duh, fmaf(B[2 * i + 1], zh, Cc[2 * i + 1])));
+        }
+        av[v] = t;
+        const int m = m0 + row0 + v * RPP;
+        if (wr && cok && m < p.M) *(u32x4*)(p.bdz + (size_t)m * p.bdz_ld + c) = t;
+      }
+    }
     if constexpr (PRE) {
       float sc[8], sh[8];
 #pragma unroll
@@ -357,6 +465,32 @@ hipError_t pw_launch_inst(const PwP& p, hipStream_t s) {
   return hipGetLastError();
 }
 
+// BNB instances: bf16 output, plain chunk loop, 32- / 64-channel chunks
+template <int BN, int KC>
+hipError_t pw_launch_bnb_inst(const PwP& p, hipStream_t s) {
+  constexpr int WN = BN / 32, WM = 4 / WN;
+  constexpr int ROWB = KC * 2 + 16, SROW = BN * 2 + 16;
+  constexpr int BM = pw_bm<BN, true>();
+  const size_t lds_main = (size_t)BM * ROWB + (size_t)5 * p.K * 4;   // row tile + the per-channel table
+  const size_t lds_epi = (size_t)BM * SROW + WM * 2 * BN * 4;
+  const size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+  auto kern = conv_pw_kernel<BN, KC, false, false, false, true>;
+  if (hipError_t e = plyolo::ensure_dynamic_lds((const void*)kern, lds); e != hipSuccess) return e;
+  const int nmt = (p.M + BM - 1) / BM;
+  PwP q = p;
+  q.nmt = nmt;
+  hipLaunchKernelGGL(kern, dim3(nmt * p.nnblk), dim3(256), lds, s, q);
+  return hipGetLastError();
+}
+
+hipError_t pw_launch_bnb(const PwP& p, int BN, int KC, hipStream_t s) {
+#define PW_BCASE(bn, kc) \
+  if (BN == bn && KC == kc) return pw_launch_bnb_inst<bn, kc>(p, s);
+  PW_BCASE(32, 32) PW_BCASE(32, 64) PW_BCASE(64, 32) PW_BCASE(64, 64) PW_BCASE(128, 32) PW_BCASE(128, 64)
+#undef PW_BCASE
+  return hipErrorInvalidValue;
+}
+
 template <bool OUT_F32, bool PRE>
 hipError_t pw_launch(const PwP& p, int BN, int KC, hipStream_t s) {
 #define PW_CASE(bn, kc) \
@@ -445,6 +579,55 @@ int conv_pw_dgrad(const plyolo_conv_desc* d, const void* dy, const void* wpd, vo
     annotate(lab, 2.0 * p.M * (double)d->Cout * d->Cin, (double)p.M * (p.K + d->Cin * (accumulate ? 2.0 : 1.0)) * 2.0);
   }
   return submit(stream, [=](hipStream_t s) { return pw_launch<false, false>(p, BN, KC, s); });
+}
+
+// ---- data gradient with the unit's BatchNorm + activation backward in the loader (plyolo_conv2d_dgrad_bn)
+static bool bnb_enabled() {
+  static const bool on = !(getenv("PLYOLO_FUSE_BNBWD") && atoi(getenv("PLYOLO_FUSE_BNBWD")) == 0);
+  return on;
+}
+
+// 1 when plyolo_conv2d_dgrad_bn covers this unit: pointwise stride-1 bf16, a cheap activation, every channel vector whole, and
+// at most two BN blocks per pixel tile (every block re-derives dz for the whole contraction length; beyond two the separate
+// bn_act_bwd_dz pass is cheaper)
+int conv_pw_dgrad_bn_fits(const plyolo_conv_desc* d, int act) {
+  if (!bnb_enabled() || !conv_pw_enabled() || d->dtype != PLYOLO_BF16 || d->ksize != 1 || d->stride != 1) return 0;
+  if (act < PLYOLO_ACT_NONE || act > PLYOLO_ACT_LRELU || d->Cout % 8 != 0 || d->Cout > 1024) return 0;
+  const int bn = d->Cin > 64 ? 128 : (d->Cin > 32 ? 64 : 32);
+  static const int maxblk = getenv("PLYOLO_FUSE_BNBWD_BLK") ? atoi(getenv("PLYOLO_FUSE_BNBWD_BLK")) : 2;
+  return (d->Cin + bn - 1) / bn <= maxblk ? 1 : 0;
+}
+
+int conv_pw_dgrad_bn(const plyolo_conv_desc* d, const plyolo_bn_bwd_fuse* f, const void* wpd, void* dx, int accumulate, void* stream) {
+  PwP p{};
+  p.x = (const bf16_t*)f->dout;
+  p.w = (const bf16_t*)wpd;
+  p.y = dx;
+  p.M = d->N * d->H * d->W;
+  p.K = d->Cout;
+  p.N = d->Cin; p.x_ld = f->dout_ld; p.y_ld = d->x_ld;
+  p.nkb = (d->Cout + 15) / 16;
+  p.nnb = (d->Cin + 31) / 32;
+  p.accumulate = accumulate;
+  p.bz = (const bf16_t*)f->z; p.bz_ld = f->z_ld;
+  p.bx2 = (const bf16_t*)f->dout2; p.bx2_ld = f->dout2_ld; p.bsplit = f->dout2 ? f->dout_split : 0;
+  p.bcoef = f->coef; p.bslots = f->bslots;
+  p.bgamma = f->gamma; p.bdgamma = f->dgamma; p.bdbeta = f->dbeta;
+  p.bpsplit = f->par_split; p.bgamma2 = f->gamma2; p.bdgamma2 = f->dgamma2; p.bdbeta2 = f->dbeta2;
+  p.bact = f->act;
+  p.bdz = (bf16_t*)f->dz; p.bdz_ld = f->dz_ld;
+  int BN, KC;
+  pw_tiles(p, false, &BN, &KC);
+  if (KC > 64) KC = 64;
+  static const int kc_env = getenv("PLYOLO_BNB_KC") ? atoi(getenv("PLYOLO_BNB_KC")) : 0;   // A/B: 32-channel chunks (4 waves per SIMD)
+  if (kc_env == 32) KC = 32;
+  p.pipe = 0;
+  {
+    char lab[64];
+    snprintf(lab, sizeof(lab), "conv_pw_dgrad_bn<BN%d,KC%d>", BN, KC);
+    annotate(lab, 2.0 * p.M * (double)d->Cout * d->Cin, (double)p.M * (3.0 * p.K + d->Cin * (accumulate ? 2.0 : 1.0)) * 2.0);
+  }
+  return submit(stream, [=](hipStream_t s) { return pw_launch_bnb(p, BN, KC, s); });
 }
 
 }  // namespace plyolo

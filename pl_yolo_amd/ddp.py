@@ -6,8 +6,8 @@ over xGMI (torch.distributed backend "nccl" is RCCL on ROCm; "gloo" is used by t
 The exchange is bucketed and overlapped with the backward plan:
   * the flat gradient buffer holds the live parameters in `model.parameters()` order (dead Bottleneck.bn pairs behind
     them, never exchanged); it is cut from the END -- the head, whose gradients are complete first -- into buckets of
-    ~25 MB (PLYOLO_BUCKET_MB), plus one small bucket (PLYOLO_BUCKET_TAIL_MB, 1 MB) for the first backbone layers, the last to
-    finish.  xGMI is point-to-point: few large collectives beat many small ones;
+    ~25 MB (PLYOLO_BUCKET_MB); optionally (PLYOLO_BUCKET_TAIL_MB > 0, default 0 = off) one small bucket for the first backbone
+    layers, the last to finish.  xGMI is point-to-point: few large collectives beat many small ones;
   * a bucket is READY when the backward of every layer owning one of its parameters has been recorded.  At that point
     the backward plan hands the weight-gradient work queued so far to its lane, unpacks the finished weight-gradient
     slabs into the flat buffer there, and records a HOST HOOK on a communication lane that waits for both lanes
@@ -88,6 +88,11 @@ class GradAllReduce:
         self.group = group
         self.world = dist.get_world_size(group)
 
+    def __deepcopy__(self, memo):
+        """ModelEMA deep-copies the model (ema.py:41) and with it this object: the copy shares the process group (a ProcessGroup can
+        neither be copied nor pickled)."""
+        return GradAllReduce(self.group)
+
     def active(self):
         return self.world > 1 or FORCE_COLLECTIVE
 
@@ -148,9 +153,10 @@ class BucketSchedule:
     def __init__(self, runner, session, g):
         self.runner, self.s, self.g, self.ddp = runner, session, g, runner.ddp
         flat = runner.flat
-        # a fork region (the head levels) is atomic for the schedule: its ops count as their region's first op
+        # graph.record_ops() reports i once EVERY op with a forward index >= i has recorded its backward (whatever lane
+        # it sits on, whatever order the lanes were issued in), so a parameter is final at its owner's own index
         def owner_index(op):
-            return op.index if op.region is None else min(o.index for o in op.region.ops)
+            return op.index
         ready_of = {}
         for op in g.ops:
             for p in _op_params(op):
@@ -208,14 +214,17 @@ class BucketSchedule:
             self.entries_left = [i for i in self.entries_left if self.entry_op[i] < done_idx]
             t = g.pack_subtable(todo)
             call("plyolo_unpack_wgrads", t.data_ptr(), len(todo), g.max_pack_elems, 0, None)
-        for op in [o for o in self.post_left if (o.index if o.region is None else min(q.index for q in o.region.ops)) >= done_idx]:
+        for op in [o for o in self.post_left if o.index >= done_idx]:
             op.post_unpack()
             self.post_left.remove(op)
         dbg = int(os.environ.get("PLYOLO_DDP_DBG", "0"))   # diagnostics: 1 no comm lane at all, 2 comm lane waits only for the wgrad lane
         if ready and dbg != 1:
             evs = [plan.record(wl)]
             if wl != 0 and dbg != 2:
-                evs.append(plan.record(0))       # BatchNorm / bias gradients are written on the main lane
+                evs.append(plan.record(0))       # BatchNorm / bias gradients are written on the compute lanes
+                for l in g.side_lanes:
+                    if l != wl:
+                        evs.append(plan.record(l))
             plan.lane(COMM_LANE)
             for ev in evs:
                 plan.wait(COMM_LANE, ev)

@@ -51,7 +51,9 @@ def coco_bbox_eval(json_list, gt, max_dets=100):
             d = sorted(dts.get((img, cat), []), key=lambda x: -x["score"])[:max_dets]
             if not g and not d:
                 continue
-            g_ig = np.array([int(a.get("iscrowd", 0)) or int(a.get("ignore", 0)) for a in g], dtype=int)
+            # bbox evaluation: pycocotools' _prepare overwrites every annotation's 'ignore' with its 'iscrowd', so a dataset's own
+            # 'ignore' flags do not count (cocoeval.py: gt['ignore'] = 'iscrowd' in gt and gt['iscrowd'])
+            g_ig = np.array([int(a.get("iscrowd", 0)) for a in g], dtype=int)
             order = np.argsort(g_ig, kind="mergesort")               # non-ignored gts first
             g = [g[k] for k in order]
             g_ig = g_ig[order]
@@ -125,6 +127,9 @@ def COCOEvaluator(json_list, val_dataset):
     try:
         from pycocotools.cocoeval import COCOeval
     except ImportError:
+        import warnings
+        warnings.warn("pycocotools is not installed: mAP comes from pl_yolo_amd.evaluators.coco_bbox_eval, a restatement of "
+                      "COCOeval('bbox') that is not pinned against pycocotools itself", RuntimeWarning, stacklevel=2)
         return coco_bbox_eval(json_list, _gt_dict(cocoGt))
     annType = ["segm", "bbox", "keypoints"]
     _, tmp = tempfile.mkstemp()

@@ -21,7 +21,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import BF16, F32, ACT, STAT_SLOTS, BnStats, Split, BnBwdSplit, ConvDesc, PackEntry, YoloxDesc, yolov7_desc, call, ptr
+from ._lib import BF16, F32, ACT, STAT_SLOTS, BnStats, Split, BnBwdSplit, BnBwdFuse, ConvDesc, PackEntry, YoloxDesc, yolov7_desc, call, ptr
 
 BN_EPS_DEFAULT = 1e-3
 
@@ -99,7 +99,8 @@ class Graph:
         self.image_act = None
         self.post_unpack = []   # ops with work that must follow unpack_wgrads
         self.plan = None        # the Plan being recorded (ops use it for lanes / events)
-        self.cur_lane, self.cur_region = 0, None
+        self.cur_lane = 0
+        self.side_lanes = []    # compute lanes besides lane 0 used by the plan being recorded (record_ops)
         self.pending = {}       # lane -> queued weight-gradient closures (defer_param_grads)
         # weight gradients on their own lane (PLYOLO_LANES=0 keeps every launch on lane 0)
         self.use_lanes = os.environ.get("PLYOLO_LANES", "1") != "0"
@@ -117,7 +118,10 @@ class Graph:
         # kernels (10.5 -> 12.2 ms/step): SiLU is 2 transcendental + ~6 plain VALU instructions per element, the whole
         # chip sustains ~3.8 T SiLU/s -- the same order as the HBM stream itself -- so inside a loader the work does not
         # disappear, it lengthens every workgroup's load -> stage -> MFMA chain
-        self.lazy_acts = os.environ.get("PLYOLO_LAZY", "0") == "1" and training
+        self.lazy_acts = os.environ.get("PLYOLO_LAZY", "0") in ("1", "2") and training
+        # PLYOLO_LAZY=2: selective -- only where EVERY reader is a pointwise (1x1 stride-1) convolution: those kernels (and their
+        # 1x1 weight gradients) are HBM-bound with an idle VALU, and there is no halo to re-pay the activation on
+        self.lazy_pw_only = os.environ.get("PLYOLO_LAZY", "0") == "2"
 
     # ------------------------------------------------------------------ batched slab folds
     def queue_reduce(self, pc):
@@ -155,6 +159,8 @@ class Graph:
         for op in self.ops:
             outs = op.lazy_outputs() if hasattr(op, "lazy_outputs") else []
             ok = self.lazy_acts and bool(outs) and all(a.lazy_users and not a.needs_tensor for a, _ in outs)
+            if ok and self.lazy_pw_only:
+                ok = all(isinstance(u, HeadPredOp) or (u.k == 1 and u.stride == 1) for a, _ in outs for u in a.lazy_users)
             for a, c_off in outs:
                 if ok:
                     a.lazy = LazySrc(op, op.z, c_off, op.act)
@@ -185,17 +191,20 @@ class Graph:
     # ------------------------------------------------------------------ lanes
     def add_op(self, op):
         op.index = len(self.ops)     # position in forward order
-        op.lane, op.region = self.cur_lane, self.cur_region
-        if self.cur_region is not None:
-            self.cur_region.ops.append(op)
+        op.lane = self.cur_lane
         self.ops.append(op)
 
+    def on_lane(self, lane):
+        """`with g.on_lane(l):` -- ops emitted inside run on launch lane `l` (its own HIP stream under the eager
+        multi-stream replay).  Lanes are a pure placement hint: record_ops() derives every cross-lane ordering from the
+        tensors the ops read and write, so any assignment is correct; a good one puts independent chains side by side
+        (the PAFPN bottom-up path and the small head levels beside the 80x80 head level).  PLYOLO_LANES=0 keeps
+        everything on lane 0."""
+        return _OnLane(self, lane if self.use_lanes else 0)
+
     def fork(self):
-        """Open a fork/join region: ops emitted inside `with region.branch(lane):` blocks run on that lane
-        (concurrently with the other branches under the eager multi-stream replay).  Branches must be
-        independent of each other; everything before / after the region happens before / after all of it.
-        Regions do not nest and only open from lane 0; otherwise (or with PLYOLO_LANES=0) the ops stay inline."""
-        return _Region(self, self.use_lanes and self.cur_region is None and self.cur_lane == 0)
+        """Compatibility spelling: `with g.fork() as r: with r.branch(lane): ...` == `with g.on_lane(lane): ...`."""
+        return _Fork(self)
 
     def defer_param_grads(self, lane, fn):
         """Queue weight-gradient work (a closure issuing launches) for the weight-gradient lane.  The hand-off
@@ -420,92 +429,182 @@ class Graph:
         return acc
 
 
-_OLD_ISSUE = os.environ.get("PLYOLO_ISSUE_OLD", "0") == "1"   # A/B switch for the issue-order experiments
 WGRAD_LANE = 1      # weight gradients (+ their slab reductions); branch lanes are 2, 3, ...
 WGRAD_BATCH = int(os.environ.get("PLYOLO_WGRAD_BATCH", "1"))   # conv units per hand-off event to the weight-gradient lane (measured: 1 == 4 > 8)
 
 
-class _Region:
-    """Fork/join region of the launch plans (Graph.fork)."""
-
-    def __init__(self, g, active):
-        self.g, self.active, self.ops, self.lanes = g, active, [], set()
+class _OnLane:
+    def __init__(self, g, lane):
+        self.g, self.lane = g, lane
 
     def __enter__(self):
-        if self.active:
-            self.g.cur_region = self
+        self.prev, self.g.cur_lane = self.g.cur_lane, self.lane
         return self
 
     def __exit__(self, *exc):
-        if self.active:
-            self.g.cur_region = None
+        self.g.cur_lane = self.prev
+        return False
+
+
+class _Fork:
+    def __init__(self, g):
+        self.g = g
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
         return False
 
     def branch(self, lane):
-        return _Branch(self, lane)
+        return self.g.on_lane(lane)
 
 
-class _Branch:
-    def __init__(self, region, lane):
-        self.region, self.lane = region, lane
+def _res(a):
+    """Resource key (buffer, lo, hi) of what an op touches: a channel range of an activation Storage, or a token tuple."""
+    if isinstance(a, Act):
+        return (id(a.storage), a.c_off, a.c_off + a.C)
+    return a
 
-    def __enter__(self):
-        if self.region.active:
-            self.region.g.cur_lane = self.lane
-            if self.lane != 0:
-                self.region.lanes.add(self.lane)
-        return self
 
-    def __exit__(self, *exc):
-        self.region.g.cur_lane = 0
-        return False
+def _overlap(r1, r2):
+    return r1[0] == r2[0] and r1[1] < r2[2] and r2[1] < r1[2]
+
+
+def op_io(op):
+    """(inputs, outputs) of a launch-plan op as activation views / resource tokens.  The forward reads the inputs and
+    writes the outputs; the backward reads the GRADIENTS of the outputs and writes / accumulates the gradients of the
+    inputs -- the same resources with the roles swapped, which is all record_ops() needs."""
+    if isinstance(op, CopyOp):
+        return [op.src], [op.dst]
+    if isinstance(op, ConvPairOp):
+        return [op.x], [op.out_a, op.out_b]
+    if isinstance(op, (ConvUnitOp, DwConvUnitOp, BnOnlyOp)):
+        return [op.x] + ([op.res] if op.res is not None else []), [op.out]
+    if isinstance(op, (BicubicUpsampleOp, ActOp, LnWidthOp, UpsampleOp, MaxPool2x2Op)):
+        return [op.x], [op.out]
+    if isinstance(op, SppPoolsOp):
+        return [op.x, ("scratch32", 0, 1)], list(op.outs)
+    if isinstance(op, ImplicitHeadOp):
+        return [op.x], [(("head", id(op.head)), op.level, op.level + 1)]
+    if isinstance(op, HeadPredOp):
+        return [op.cls_feat, op.reg_feat], [(("head", id(op.head)), op.level, op.level + 1)]
+    if isinstance(op, (YoloxLossOp, YoloV7LossOp, YoloxEvalDecodeOp, YoloV7EvalDecodeOp)):
+        return [(("head", id(op.head)), 0, 1 << 20)], []
+    raise TypeError("record_ops: op_io() does not know %s" % type(op).__name__)
 
 
 def record_ops(g, plan, ops, method, lanes=True, after=None):
-    """Record `op.<method>()` for every op in `ops` (forward order, or reversed for the backward plan)
-    with the fork / join events of the regions they belong to.  Inside a region the branches are issued
-    round-robin (lane 0 first): the branches are independent, so any interleaving that keeps each lane's
-    order is a valid serial order, and every lane gets work while the host is still issuing the others."""
-    i, n = 0, len(ops)
-    while i < n:
-        op = ops[i]
-        r = op.region if lanes else None
-        if r is None:
+    """Record `op.<method>()` for every op of `ops` (forward order, or reversed for the backward plan), each on its
+    lane, with exactly the cross-lane events the data flow needs.
+
+    `ops` is a valid serial order.  Two ops conflict when one writes a resource the other touches (op_io; in a backward
+    plan a gradient that several consumers accumulate into is written by all of them, so they stay ordered as listed,
+    which is also the order the first-writer / accumulate flags are resolved in).  Conflicts between ops of ONE lane are
+    ordered by the lane; for a conflict across lanes the later op waits for an event recorded right behind the earlier
+    one.  The issue order is a list schedule: the lanes take turns (lane 0 first) and a lane whose next op still waits
+    for an unrecorded producer is skipped -- every lane gets launches while the host is still issuing the others, and
+    the recorded order stays a valid serialisation (single-stream replays, hipGraph capture, the profiler).
+    `after(i)` (data-parallel bucket schedule) is called whenever every op with forward index >= i has been recorded."""
+    n = len(ops)
+    use = lanes and g.use_lanes
+    lane = [(o.lane if use else 0) for o in ops]
+    g.side_lanes = sorted(set(lane) - {0})
+    done = [False] * len(g.ops)
+    bound = [len(g.ops)]
+
+    def mark(op):
+        if after is None:
+            return
+        done[op.index] = True
+        b = bound[0]
+        while b > 0 and done[b - 1]:
+            b -= 1
+        if b != bound[0]:
+            bound[0] = b
+            after(b)
+
+    if not g.side_lanes:
+        for op in ops:
             plan.lane(0)
             getattr(op, method)()
-            i += 1
-            if after is not None:
-                after(op.index)      # backward plans: every op with a forward index >= op.index has been recorded
-            continue
-        j = i
-        while j < n and ops[j].region is r:
-            j += 1
-        assert j - i == len(r.ops), "a fork region must be contiguous in the op list"
-        queues = {}
-        for o in ops[i:j]:
-            queues.setdefault(o.lane, []).append(o)
-        order = sorted(queues)           # lane 0 (the critical path) first
-        fork = plan.record(0)
+            mark(op)
+        plan.lane(0)
+        g.flush_reduce_on_lane()
+        return
+    bwd = method == "bwd"
+    rd, wr = [], []
+    for o in ops:
+        ins, outs = op_io(o)
+        ins, outs = [_res(a) for a in ins], [_res(a) for a in outs]
+        rd.append(outs if bwd else ins)
+        wr.append(ins if bwd else outs)
+
+    def conflict(j, i):
+        for w in wr[j]:
+            for t in rd[i] + wr[i]:
+                if _overlap(w, t):
+                    return True
+        for w in wr[i]:
+            for t in rd[j]:
+                if _overlap(w, t):
+                    return True
+        return False
+
+    # deps[i]: for every other lane the LATEST earlier op there that conflicts with op i (older ones are implied by the
+    # lane's order), unless this lane already waited for that lane at or beyond it
+    deps, need_ev = [[] for _ in range(n)], [False] * n
+    synced = {}
+    for i in range(n):
+        li = lane[i]
+        latest = {}
+        for j in range(i - 1, -1, -1):
+            lj = lane[j]
+            if lj == li or lj in latest:
+                continue
+            if conflict(j, i):
+                latest[lj] = j
+        for lj, j in latest.items():
+            if synced.get((li, lj), -1) >= j:
+                continue
+            synced[(li, lj)] = j
+            deps[i].append(j)
+            need_ev[j] = True
+    queues = {}
+    for i in range(n):
+        queues.setdefault(lane[i], []).append(i)
+    order = sorted(queues)
+    plan.lane(0)
+    ev0 = plan.record(0)         # whatever the plan recorded before its ops (weight packing, stat-slot fills)
+    started = {0}
+    issued, ev = [False] * n, [None] * n
+    left = n
+    while left:
+        progressed = False
         for l in order:
-            if l != 0:
-                plan.wait(l, fork)
-        if _OLD_ISSUE:                   # branch after branch, in list order
-            for o in ops[i:j]:
-                plan.lane(o.lane)
-                getattr(o, method)()
-            queues = {}
-        while any(queues.values()):
-            for l in order:
-                if queues[l]:
-                    plan.lane(l)
-                    getattr(queues[l].pop(0), method)()
-        for l in order:                 # join: lane 0 continues after every branch lane
-            if l != 0:
-                g.flush_param_grads(l)  # weight-gradient work queued by this branch leaves with the branch
-                plan.wait(0, plan.record(l))
-        if after is not None:
-            after(min(o.index for o in ops[i:j]))
-        i = j
+            q = queues[l]
+            if not q or not all(issued[j] for j in deps[q[0]]):
+                continue
+            i = q.pop(0)
+            plan.lane(l)
+            if l not in started:
+                started.add(l)
+                plan.wait(l, ev0)
+            for j in deps[i]:
+                plan.wait(l, ev[j])
+            getattr(ops[i], method)()
+            plan.lane(l)
+            if need_ev[i]:
+                ev[i] = plan.record(l)
+            issued[i] = True
+            left -= 1
+            progressed = True
+            mark(ops[i])
+        assert progressed, "record_ops: the op list is not a valid serial order"
+    for l in order:                 # what follows the ops on lane 0 (slab folds, unpack, optimizer) sees every lane's results
+        if l != 0:
+            g.flush_param_grads(l)
+            plan.wait(0, plan.record(l))
     plan.lane(0)
     g.flush_reduce_on_lane()   # slab folds still queued (backward plans): nothing may read slab 0 before them
 
@@ -685,18 +784,31 @@ class ConvUnitOp:
             call("plyolo_copy_add", g.dtype, M, Cout, dout, self.out.ld, g.gptr(self.res), self.res.ld, acc, None)
         plan, lanes, me = g.plan, g.use_lanes, self.lane
         dz, key = g.dz_buffer(self, M * Cout)
+        fused = False
         if bn is None:
             # BaseConv(norm=None): out = act(z)  (ecmnet.py:158 Bottleneck.conv1) -> dz = dout * act'(z)
             call("plyolo_act_bwd", g.dtype, M, Cout, dout, self.out.ld, zt, Cout, self.act, dz, Cout, 0, None)
         else:
             bslots = g.bstat_arena.data_ptr() + self.slot_off * 8
             call("plyolo_bn_act_bwd_reduce", g.dtype, M, Cout, dout, self.out.ld, zt, Cout, self.coef.data_ptr(), self.act, bslots, None, None)
-            call("plyolo_bn_act_bwd_dz", g.dtype, M, Cout, dout, self.out.ld, zt, Cout, self.coef.data_ptr(), bslots, ptr(bn.weight),
-                 g.grad_ptr_of(bn.weight), g.grad_ptr_of(bn.bias), 0, self.act, dz, Cout, None, None, None)
+            # pointwise units: dz is formed inside the data gradient's loader (one launch and one pass over dout / z less)
+            fused = self.need_dgrad and _lib.lib().plyolo_conv2d_dgrad_bn_fits(C.byref(self.desc_d), self.act) == 1
+            if fused:
+                f = BnBwdFuse()
+                f.dout, f.dout_ld, f.z, f.z_ld, f.coef, f.bslots = dout, self.out.ld, zt, Cout, self.coef.data_ptr(), bslots
+                f.gamma, f.dgamma, f.dbeta = ptr(bn.weight), g.grad_ptr_of(bn.weight), g.grad_ptr_of(bn.bias)
+                f.act, f.dz, f.dz_ld = self.act, dz, Cout
+                self.keep_f = f
+            else:
+                call("plyolo_bn_act_bwd_dz", g.dtype, M, Cout, dout, self.out.ld, zt, Cout, self.coef.data_ptr(), bslots, ptr(bn.weight),
+                     g.grad_ptr_of(bn.weight), g.grad_ptr_of(bn.bias), 0, self.act, dz, Cout, None, None, None)
         def dgrad():
             if self.need_dgrad:
                 acc = g.grad_mode(self.x)
-                call("plyolo_conv2d_dgrad", C.byref(self.desc_d), dz, self.pc.wpd, g.gptr(self.x), acc, None)
+                if fused:
+                    call("plyolo_conv2d_dgrad_bn", C.byref(self.desc_d), C.byref(f), self.pc.wpd, g.gptr(self.x), acc, None)
+                else:
+                    call("plyolo_conv2d_dgrad", C.byref(self.desc_d), dz, self.pc.wpd, g.gptr(self.x), acc, None)
 
         def wgrad():
             call("plyolo_conv2d_wgrad", C.byref(self.desc), self.xptr, dz, self.pc.dwp, None)
@@ -708,8 +820,12 @@ class ConvUnitOp:
             dgrad()
             g.defer_param_grads(me, wgrad)
         else:
-            wgrad()
-            dgrad()
+            if fused:   # the fused data gradient produces dz: it has to run first
+                dgrad()
+                wgrad()
+            else:
+                wgrad()
+                dgrad()
 
 
 class ConvPairOp:
@@ -799,22 +915,42 @@ class ConvPairOp:
              bslots, C.byref(dsp), None)
         plan, lanes, me = g.plan, g.use_lanes, self.lane
         dz, key = g.dz_buffer(self, M * Cout)
-        p2 = BnBwdSplit()
-        p2.split, p2.gamma2, p2.dgamma2, p2.dbeta2 = self.Ca, ptr(b.weight), g.grad_ptr_of(b.weight), g.grad_ptr_of(b.bias)
-        call("plyolo_bn_act_bwd_dz", g.dtype, M, Cout, g.gptr(self.out_a), self.out_a.ld, zt, Cout, self.coef.data_ptr(), bslots,
-             ptr(a.weight), g.grad_ptr_of(a.weight), g.grad_ptr_of(a.bias), 0, self.act, dz, Cout, C.byref(dsp), C.byref(p2), None)
+        fused = _lib.lib().plyolo_conv2d_dgrad_bn_fits(C.byref(self.desc_d), self.act) == 1
+        if fused:    # pointwise pair (CSP conv1 || conv2): dz is formed inside the data gradient's loader
+            f = BnBwdFuse()
+            f.dout, f.dout_ld, f.dout2, f.dout2_ld, f.dout_split = g.gptr(self.out_a), self.out_a.ld, dsp.p2, dsp.ld2, self.Ca
+            f.z, f.z_ld, f.coef, f.bslots = zt, Cout, self.coef.data_ptr(), bslots
+            f.gamma, f.dgamma, f.dbeta = ptr(a.weight), g.grad_ptr_of(a.weight), g.grad_ptr_of(a.bias)
+            f.par_split, f.gamma2, f.dgamma2, f.dbeta2 = self.Ca, ptr(b.weight), g.grad_ptr_of(b.weight), g.grad_ptr_of(b.bias)
+            f.act, f.dz, f.dz_ld = self.act, dz, Cout
+            self.keep_f = f
+        else:
+            p2 = BnBwdSplit()
+            p2.split, p2.gamma2, p2.dgamma2, p2.dbeta2 = self.Ca, ptr(b.weight), g.grad_ptr_of(b.weight), g.grad_ptr_of(b.bias)
+            call("plyolo_bn_act_bwd_dz", g.dtype, M, Cout, g.gptr(self.out_a), self.out_a.ld, zt, Cout, self.coef.data_ptr(), bslots,
+                 ptr(a.weight), g.grad_ptr_of(a.weight), g.grad_ptr_of(a.bias), 0, self.act, dz, Cout, C.byref(dsp), C.byref(p2), None)
         acc = g.grad_mode(self.x)
 
         def wgrad():
             call("plyolo_conv2d_wgrad", C.byref(self.desc), self.xptr, dz, self.pc.dwp, None)
             self.pc.reduce_slabs()
 
+        def dgrad():
+            if fused:
+                call("plyolo_conv2d_dgrad_bn", C.byref(self.desc_d), C.byref(f), self.pc.wpd, g.gptr(self.x), acc, None)
+            else:
+                call("plyolo_conv2d_dgrad", C.byref(self.desc_d), dz, self.pc.wpd, g.gptr(self.x), acc, None)
+
         if lanes:
-            call("plyolo_conv2d_dgrad", C.byref(self.desc_d), dz, self.pc.wpd, g.gptr(self.x), acc, None)
+            dgrad()
             g.defer_param_grads(me, wgrad)
         else:
-            wgrad()
-            call("plyolo_conv2d_dgrad", C.byref(self.desc_d), dz, self.pc.wpd, g.gptr(self.x), acc, None)
+            if fused:     # the fused data gradient produces dz: it has to run first
+                dgrad()
+                wgrad()
+            else:
+                wgrad()
+                dgrad()
 
 
 class DwConvUnitOp:

@@ -9,11 +9,16 @@ from . import graph as G
 from .layers import emit_pair, BaseConv, HipModule
 
 
-# Lanes of the head levels.  PLYOLO_HEAD_ONE_LANE: 0 a lane per level (lanes 2, 3), 1 levels 1 and 2 share lane 2 (three streams per
-# plan, the default: one per hardware queue), 2 every level on the main lane.  pl_yolo_amd/__init__.py has the measurements.
-_HEAD_LANES = os.environ.get("PLYOLO_HEAD_ONE_LANE", "1")
-_NO_SIDE_LANE = _HEAD_LANES == "2"
-_ONE_SIDE_LANE = _HEAD_LANES == "1"
+# Launch lanes (graph.Graph.on_lane) of the head levels: PLYOLO_HEAD_LANES = one lane per level, the last entry repeats.
+# Default "0,0,2": the 80x80 and the 40x40 level on the main lane, the 20x20 level on the side lane that also carries the
+# neck's bottom-up path (necks.py) -- the big level-0 kernels then run beside the short, latency-bound 40x40 / 20x20 kernels of
+# the neck instead of after them.  "0,2,2" is the round-2 layout (with PLYOLO_NECK_LANE=0), "0,0,0" keeps every level on lane 0.
+_LEGACY = os.environ.get("PLYOLO_HEAD_ONE_LANE")
+_HEAD_LANES = [int(v) for v in os.environ.get("PLYOLO_HEAD_LANES", {"0": "0,2,3", "1": "0,2,2", "2": "0,0,0"}.get(_LEGACY, "0,0,2")).split(",")]
+
+
+def head_lane(k):
+    return _HEAD_LANES[k] if k < len(_HEAD_LANES) else _HEAD_LANES[-1]
 
 
 class DecoupledHead(HipModule):
@@ -53,20 +58,18 @@ class DecoupledHead(HipModule):
     def emit(self, g, inputs, head_buffers):
         """Writes the raw predictions of every level into `head_buffers.raw`
         (channel order reg(4), obj(1), cls(C) -- decoupled_head.py:93)."""
-        # the levels are independent from the stem conv to the prediction convs (and back, in the backward
-        # plan): level 0 stays on the main lane, the two smaller levels run beside it on lane 2, one after the other (with a lane
-        # each the step is 0.9 % slower: four streams on three hardware queues, see pl_yolo_amd/__init__.py)
-        with g.fork() as region:
-            for k, x in enumerate(inputs):
-                with region.branch(0 if (k == 0 or _NO_SIDE_LANE) else (2 if _ONE_SIDE_LANE else 1 + k)):
-                    x = self.stems[k].emit(g, x)
-                    # the first conv of the cls and of the reg branch read the same stem output: one merged conv
-                    cls_feat, reg_feat = emit_pair(g, x, self.cls_convs[k][0], self.reg_convs[k][0])
-                    for m in list(self.cls_convs[k])[1:]:
-                        cls_feat = m.emit(g, cls_feat)
-                    for m in list(self.reg_convs[k])[1:]:
-                        reg_feat = m.emit(g, reg_feat)
-                    G.HeadPredOp(g, head_buffers, k, cls_feat, reg_feat, self.cls_preds[k], self.reg_preds[k], self.obj_preds[k])
+        # the levels are independent from the stem conv to the prediction convs (and back, in the backward plan): each runs
+        # on the lane head_lane() names; graph.record_ops() orders them against the neck from the tensors they touch
+        for k, x in enumerate(inputs):
+            with g.on_lane(head_lane(k)):
+                x = self.stems[k].emit(g, x)
+                # the first conv of the cls and of the reg branch read the same stem output: one merged conv
+                cls_feat, reg_feat = emit_pair(g, x, self.cls_convs[k][0], self.reg_convs[k][0])
+                for m in list(self.cls_convs[k])[1:]:
+                    cls_feat = m.emit(g, cls_feat)
+                for m in list(self.reg_convs[k])[1:]:
+                    reg_feat = m.emit(g, reg_feat)
+                G.HeadPredOp(g, head_buffers, k, cls_feat, reg_feat, self.cls_preds[k], self.reg_preds[k], self.obj_preds[k])
         return head_buffers
 
 

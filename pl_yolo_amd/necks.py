@@ -1,10 +1,17 @@
 """CSP-PAFPN neck (reference models/necks/pafpn_csp.py:7-86)."""
+import os
+
 import torch
 import torch.nn as nn
 
 from . import graph as G
 from ._lib import PlyoloError
 from .layers import emit_pair, BaseConv, CSPLayer, HipModule
+
+
+# Launch lane of the bottom-up path (n3 -> n4 -> n5): its 40x40 / 20x20 kernels are short and latency-bound, and nothing on the
+# 80x80 head level depends on them -- on a side lane they run beside that level instead of in front of it (heads.py: PLYOLO_HEAD_LANES).
+_NECK_LANE = int(os.environ.get("PLYOLO_NECK_LANE", "2"))
 
 
 class CSPPAFPN(HipModule):
@@ -34,10 +41,11 @@ class CSPPAFPN(HipModule):
         p3 = self.p4_p3.emit(g, g.concat([p4_upsample, c3]))
         # bottom-up
         n3 = p3
-        n3_downsample = self.downsample_conv1.emit(g, n3)
-        n4 = self.n3_n4.emit(g, g.concat([n3_downsample, p4_expand]))
-        n4_downsample = self.downsample_conv2.emit(g, n4)
-        n5 = self.n4_n5.emit(g, g.concat([n4_downsample, p5_expand]))
+        with g.on_lane(_NECK_LANE):
+            n3_downsample = self.downsample_conv1.emit(g, n3)
+            n4 = self.n3_n4.emit(g, g.concat([n3_downsample, p4_expand]))
+            n4_downsample = self.downsample_conv2.emit(g, n4)
+            n5 = self.n4_n5.emit(g, g.concat([n4_downsample, p5_expand]))
         return (n3, n4, n5)
 
 
@@ -198,8 +206,10 @@ class YOLOv7NECK(HipModule):
         p4_upsample = G.UpsampleOp(g, p4_shrink).out
         p3 = self.p4_p3.emit(g, g.concat([p4_upsample, self.conv_for_C3.emit(g, c3)]))
         n3 = p3
-        n3_downsample = self.downsample_conv1.emit(g, n3)
-        n4 = self.n3_n4.emit(g, g.concat([n3_downsample, p4]))
-        n4_downsample = self.downsample_conv2.emit(g, n4)
-        n5 = self.n4_n5.emit(g, g.concat([n4_downsample, p5]))
-        return (self.n3.emit(g, n3), self.n4.emit(g, n4), self.n5.emit(g, n5))
+        with g.on_lane(_NECK_LANE):
+            n3_downsample = self.downsample_conv1.emit(g, n3)
+            n4 = self.n3_n4.emit(g, g.concat([n3_downsample, p4]))
+            n4_downsample = self.downsample_conv2.emit(g, n4)
+            n5 = self.n4_n5.emit(g, g.concat([n4_downsample, p5]))
+            o4, o5 = self.n4.emit(g, n4), self.n5.emit(g, n5)
+        return (self.n3.emit(g, n3), o4, o5)

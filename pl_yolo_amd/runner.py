@@ -240,7 +240,7 @@ class DetectorRunner:
         stream.  Eager replays go straight onto that stream; hipGraph replays use a
         private stream (capture is not allowed on the legacy default stream) fenced with
         events on both sides."""
-        use_graph = self.use_graph if self.use_graph != "auto" else plan.lanes() <= 1
+        use_graph = self.use_graph if self.use_graph != "auto" else (plan.lanes() <= 1 and not plan.hooks())
         if self.use_graph == "auto" and os.environ.get("PLYOLO_GRAPH_FWD") == "1" and getattr(plan, "is_fwd", False):
             use_graph = True    # experiment: forward plans as hipGraphs, backward plans eagerly
         if use_graph and plan.hooks():
@@ -289,12 +289,31 @@ class DetectorRunner:
         s.generation += 1
         return s
 
-    def backward_train(self, s, gout):
-        s.head.gout[:gout.numel()].copy_(gout.reshape(-1))
-        self._run_plan(s.bwd)
+    def _run_backward(self, s):
+        """Replay the backward plan.  A failing launch or gradient-exchange hook surfaces as the REAL error (the exception the hook
+        stored, not the replay's generic 'launch N (hook) failed'), the collectives already started are still awaited so the next
+        step does not inherit them, and in a process group the failure takes the job down instead of leaving the peers in a collective."""
+        try:
+            self._run_plan(s.bwd)
+        except BaseException as e:
+            if s.sched is not None:
+                try:
+                    s.sched.wait_all()
+                except BaseException:
+                    pass
+                s.sched.pending = []
+                hook_err = getattr(s.sched.plan, "hook_error", None)
+                s.sched.plan.hook_error = None
+                if hook_err is not None:
+                    raise PlyoloError("gradient exchange failed inside the backward plan: %r" % (hook_err,)) from hook_err
+            raise e
         if s.sched is not None:
             s.sched.wait_all()
             s.sched.check()
+
+    def backward_train(self, s, gout):
+        s.head.gout[:gout.numel()].copy_(gout.reshape(-1))
+        self._run_backward(s)
 
     def forward_eval(self, x):
         x = self._check_input(x)
@@ -321,10 +340,7 @@ class DetectorRunner:
 
     def backward_maps(self, s, grads):
         s.head.set_map_grads(grads)
-        self._run_plan(s.bwd)
-        if s.sched is not None:
-            s.sched.wait_all()
-            s.sched.check()
+        self._run_backward(s)
 
 
 def _check_generation(ctx, s):

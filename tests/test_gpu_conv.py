@@ -242,3 +242,69 @@ def test_conv3ws_opt_in_kernel(shape, monkeypatch):
     monkeypatch.setenv("PLYOLO_CONV3WS", "1")
     test_conv_fwd_stats(BF16, shape)
     test_conv_dgrad(BF16, shape)
+
+
+# (N, H, W, Cin, Cout, split): pointwise units; Cin 256 = two output blocks of the kernel, Cout 96 = a 64 + 32 channel chunk tail
+@pytest.mark.parametrize("shape", [(2, 20, 20, 128, 128, 0), (3, 20, 20, 256, 96, 0), (2, 40, 40, 64, 128, 64), (1, 13, 9, 32, 64, 24), (4, 40, 40, 16, 32, 0)], ids=str)
+@pytest.mark.parametrize("act", ["silu", "lrelu", None])
+def test_pointwise_dgrad_with_fused_bn_backward(shape, act):
+    """plyolo_conv2d_dgrad_bn == plyolo_bn_act_bwd_dz + plyolo_conv2d_dgrad, bit for bit (dz, dx, dgamma, dbeta), also for a merged pair
+    (output gradient in two matrices, two BatchNorm parameter sets) and with accumulation into dx."""
+    from pl_yolo_amd._lib import ACT, BnBwdFuse, Split, BnBwdSplit, STAT_SLOTS
+    N, H, W, Cin, Cout, split = shape
+    dt, M = BF16, N * H * W
+    torch.manual_seed(sum(shape) + 3)
+    dev = hu.DEV
+    w = hu.rnd_bf16(torch.randn(Cout, Cin, 1, 1, device=dev) / Cout ** 0.5)
+    pk = hu.Packed(w, dt)
+    z = (torch.randn(M, Cout, device=dev) * 1.5).to(torch.bfloat16)
+    Ca = split if split else Cout
+    d_ld = Ca + 8
+    dout = torch.randn(M, d_ld, device=dev).to(torch.bfloat16)
+    dout2 = torch.randn(M, Cout - Ca + 16, device=dev).to(torch.bfloat16) if split else None
+    gamma, gamma2 = torch.rand(Cout, device=dev) + 0.5, torch.rand(Cout, device=dev) + 0.5
+    mean, invstd = torch.randn(Cout, device=dev) * 0.1, torch.rand(Cout, device=dev) + 0.5
+    beta = torch.randn(Cout, device=dev) * 0.1
+    g_eff = torch.cat([gamma[:Ca], gamma2[:Cout - Ca]]) if split else gamma
+    scale = g_eff * invstd
+    coef = torch.cat([scale, beta - mean * scale, mean, invstd]).contiguous()
+    bslots = torch.zeros(STAT_SLOTS * 2 * Cout, dtype=torch.float64, device=dev)
+    sp = Split()
+    if split:
+        sp.split, sp.p2, sp.ld2 = Ca, dout2.data_ptr(), dout2.shape[1]
+    a = ACT[act]
+    call("plyolo_bn_act_bwd_reduce", dt, M, Cout, dout.data_ptr(), d_ld, z.data_ptr(), Cout, coef.data_ptr(), a, bslots.data_ptr(),
+         C.byref(sp) if split else None, hu.stream())
+    x_ld = Cin + 8
+    d = hu.conv_desc(dt, N, H, W, Cin, Cout, 1, 1, x_ld, Cout)
+    assert hu._lib.lib().plyolo_conv2d_dgrad_bn_fits(C.byref(d), a) == 1
+    base = torch.randn(M, x_ld, device=dev).to(torch.bfloat16)
+    for acc in (0, 1):
+        # reference: the two separate launches
+        dz0 = torch.zeros(M, Cout, dtype=torch.bfloat16, device=dev)
+        dg0, db0, dg0b, db0b = (torch.zeros(Cout, device=dev) for _ in range(4))
+        p2 = BnBwdSplit()
+        if split:
+            p2.split, p2.gamma2, p2.dgamma2, p2.dbeta2 = Ca, gamma2.data_ptr(), dg0b.data_ptr(), db0b.data_ptr()
+        call("plyolo_bn_act_bwd_dz", dt, M, Cout, dout.data_ptr(), d_ld, z.data_ptr(), Cout, coef.data_ptr(), bslots.data_ptr(), gamma.data_ptr(),
+             dg0.data_ptr(), db0.data_ptr(), 0, a, dz0.data_ptr(), Cout, C.byref(sp) if split else None, C.byref(p2) if split else None, hu.stream())
+        dx0 = base.clone()
+        call("plyolo_conv2d_dgrad", C.byref(d), dz0.data_ptr(), pk.wpd.data_ptr(), dx0.data_ptr(), acc, hu.stream())
+        # fused
+        dz1 = torch.zeros(M, Cout, dtype=torch.bfloat16, device=dev)
+        dg1, db1, dg1b, db1b = (torch.zeros(Cout, device=dev) for _ in range(4))
+        f = BnBwdFuse()
+        f.dout, f.dout_ld, f.z, f.z_ld, f.coef, f.bslots = dout.data_ptr(), d_ld, z.data_ptr(), Cout, coef.data_ptr(), bslots.data_ptr()
+        if split:
+            f.dout2, f.dout2_ld, f.dout_split = dout2.data_ptr(), dout2.shape[1], Ca
+            f.par_split, f.gamma2, f.dgamma2, f.dbeta2 = Ca, gamma2.data_ptr(), dg1b.data_ptr(), db1b.data_ptr()
+        f.gamma, f.dgamma, f.dbeta, f.act, f.dz, f.dz_ld = gamma.data_ptr(), dg1.data_ptr(), db1.data_ptr(), a, dz1.data_ptr(), Cout
+        dx1 = base.clone()
+        call("plyolo_conv2d_dgrad_bn", C.byref(d), C.byref(f), pk.wpd.data_ptr(), dx1.data_ptr(), acc, hu.stream())
+        torch.cuda.synchronize()
+        assert torch.equal(dz0.view(torch.int16), dz1.view(torch.int16)), "dz differs"
+        assert torch.equal(dx0[:, :Cin].view(torch.int16), dx1[:, :Cin].view(torch.int16)), "dx differs"
+        assert torch.equal(dx1[:, Cin:], base[:, Cin:]), "pad columns of dx touched"
+        for u, v in ((dg0, dg1), (db0, db1), (dg0b, dg1b), (db0b, db1b)):
+            assert torch.equal(u, v)
+        assert float(dz1.float().abs().max()) > 0
