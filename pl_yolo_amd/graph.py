@@ -99,7 +99,7 @@ class Graph:
         self.image_act = None
         self.post_unpack = []   # ops with work that must follow unpack_wgrads
         self.plan = None        # the Plan being recorded (ops use it for lanes / events)
-        self.cur_lane = 0
+        self.cur_lane, self.cur_lane_fwd = 0, None
         self.side_lanes = []    # compute lanes besides lane 0 used by the plan being recorded (record_ops)
         self.pending = {}       # lane -> queued weight-gradient closures (defer_param_grads)
         # weight gradients on their own lane (PLYOLO_LANES=0 keeps every launch on lane 0)
@@ -192,6 +192,7 @@ class Graph:
     def add_op(self, op):
         op.index = len(self.ops)     # position in forward order
         op.lane = self.cur_lane
+        op.lane_fwd = self.cur_lane_fwd if self.cur_lane_fwd is not None else self.cur_lane   # forward plans may place an op elsewhere
         self.ops.append(op)
 
     def on_lane(self, lane):
@@ -200,7 +201,12 @@ class Graph:
         tensors the ops read and write, so any assignment is correct; a good one puts independent chains side by side
         (the PAFPN bottom-up path and the small head levels beside the 80x80 head level).  PLYOLO_LANES=0 keeps
         everything on lane 0."""
-        return _OnLane(self, lane if self.use_lanes else 0)
+        return _OnLane(self, lane if self.use_lanes else 0, None)
+
+    def on_lanes(self, lane_fwd, lane_bwd):
+        """Like on_lane, with a lane of its own for the FORWARD plan: the weight-gradient lane (1) idles there and can carry a
+        branch; in the backward plan the same ops sit on `lane_bwd`."""
+        return _OnLane(self, lane_bwd if self.use_lanes else 0, lane_fwd if self.use_lanes else 0)
 
     def fork(self):
         """Compatibility spelling: `with g.fork() as r: with r.branch(lane): ...` == `with g.on_lane(lane): ...`."""
@@ -434,15 +440,16 @@ WGRAD_BATCH = int(os.environ.get("PLYOLO_WGRAD_BATCH", "1"))   # conv units per 
 
 
 class _OnLane:
-    def __init__(self, g, lane):
-        self.g, self.lane = g, lane
+    def __init__(self, g, lane, lane_fwd):
+        self.g, self.lane, self.lane_fwd = g, lane, lane_fwd
 
     def __enter__(self):
-        self.prev, self.g.cur_lane = self.g.cur_lane, self.lane
+        self.prev = (self.g.cur_lane, self.g.cur_lane_fwd)
+        self.g.cur_lane, self.g.cur_lane_fwd = self.lane, self.lane_fwd
         return self
 
     def __exit__(self, *exc):
-        self.g.cur_lane = self.prev
+        self.g.cur_lane, self.g.cur_lane_fwd = self.prev
         return False
 
 
@@ -508,7 +515,7 @@ def record_ops(g, plan, ops, method, lanes=True, after=None):
     `after(i)` (data-parallel bucket schedule) is called whenever every op with forward index >= i has been recorded."""
     n = len(ops)
     use = lanes and g.use_lanes
-    lane = [(o.lane if use else 0) for o in ops]
+    lane = [((o.lane_fwd if method == "fwd" else o.lane) if use else 0) for o in ops]
     g.side_lanes = sorted(set(lane) - {0})
     done = [False] * len(g.ops)
     bound = [len(g.ops)]

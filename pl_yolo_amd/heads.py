@@ -17,8 +17,12 @@ _LEGACY = os.environ.get("PLYOLO_HEAD_ONE_LANE")
 _HEAD_LANES = [int(v) for v in os.environ.get("PLYOLO_HEAD_LANES", {"0": "0,2,3", "1": "0,2,2", "2": "0,0,0"}.get(_LEGACY, "0,0,2")).split(",")]
 
 
-def head_lane(k):
-    return _HEAD_LANES[k] if k < len(_HEAD_LANES) else _HEAD_LANES[-1]
+_HEAD_LANES_FWD = [int(v) for v in os.environ["PLYOLO_HEAD_LANES_FWD"].split(",")] if os.environ.get("PLYOLO_HEAD_LANES_FWD") else _HEAD_LANES
+
+
+def head_lane(k, fwd=False):
+    t = _HEAD_LANES_FWD if fwd else _HEAD_LANES
+    return t[k] if k < len(t) else t[-1]
 
 
 class DecoupledHead(HipModule):
@@ -61,7 +65,7 @@ class DecoupledHead(HipModule):
         # the levels are independent from the stem conv to the prediction convs (and back, in the backward plan): each runs
         # on the lane head_lane() names; graph.record_ops() orders them against the neck from the tensors they touch
         for k, x in enumerate(inputs):
-            with g.on_lane(head_lane(k)):
+            with g.on_lanes(head_lane(k, True), head_lane(k)):
                 x = self.stems[k].emit(g, x)
                 # the first conv of the cls and of the reg branch read the same stem output: one merged conv
                 cls_feat, reg_feat = emit_pair(g, x, self.cls_convs[k][0], self.reg_convs[k][0])

@@ -20,6 +20,19 @@ def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
 
 
+def warm_s_state(g):
+    """state_dict of the network_yolox_s_warm fixture: float tensors are stored as bf16 bit patterns (the reference's recorded step
+    ran from exactly these values), integer buffers as they are."""
+    import torch
+    sd = {}
+    for k, v in g.items():
+        if k.startswith("state16/"):
+            sd[k[8:]] = torch.from_numpy(v.copy()).view(torch.bfloat16).float()
+        elif k.startswith("state/"):
+            sd[k[6:]] = torch.from_numpy(v.copy())
+    return sd
+
+
 @pytest.fixture(scope="session")
 def golden():
     return load_golden

@@ -15,7 +15,7 @@ import yaml
 pytestmark = pytest.mark.gpu
 
 import pl_yolo_amd  # noqa: E402
-from conftest import load_golden, ROOT  # noqa: E402
+from conftest import load_golden, warm_s_state, ROOT  # noqa: E402
 from oracle import net as onet, detector as odet  # noqa: E402
 import hiputil as hu  # noqa: E402
 
@@ -136,9 +136,9 @@ def test_bf16_train_step_vs_golden():
             print("low cosine", n, c)
     allc = hu.cossim(torch.cat([g16[n].flatten() for n in g32]), torch.cat([g32[n].flatten() for n in g32]))
     print("bf16 vs fp32 gradient cosine: all %.5f worst tensor %.5f" % (allc, worst))
-    # random-init BN nets amplify perturbations ~1.1x per layer ("bf16 mode"),
-    # so cross-precision gradient agreement is bounded by the forward divergence
-    assert allc >= 0.8 and worst >= 0.4  # 8-channel toy net: sanity bound only; see test_yolox_s_bf16_vs_oracle
+    # Printed, not asserted: a random-initialised 8-channel BatchNorm net amplifies a bf16 rounding ~1.1x per layer (DESIGN.md,
+    # "bf16 mode"), so this cosine says nothing about the kernels (0.8 / 0.4 used to be "asserted" here).  The bf16 backward is
+    # held to >= 0.99 on trained weights instead: test_warm_weights_* (toy net) and test_warm_yolox_s_* (the benchmarked net).
 
 
 def test_hipgraph_replay_matches_eager():
@@ -220,7 +220,7 @@ def test_yolox_s_bf16_vs_oracle():
     cs = hu.cossim(a, b)
     worst = min(hu.cossim(grads[n].cpu(), state[n].grad) for n in grads)
     print("yolox_s gradient cosine vs oracle: all %.5f worst tensor %.5f" % (cs, worst))
-    assert cs >= 0.88 and worst >= 0.8  # bounded by the bf16 forward divergence of a random-init BN net
+    # printed only (random-init amplification, see above); the asserted bounds live in test_warm_yolox_s_bf16_end_to_end
     out = model(imgs.to(hu.DEV), labels.to(hu.DEV))
     rel = abs(float(out["loss"]) - float(out_ref["loss"])) / float(out_ref["loss"])
     print("yolox_s loss hip %.5f oracle %.5f rel %.3g" % (float(out["loss"]), float(out_ref["loss"]), rel))
@@ -376,8 +376,8 @@ def test_bf16_gradients_vs_bf16_emulating_oracle_yolox_s():
         assert hu.relrms(a.cpu(), c) <= 1.5e-2
     allc, allr, worst_rms, worst_cos = _grad_report("yolox_s bf16 vs bf16-emulating oracle", grads, emu_grads)
     # measured 0.9625 / 0.942 (the fp32 oracle: 0.904 / 0.837): what remains is the random-initialised net's amplification
-    # of the few roundings that flip with the summation order; the warm-weights test below holds the same path to 1e-2
-    assert allc >= 0.95 and worst_cos >= 0.9
+    # of the few roundings that flip with the summation order -- printed only; the same comparison on the reference's warm
+    # weights is asserted at >= 0.99 in test_warm_yolox_s_bf16_gradients_vs_emulating_oracle
 
 
 def _warm_model(dtype):
@@ -450,6 +450,91 @@ def test_warm_weights_bf16_gradients_vs_emulating_oracle():
         assert r <= 5e-3
     allc, allr, worst_rms, worst_cos = _grad_report("warm weights bf16 vs bf16-emulating oracle", grads, emu_grads)
     assert allc >= 0.9995 and allr <= 2e-2 and worst_rms <= 6e-2
+
+
+def _warm_s_model(dtype):
+    g = load_golden("network_yolox_s_warm")
+    model = pl_yolo_amd.build_model(_cfg("yolox_s"), int(g["num_classes"]))
+    model.load_state_dict(warm_s_state(g))
+    model.compute_dtype = dtype
+    return g, model.to(hu.DEV).train()
+
+
+def _fixture_grad_checks(tag, model, g):
+    """Stored gradients (every tensor up to 40k elements + the 128-channel 3x3 layers) per tensor, all-parameter L2 norms."""
+    params = dict(model.named_parameters())
+    want = {k[5:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("grad/")}
+    got = {n: params[n].grad for n in want}
+    allc, allr, worst_rms, worst_cos = _grad_report(tag, got, want)
+    gmax = max(float(v) for k, v in g.items() if k.startswith("gnorm/"))
+    worst_norm = 0.0
+    for k, v in g.items():
+        if k.startswith("gnorm/") and float(v) > 1e-3 * gmax:
+            worst_norm = max(worst_norm, abs(float(params[k[6:]].grad.double().norm()) - float(v)) / float(v))
+    print("%s: worst relative error of a gradient L2 norm %.4f" % (tag, worst_norm))
+    return allc, allr, worst_rms, worst_cos, worst_norm
+
+
+def test_warm_yolox_s_fp32_vs_reference():
+    """yolox_s.yaml itself on the reference's warm weights (tools/gen_golden.py: gen_network_warm_s), parity mode: losses within
+    1e-4, the stored gradients within 2e-4 of the reference's."""
+    g, model = _warm_s_model("fp32")
+    x, labels = torch.from_numpy(g["x"]).to(hu.DEV), torch.from_numpy(g["labels"]).to(hu.DEV)
+    out = model(x, labels)
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    for k in ("loss", "loss_iou", "loss_obj", "loss_cls"):
+        got, want = float(out[k]), float(g["out/" + k])
+        assert abs(got - want) <= 1e-4 * max(1.0, abs(want)), (k, got, want)
+    params = dict(model.named_parameters())
+    gmax = max(float(np.abs(v).max()) for k, v in g.items() if k.startswith("grad/"))
+    for k, v in g.items():
+        if k.startswith("grad/"):
+            err = float((params[k[5:]].grad.cpu() - torch.from_numpy(v)).abs().max())
+            assert err <= 2e-4 * max(float(np.abs(v).max()), 1e-3 * gmax), (k, err)
+
+
+def test_warm_yolox_s_bf16_end_to_end():
+    """The benchmarked kernels (128-channel blocks, 32-channel chunks, 8-row tiles, 64x64 weight-gradient slabs, the pointwise
+    kernel with the fused BatchNorm backward) end to end in bf16 -- SimOTA included -- against the REFERENCE's fp32 step on its
+    own warm yolox_s weights: losses 2e-3, gradient cosine >= 0.999 over the stored tensors, every tensor >= 0.99."""
+    g, model = _warm_s_model("bf16")
+    x, labels = torch.from_numpy(g["x"]).to(hu.DEV), torch.from_numpy(g["labels"]).to(hu.DEV)
+    with torch.no_grad():
+        maps = model(x, None)
+    for i, m in enumerate(maps):
+        r = hu.relrms(m.float().cpu(), torch.from_numpy(g["maps_train%d" % i]))
+        print("warm yolox_s bf16 head map %d rel-rms vs reference %.4f" % (i, r))
+        assert r <= 3e-2
+    g, model = _warm_s_model("bf16")
+    out = model(x, labels)
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    for k in ("loss", "loss_iou", "loss_obj", "loss_cls"):
+        got, want = float(out[k]), float(g["out/" + k])
+        print("warm yolox_s bf16", k, got, want)
+        assert abs(got - want) <= 2e-3 * max(1.0, abs(want)), (k, got, want)
+    allc, allr, worst_rms, worst_cos, worst_norm = _fixture_grad_checks("warm yolox_s bf16 vs reference fp32", model, g)
+    assert allc >= 0.9995 and worst_cos >= 0.995 and allr <= 2e-2 and worst_norm <= 3e-2   # measured 0.99998 / 0.99969 / 0.0067 / 0.0104
+
+
+def test_warm_yolox_s_bf16_gradients_vs_emulating_oracle():
+    """labels=None path on the warm yolox_s weights, fixed upstream gradients: every HIP bf16 parameter gradient against the
+    bf16-emulating oracle (replaces the random-init comparison whose bound was 0.95 / 0.9)."""
+    g, model = _warm_s_model("bf16")
+    cfg, nc = _cfg("yolox_s"), int(g["num_classes"])
+    state = warm_s_state(g)
+    x = torch.from_numpy(g["x"])
+    gen = torch.Generator().manual_seed(11)
+    rs = [torch.randn(m.shape, generator=gen) for m in (g["maps_train0"], g["maps_train1"], g["maps_train2"])]
+    emu_maps, emu_grads = _emu_grads(cfg, nc, state, x, rs)
+    maps, grads = _maps_grads(model, x.to(hu.DEV), [r.to(hu.DEV) for r in rs])
+    for a, c in zip(maps, emu_maps):
+        r = hu.relrms(a.cpu(), c)
+        print("warm yolox_s bf16 head map vs emulating oracle rel-rms %.5f" % r)
+        assert r <= 1e-2
+    allc, allr, worst_rms, worst_cos = _grad_report("warm yolox_s bf16 vs bf16-emulating oracle", grads, emu_grads)
+    assert allc >= 0.9995 and worst_cos >= 0.995 and allr <= 2.5e-2    # measured 0.99994 / 0.99981 / 0.0107
 
 
 def test_stale_forward_and_gradient_accumulation_are_refused():

@@ -7,7 +7,7 @@ import yaml
 import os
 
 from oracle import net, detector, harness
-from conftest import load_golden, ROOT
+from conftest import load_golden, warm_s_state, ROOT
 
 
 def _cfg(name="yolox_test"):
@@ -164,3 +164,32 @@ def test_harness_trajectory():
         refe = h["ema/" + k]
         gote = ema[k].detach().numpy()
         assert float(np.abs(gote - refe).max()) <= 1e-4 * max(1.0, float(np.abs(refe).max())), k
+
+
+def test_warm_yolox_s_step_vs_reference():
+    """The benchmarked network (yolox_s.yaml, 80 classes) on the reference's warm weights (50 SGD steps, tools/gen_golden.py:
+    gen_network_warm_s), 160x160 batch 2: the oracle's losses, head maps and gradients against the reference's recorded step."""
+    g = load_golden("network_yolox_s_warm")
+    cfg, C = _cfg("yolox_s"), int(g["num_classes"])
+    state = warm_s_state(g)
+    x, labels = torch.from_numpy(g["x"]), torch.from_numpy(g["labels"])
+    with torch.no_grad():
+        maps = detector.forward({k: v.clone() for k, v in state.items()}, cfg, C, x, None, training=True)
+    for i, m in enumerate(maps):
+        ref = g["maps_train%d" % i]
+        assert float(np.abs(m.numpy() - ref).max()) <= 2e-4 * max(1.0, float(np.abs(ref).max()))
+    out, grads = detector.train_step_grads({k: v.clone() for k, v in state.items()}, cfg, C, x, labels)
+    for k in ("loss", "loss_iou", "loss_obj", "loss_cls"):
+        got, want = float(out[k].detach()), float(g["out/" + k])
+        assert abs(got - want) <= 1e-4 * max(1.0, abs(want)), (k, got, want)
+    gmax = max(float(v) for k, v in g.items() if k.startswith("gnorm/"))
+    n_full = 0
+    for k, v in g.items():
+        if k.startswith("grad/"):
+            got = grads[k[5:]].numpy()
+            assert float(np.abs(got - v).max()) <= 2e-4 * max(float(np.abs(v).max()), 1e-6 * gmax), k
+            n_full += 1
+        elif k.startswith("gnorm/"):
+            got = float(grads[k[6:]].double().norm())
+            assert abs(got - float(v)) <= 1e-3 * max(float(v), 1e-6 * gmax), k
+    assert n_full >= 200

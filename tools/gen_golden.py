@@ -58,14 +58,17 @@ def _dk_spy(fg_mask, cost, pair_wise_ious, gt_classes, num_gt):
     r = _orig_dk(fg_mask, cost, pair_wise_ious, gt_classes, num_gt)
     # boundary gap diagnostic on the reference's own cost matrix
     n_k = min(10, pair_wise_ious.size(1))
-    ks = torch.clamp(pair_wise_ious.sort(descending=True)[0][:, :n_k].sum(1).int(), min=1)
+    ksum = pair_wise_ious.sort(descending=True)[0][:, :n_k].sum(1)
+    ks = torch.clamp(ksum.int(), min=1)
+    # distance of every dynamic-k sum from the integer where int() would change k (sums below 1 clamp to k = 1: safe below 1)
+    kmargin = float(torch.where(ksum < 1.0, 1.0 - ksum, torch.minimum(ksum - ksum.floor(), ksum.floor() + 1.0 - ksum)).min()) if num_gt > 0 else float("inf")
     gap = float("inf")
     for g in range(num_gt):
         sc = cost[g].sort()[0]
         k = int(ks[g])
         if k < sc.numel() - 1:
             gap = min(gap, abs(float(sc[k]) - float(sc[k - 1])) / max(abs(float(sc[k - 1])), 1.0))
-    _calls.append(dict(fg=r[0].clone(), num_fg=int(r[1]), mg=r[2].clone(), iou=r[4].clone(), gap=gap, ks=ks.clone()))
+    _calls.append(dict(fg=r[0].clone(), num_fg=int(r[1]), mg=r[2].clone(), iou=r[4].clone(), gap=gap, ks=ks.clone(), kmargin=kmargin))
     return r
 
 
@@ -657,6 +660,102 @@ def gen_network_warm():
     save("network_yolox_warm", d)
 
 
+# gradients of the warm yolox_s fixture stored in full besides every tensor up to 40k elements: the 128 -> 128 3x3 layers the
+# benchmark spends its time in (backbone / neck / head, 20x20 and 10x10 maps at 160x160), a stride-2 layer, a wide 1x1
+_WARM_S_FULL = ("backbone.stage3.1.m.0.conv2.conv.weight", "backbone.stage2.0.conv.weight", "backbone.stage3.0.conv.weight",
+                "neck.p5_p4.m.0.conv2.conv.weight", "neck.n3_n4.m.0.conv2.conv.weight", "head.cls_convs.0.0.conv.weight",
+                "head.cls_convs.0.1.conv.weight", "head.reg_convs.0.1.conv.weight", "head.reg_convs.1.0.conv.weight",
+                "backbone.stage3.1.conv3.conv.weight")
+
+
+def gen_network_warm_s():
+    """The benchmarked network itself, warm: yolox_s.yaml (80 classes) after 50 SGD steps of the REFERENCE at 160x160, batch 2, then
+    one recorded training step.  The state is stored as bf16 bit patterns (the 50-step weights are rounded to bf16 FIRST and the
+    recorded step runs FROM the rounded state, so the stored inputs are exact); gradients: every tensor up to 40k elements and the
+    _WARM_S_FULL layers in full, the L2 norm of all of them.  Covers the tile shapes the benchmark runs (128-channel blocks, 32-channel chunks, 8-row
+    tiles, 64x64 weight-gradient slabs) with a tight end-to-end bf16 check, which the 8-channel toy net cannot."""
+    cfg = load_cfg("yolox_s")
+    C = 80
+    torch.manual_seed(96)
+    model = build_model(cfg, C)
+    model.train()
+    gen = torch.Generator().manual_seed(777)
+    S, B = 160, 2
+    data = []
+    for i in range(4):
+        x = torch.rand(B, 3, S, S, generator=gen) * 255
+        labels = rand_labels(gen, [3, 4], C, S, 8, min_wh=12.0)
+        data.append((x, labels))
+    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9)
+    losses = []
+    for step in range(50):
+        x, labels = data[step % 4]
+        out = model(x, labels)
+        opt.zero_grad()
+        out["loss"].backward()
+        opt.step()
+        losses.append(float(out["loss"]))
+    # round the warm state to bf16 and continue FROM the rounded state
+    sd = {}
+    for k, v in model.state_dict().items():
+        sd[k] = v.to(torch.bfloat16).float() if v.dtype.is_floating_point else v.clone()
+    model.load_state_dict(sd)
+    # the recorded batch: SimOTA is discrete, and the bf16 path moves the head logits by ~1e-3 -- pick a batch whose assignment
+    # is as far from a knife's edge as 300 candidate batches offer (relative cost gap at every k-th boundary, distance of every
+    # dynamic-k sum from an integer), so that
+    # the end-to-end bf16 comparison measures the kernels and not a flipped anchor
+    x = labels = None
+    best = (-1.0, None)
+    for seed in range(1000, 1300):
+        g2 = torch.Generator().manual_seed(seed)
+        xc = torch.rand(B, 3, S, S, generator=g2) * 255
+        lc = rand_labels(g2, [2, 3], C, S, 8, min_wh=12.0)
+        model.load_state_dict(sd)
+        _calls.clear()
+        with torch.no_grad():
+            model(xc, lc)
+        gap = min([c["gap"] for c in _calls] + [float("inf")])
+        km = min([c["kmargin"] for c in _calls] + [float("inf")])
+        score = min(gap / 5e-3, km / 0.05)
+        if score > best[0]:
+            best = (score, (seed, gap, km, xc, lc))
+        if score >= 2.0:
+            break
+    seed, gap, km, x, labels = best[1]
+    print("recorded batch: seed %d, boundary gap %.3g, dynamic-k margin %.3g" % (seed, gap, km))
+    assert x is not None
+    model.load_state_dict(sd)
+    d = dict(x=x, labels=labels, num_classes=C, warm_losses=np.asarray(losses))
+    for k, v in sd.items():
+        if v.dtype.is_floating_point:
+            d["state16/" + k] = v.to(torch.bfloat16).view(torch.int16).numpy().copy()
+        else:
+            d["state/" + k] = v.clone()
+    maps = model(x)
+    for i, m in enumerate(maps):
+        d["maps_train%d" % i] = m.detach().clone()
+    model.load_state_dict(sd)          # the labels=None forward above moved the running statistics
+    model.zero_grad()
+    _calls.clear()
+    out = model(x, labels)
+    out["loss"].backward()
+    for k in ("loss", "loss_iou", "loss_obj", "loss_cls"):
+        d["out/" + k] = out[k].detach()
+    d["out/proportion"] = float(out["proportion"])
+    d["boundary_gap"] = min([c["gap"] for c in _calls] + [float("inf")])
+    d["k_margin"] = min([c["kmargin"] for c in _calls] + [float("inf")])
+    full = 0
+    for n, p in model.named_parameters():
+        if p.grad is not None:
+            d["gnorm/" + n] = float(p.grad.double().norm())
+            if p.numel() <= 40000 or n in _WARM_S_FULL:
+                d["grad/" + n] = p.grad.clone()
+                full += p.numel()
+    print("warm yolox_s fixture: loss %.4f -> %.4f over 50 steps; recorded step loss=%.6f gap=%.3g; %d gradient elements in full"
+          % (losses[0], losses[-1], float(out["loss"]), d["boundary_gap"], full))
+    save("network_yolox_s_warm", d)
+
+
 def gen_cfg1():
     """BASELINE.json configs[0]: "YOLOX-nano" (yolox_s.yaml at width 0.25) 416x416 batch 4 through the
     REFERENCE on the benchmark's synthetic batch: loss scalars + a handful of gradients + weight checksums."""
@@ -784,6 +883,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "deploy":
         gen_deploy()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "warm_s":
+        gen_network_warm_s()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "warm":
         gen_network_warm()
