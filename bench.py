@@ -192,13 +192,18 @@ def load_pmc_traffic(args):
     and the entry says which build it belongs to."""
     if (args.model, args.size, args.batch) != ("yolox_s", 640, 32):
         return None
-    for tag in ("r02", "r01"):
+    for tag in ("r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", "%s_pmc_hbm_traffic.json" % tag)
         try:
             with open(path) as f:
                 pm = json.load(f)
         except OSError:
             continue
+        build = pm.get("build")
+        if not isinstance(build, dict) or build.get("lib_md5") != lib_md5():
+            # counters of ANOTHER build say nothing about the kernels this run launched: no traffic rather than stale traffic
+            return {"kernels": {}, "source": "profiles/%s_pmc_hbm_traffic.json" % tag, "build": build,
+                    "stale": "lib_md5 of the profiled build differs from the library loaded by this run; re-run tools/collect_evidence.sh"}
         kernels = {}
         for k, v in pm.items():   # rocpd family names drop the "_kernel" suffix of the __global__ functions
             if isinstance(v, dict) and "read_MB_per_launch" in v:
@@ -294,6 +299,7 @@ def main():
     if ddp_on and os.environ.get("PLYOLO_BENCH_PG_ONLY", "0") != "1":   # PG_ONLY: process group up, no data-parallel schedule (diagnostics)
         from pl_yolo_amd import ddp
         ddp.FORCE_COLLECTIVE = world == 1
+        ddp.TIME_EXPOSED = True       # event pair around the end-of-backward wait for the gradient buckets
         ddp.attach(model)
     imgs, labels = synthetic(args.batch, args.size, nc, 1234 + rank)
     imgs, labels = imgs.to(dev), labels.to(dev)
@@ -307,6 +313,9 @@ def main():
     for _ in range(args.warmup):
         out = step()
     torch.cuda.synchronize()
+    scheds = [v.sched for v in runner.sessions.values() if getattr(v, "sched", None) is not None]
+    for sc in scheds:
+        sc.exposed = []
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -318,7 +327,15 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # per rank: its own wall time per step and the communication it could not hide (time the stream that consumes the
+    # gradients sat in wait_all() behind the last collectives, hipEvents on that stream)
+    exposed_ms = sum(a.elapsed_time(b) for sc in scheds for (a, b) in sc.exposed) / max(args.steps, 1)
+    per_rank = None
     if dist is not None:
+        mine = torch.tensor([dt * 1e3 / args.steps, exposed_ms], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = {"ms_per_step": [float(v[0]) for v in allr], "exposed_comm_ms_per_step": [float(v[1]) for v in allr]}
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
@@ -403,6 +420,10 @@ def main():
             "roofline": roof,
             "lib_md5": lib_md5(),
         }
+        if per_rank is not None:
+            result["per_rank"] = per_rank          # the driver's scaling runs: which rank is slow, and how much of it is exchange
+        if pmc and pmc.get("stale"):
+            result["roofline"]["traffic_note"] = pmc["stale"]
         try:
             result["nms"] = nms_bench(dev, cpu=(world == 1 and not args.no_cpu_baseline))
         except Exception as e:  # the headline number must still print

@@ -26,6 +26,7 @@ from ._lib import call, PlyoloError
 
 FORCE_COLLECTIVE = False   # self-test: issue the collectives even in a one-rank group (bench.py PLYOLO_BENCH_FORCE_DDP)
 DEFER = os.environ.get("PLYOLO_DDP_DEFER", "1") == "1"   # 1: collectives are started from the hooks and awaited once, after the plan; 0: the hook's lane waits for each
+TIME_EXPOSED = False        # bench.py: bracket wait_all() with events -> the part of the exchange the step could not hide
 COMM_LANE = int(os.environ.get("PLYOLO_COMM_LANE", "1"))   # plan lane of the exchange (0 main, 1 weight gradients, 2.. head levels); 1 = on the weight-gradient lane itself
 
 
@@ -186,6 +187,7 @@ class BucketSchedule:
         self.post_left = list(g.post_unpack)
         self.errors = []
         self.pending = []
+        self.exposed = []       # (start, end) event pairs of wait_all(), when TIME_EXPOSED
 
     # ---- recording
     def after(self, done_idx):
@@ -256,9 +258,16 @@ class BucketSchedule:
     def wait_all(self):
         """After the backward plan has been issued: the caller's current stream waits for every started collective."""
         pend, self.pending = self.pending, []
+        timed = TIME_EXPOSED and torch.cuda.is_available() and self.runner.flat["g"].is_cuda
+        if timed:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()          # reached when the backward plan has joined the caller's stream
         for fin in pend:
             if callable(fin):
                 fin()
+        if timed:
+            ev1.record()          # reached when the last collective has finished: ev0 -> ev1 = exposed communication
+            self.exposed.append((ev0, ev1))
 
     def check(self):
         e = getattr(self.plan, "hook_error", None)

@@ -19,8 +19,14 @@ from oracle import detector as odet  # noqa: E402
 def main():
     out_path, steps = sys.argv[1], int(sys.argv[2])
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    dev = torch.device("cuda:0")
+    # default: both ranks share cuda:0 and gloo carries the exchange; PLYOLO_TWO_RANK_BACKEND=nccl: one GPU per rank, RCCL over xGMI
+    if os.environ.get("PLYOLO_TWO_RANK_BACKEND", "gloo") == "nccl":
+        dev = torch.device("cuda", rank)
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dev = torch.device("cuda:0")
     with open(os.path.join(ROOT, "configs", "model", "yolox", "yolox_test.yaml")) as f:
         cfg = yaml.safe_load(f)
     torch.manual_seed(96 + 7 * rank)          # DIFFERENT initial weights per rank: attach() must bring rank 0's everywhere

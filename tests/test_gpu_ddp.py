@@ -180,3 +180,35 @@ def test_two_processes_one_gpu_gloo(tmp_path, monkeypatch):
     for n in grads[0]:
         want = (grads[0][n] + grads[1][n]) * np.float32(0.5)
         assert np.array_equal(a["g/" + n], want), n
+
+
+def test_two_gpus_rccl_weights_and_gradients_equal_across_ranks(tmp_path):
+    """TWO ranks on TWO GPUs, RCCL (ReduceOp.AVG over xGMI) carrying the bucketed exchange of the backward plan: after attach() +
+    two steps both ranks hold rank 0's weights and the same averaged gradients.  Skipped on a one-GPU box (every gpurun box of
+    this pool exposes one GPU); the driver's multi-GPU node runs it."""
+    import subprocess
+    import sys
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (this box exposes %d)" % torch.cuda.device_count())
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", PLYOLO_BUCKET_MB="0.02", PLYOLO_TWO_RANK_BACKEND="nccl",
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ddp_two_rank_worker.py"), str(tmp_path / ("r%d.npz" % r)), "2"],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=300)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("the two-GPU run did not finish in 300 s (a rank is waiting for a collective the other never issued)")
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-2000:] for o in outs)
+    a, b = np.load(tmp_path / "r0.npz"), np.load(tmp_path / "r1.npz")
+    assert int(a["buckets"]) >= 3 and int(a["hooks"]) == int(a["buckets"]) == int(b["buckets"])
+    for k in a.files:
+        if k.startswith("w/") or k.startswith("g/"):
+            assert np.array_equal(a[k], b[k]), k

@@ -316,6 +316,25 @@ def test_bench_rccl_path_single_rank():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["value"] > 0 and np.isfinite(out["config"]["loss"])
+    # the multi-GPU report fields: per-rank step time and the exposed part of the gradient exchange
+    pr = out["per_rank"]
+    assert len(pr["ms_per_step"]) == 1 and pr["ms_per_step"][0] > 0 and 0 <= pr["exposed_comm_ms_per_step"][0] < pr["ms_per_step"][0]
+
+
+def test_bench_two_gpus_rccl():
+    """`python bench.py --gpus 2`: two real ranks, RCCL ReduceOp.AVG over xGMI, the bucket hooks of the backward plan under real
+    traffic.  SKIPPED on a one-GPU box (every gpurun box of this pool); the driver's 8-GPU node runs it on first contact."""
+    import json, subprocess, sys
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (this box exposes %d)" % torch.cuda.device_count())
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["rccl_world_size"] == 2 and out["value"] > 0 and np.isfinite(out["config"]["loss"])
+    pr = out["per_rank"]
+    assert len(pr["ms_per_step"]) == 2 and all(v > 0 for v in pr["ms_per_step"])
+    assert all(0 <= e < t for e, t in zip(pr["exposed_comm_ms_per_step"], pr["ms_per_step"]))
 
 
 # ----------------------------------------------------------------------------------------------------------------
