@@ -49,6 +49,12 @@ extern "C" {
 /* ---------------------------------------------------------------- probes */
 int plyolo_version(void);            /* ABI version */
 const char* plyolo_arch(void);       /* "gfx950" */
+/* What this build of the library carries beyond the default kernels: PLYOLO_BUILD_OPTIN = the measured-slower opt-in paths
+ * (lazy-input instances behind plyolo_conv_desc.x_coef, the weights-stationary 3x3 kernel, the tap-row split of the weight
+ * gradient; `make OPTIN=1`), PLYOLO_BUILD_DIAG = the compile-time ablation instances (`make DIAG=1`). */
+#define PLYOLO_BUILD_OPTIN 1
+#define PLYOLO_BUILD_DIAG 2
+int plyolo_build_flags(void);
 const char* plyolo_last_error(void); /* thread-local message of the last failure */
 
 /* ------------------------------------------------------------------ plans */

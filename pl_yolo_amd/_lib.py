@@ -132,6 +132,7 @@ _P = C.POINTER
 SIGNATURES = {
     "plyolo_version": (_i, []),
     "plyolo_arch": (C.c_char_p, []),
+    "plyolo_build_flags": (_i, []),
     "plyolo_last_error": (C.c_char_p, []),
     "plyolo_plan_create": (_vp, []),
     "plyolo_plan_destroy": (None, [_vp]),

@@ -88,6 +88,9 @@ static int check_conv(const plyolo_conv_desc* d, const char* who, bool fwd) {
     PLY_CHECK_ARG((double)d->N * d->H * d->W < 2147483000.0, "%s: more than 2^31 pixels", who);
   }
   if (d->x_coef != nullptr) {
+#ifndef PLYOLO_OPTIN
+    PLY_CHECK_ARG(d->dtype != PLYOLO_BF16, "%s: this libplyolo_hip.so was built without the lazy-input instances of the bf16 kernels (plyolo_conv_desc.x_coef: measured slower, opt-in) -- rebuild with `make -C pl_yolo_amd/csrc OPTIN=1`", who);
+#endif
     PLY_CHECK_ARG(d->x_coef_ld >= d->Cin && d->x_act >= 0 && d->x_act <= PLYOLO_ACT_LRELU, "%s: lazy input needs x_coef_ld >= Cin and a valid x_act", who);
     PLY_CHECK_ARG(d->dtype != PLYOLO_BF16 || is_pointwise(d) || lazy_3x3_ok(d), "%s: lazy input is not available for this bf16 convolution shape", who);
   }
@@ -118,6 +121,16 @@ using namespace plyolo;
 extern "C" {
 
 int plyolo_version(void) { return 1; }
+int plyolo_build_flags(void) {
+  int f = 0;
+#ifdef PLYOLO_OPTIN
+  f |= PLYOLO_BUILD_OPTIN;
+#endif
+#ifdef PLYOLO_DIAG_ABLATE
+  f |= PLYOLO_BUILD_DIAG;
+#endif
+  return f;
+}
 const char* plyolo_arch(void) { return "gfx950"; }
 const char* plyolo_last_error(void) { return g_err.c_str(); }
 

@@ -23,12 +23,19 @@
 #include "conv_mfma_body.h"
 
 namespace plyolo {
+#ifdef PLYOLO_OPTIN   // opt-in paths (make OPTIN=1)
 // lazy-input instances (conv_mfma_pre.hip); `convp` is a ConvP
 hipError_t conv_mfma_launch_pre(const void* convp, int BN, int CK, int TH, bool out_f32, hipStream_t s);
 // weights-stationary 3x3 stride-1 kernel (conv3ws.hip)
 int conv3ws_accepts(int N, int H, int W, int Cin, int Cout, int x_ld, int y_ld, const void* y);
 hipError_t conv3ws_launch(const void* x, const void* w, void* y, double* stats, int N, int H, int W, int Cin, int Cout, int x_ld, int y_ld,
                           int nkb, int nnb, int accumulate, unsigned long long taps_lo, unsigned taps_hi, hipStream_t s);
+#else
+static inline hipError_t conv_mfma_launch_pre(const void*, int, int, int, bool, hipStream_t) { return hipErrorNotSupported; }   // refused at the C ABI (api.hip: check_conv)
+static inline int conv3ws_accepts(int, int, int, int, int, int, int, const void*) { return 0; }
+static inline hipError_t conv3ws_launch(const void*, const void*, void*, double*, int, int, int, int, int, int, int, int, int, int, unsigned long long, unsigned,
+                                        hipStream_t) { return hipErrorNotSupported; }
+#endif
 }
 
 namespace {

@@ -554,8 +554,10 @@ int conv_pw_fwd(const plyolo_conv_desc* d, const void* x, const void* wp, const 
     annotate(lab, 2.0 * p.M * (double)d->Cout * d->Cin, (double)p.M * (d->Cout * (f32 ? 4.0 : 2.0) + d->Cin * 2.0));
   }
   return submit(stream, [=](hipStream_t s) {
-    if (f32) return pre ? pw_launch<true, true>(p, BN, KC, s) : pw_launch<true, false>(p, BN, KC, s);
-    return pre ? pw_launch<false, true>(p, BN, KC, s) : pw_launch<false, false>(p, BN, KC, s);
+#ifdef PLYOLO_OPTIN
+    if (pre) return f32 ? pw_launch<true, true>(p, BN, KC, s) : pw_launch<false, true>(p, BN, KC, s);
+#endif
+    return f32 ? pw_launch<true, false>(p, BN, KC, s) : pw_launch<false, false>(p, BN, KC, s);
   });
 }
 

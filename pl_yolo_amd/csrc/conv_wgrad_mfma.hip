@@ -529,7 +529,11 @@ template <int CO_T, int CI_T, int WK, int TH_, int SI>
 hipError_t launch_wg3(const WgP& p, int S, hipStream_t s) {
   constexpr int DZB = pitch_for(CO_T), XB = pitch_for(CI_T);
   const size_t lds = 2 * ((size_t)TH_ * TW * DZB + (size_t)((TH_ - 1) * SI + 3) * ((TW - 1) * SI + 3) * XB + 4096);
+#ifdef PLYOLO_OPTIN
   auto kern = p.pre ? conv_wgrad3_kernel<CO_T, CI_T, WK, TH_, SI, true> : conv_wgrad3_kernel<CO_T, CI_T, WK, TH_, SI, false>;
+#else
+  auto kern = conv_wgrad3_kernel<CO_T, CI_T, WK, TH_, SI, false>;   // lazy inputs are refused at the C ABI (api.hip: check_conv)
+#endif
   if (hipError_t e = plyolo::ensure_dynamic_lds((const void*)kern, 160 * 1024); e != hipSuccess) return e;
   const int nco = (p.Cout + CO_T - 1) / CO_T;
   WgP q = p;
@@ -545,7 +549,11 @@ template <int CO_T, int CI_T, int KS, int WK, int MTC, int MTI, int TH_, int SI,
 hipError_t launch_wg(const WgP& p, int S, hipStream_t s) {
   constexpr int DZB = pitch_for(CO_T), XB = pitch_for(CI_T);
   const size_t lds = (size_t)TH_ * TW * DZB + (size_t)((TH_ - 1) * SI + KS / TRS) * ((TW - 1) * SI + KS) * XB;
+#ifdef PLYOLO_OPTIN
   auto kern = p.pre ? conv_wgrad_kernel<CO_T, CI_T, KS, WK, MTC, MTI, TH_, SI, true, TRS> : conv_wgrad_kernel<CO_T, CI_T, KS, WK, MTC, MTI, TH_, SI, false, TRS>;
+#else
+  auto kern = conv_wgrad_kernel<CO_T, CI_T, KS, WK, MTC, MTI, TH_, SI, false, TRS>;
+#endif
   if (hipError_t e = plyolo::ensure_dynamic_lds((const void*)kern, 160 * 1024); e != hipSuccess) return e;
   const int nco = (p.Cout + CO_T - 1) / CO_T;
   WgP q = p;
@@ -620,7 +628,11 @@ static WgPlan plan_wgrad(const plyolo_conv_desc* d) {
   // Round 2, later: with two tiles in flight and the hand-pipelined MFMA phase the unsplit kernel is the better co-runner again
   // (a third of the L2 traffic: the three row workgroups each re-read the dY tile): its launches are longer (3.15 vs 2.95 ms per
   // step) but the step is shorter, 10.32 / 10.36 / 10.37 vs 10.49 / 10.55 / 10.52 ms on one box.  Default 1.
+#ifdef PLYOLO_OPTIN
   static const int trs_env = getenv("PLYOLO_WG_TRS") ? atoi(getenv("PLYOLO_WG_TRS")) : 1;
+#else
+  constexpr int trs_env = 1;    // the tap-row split instances are an opt-in build (make OPTIN=1)
+#endif
   w.trs = ((w.id == 0 && trs_env >= 3) || (w.id == 1 && trs_env == 13)) ? 3 : 1;
   int S = target / (nco * p.nci * w.WK * w.trs);
   if (S * w.WK > 1024) S = 1024 / w.WK;
@@ -683,9 +695,14 @@ int conv_mfma_wgrad(const plyolo_conv_desc* d, const void* x, const void* dy, fl
     }
     switch (id) {
       case 0:
-        return trs == 3 ? launch_wg<64, 64, 3, 1, 1, 1, 8, 1, 3>(p, S, s) : launch_wg<64, 64, 3, 1, 1, 1, 8, 1>(p, S, s);
+#ifdef PLYOLO_OPTIN
+        if (trs == 3) return launch_wg<64, 64, 3, 1, 1, 1, 8, 1, 3>(p, S, s);
+#endif
+        return launch_wg<64, 64, 3, 1, 1, 1, 8, 1>(p, S, s);
       case 1:
+#ifdef PLYOLO_OPTIN
         if (trs == 3) return s2 ? launch_wg<128, 32, 3, 1, 1, 1, 8, 2, 3>(p, S, s) : launch_wg<128, 32, 3, 1, 1, 1, 8, 1, 3>(p, S, s);
+#endif
         return s2 ? launch_wg<128, 32, 3, 1, 1, 1, 8, 2>(p, S, s) : launch_wg<128, 32, 3, 1, 1, 1, 8, 1>(p, S, s);
       case 2: return s2 ? launch_wg<64, 32, 3, 2, 1, 1, 8, 2>(p, S, s) : (th16 ? launch_wg<64, 32, 3, 2, 1, 1, 16, 1>(p, S, s) : launch_wg<64, 32, 3, 2, 1, 1, 8, 1>(p, S, s));
       case 3: return s2 ? launch_wg<32, 32, 3, 4, 1, 1, 8, 2>(p, S, s) : (th16 ? launch_wg<32, 32, 3, 4, 1, 1, 16, 1>(p, S, s) : launch_wg<32, 32, 3, 4, 1, 1, 8, 1>(p, S, s));

@@ -122,6 +122,9 @@ class Graph:
         # PLYOLO_LAZY=2: selective -- only where EVERY reader is a pointwise (1x1 stride-1) convolution: those kernels (and their
         # 1x1 weight gradients) are HBM-bound with an idle VALU, and there is no halo to re-pay the activation on
         self.lazy_pw_only = os.environ.get("PLYOLO_LAZY", "0") == "2"
+        if self.lazy_acts and dtype == BF16 and not (_lib.lib().plyolo_build_flags() & 1):
+            raise _lib.PlyoloError("PLYOLO_LAZY needs the lazy-input kernel instances, which the shipped libplyolo_hip.so does not carry "
+                                   "(measured slower): rebuild with `make -C pl_yolo_amd/csrc OPTIN=1`")
 
     # ------------------------------------------------------------------ batched slab folds
     def queue_reduce(self, pc):

@@ -239,6 +239,8 @@ def test_conv_fwd_fused_bn_act_inference(shape, with_res):
 def test_conv3ws_opt_in_kernel(shape, monkeypatch):
     """The weights-stationary 3x3 kernel (csrc/conv3ws.hip, PLYOLO_CONV3WS=1, off by default): forward + BatchNorm statistics
     and the data gradient (overwrite and accumulate) on every 3x3 stride-1 shape it accepts, ragged maps included."""
+    if not (hu._lib.lib().plyolo_build_flags() & 1):
+        pytest.skip("opt-in kernel: libplyolo_hip.so built without OPTIN=1")
     monkeypatch.setenv("PLYOLO_CONV3WS", "1")
     test_conv_fwd_stats(BF16, shape)
     test_conv_dgrad(BF16, shape)

@@ -611,6 +611,9 @@ def test_lazy_activations_match_materialised(dtype):
     and 3x3 forward, weight gradient) apply BatchNorm + SiLU to the producer's raw output instead.  Same arithmetic on
     the same bf16 / fp32 values: losses and every gradient equal the materialised plan's -- and in fp32 the golden
     fixture's (1e-4), so the lazy lowering is pinned to the reference too."""
+    from pl_yolo_amd import _lib
+    if dtype == "bf16" and not (_lib.lib().plyolo_build_flags() & 1):
+        pytest.skip("opt-in kernels: libplyolo_hip.so built without OPTIN=1 (the fp32 parity kernels always take lazy inputs)")
     g = load_golden("network_yolox_test")
     l0, g0, n0 = _step_with_env({"PLYOLO_LAZY": "0"}, dtype, g)
     l1, g1, n1 = _step_with_env({"PLYOLO_LAZY": "1"}, dtype, g)

@@ -17,6 +17,6 @@ for kid, ev, s, e in cur.execute(f"select kernel_id, event_id, start, end from {
     if flt and not re.search(flt, n): continue
     a = agg[n]; a[0] += 1; a[2] += e - s
     for c, v in vals.get(ev, {}).items(): a[1][c] += v
-for n, (cnt, cs, dur) in sorted(agg.items(), key=lambda kv: -kv[1][2])[:12]:
+for n, (cnt, cs, dur) in sorted(agg.items(), key=lambda kv: -kv[1][2])[:int(sys.argv[3]) if len(sys.argv) > 3 else 12]:
     print("%s  x%d  avg %.1f us" % (n, cnt, dur / cnt / 1e3))
     for c, v in sorted(cs.items()): print("     %-32s %14.0f" % (c, v / cnt))
