@@ -21,7 +21,6 @@ import os
 import sys
 import time
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "4"); os.environ.setdefault("PLYOLO_OWN_MAIN", "1")   # before the HIP runtime starts: see pl_yolo_amd/__init__.py
 
 import torch  # noqa: E402
 

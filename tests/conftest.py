@@ -1,7 +1,6 @@
 import os
 import sys
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "4"); os.environ.setdefault("PLYOLO_OWN_MAIN", "1")   # before the HIP runtime starts: see pl_yolo_amd/__init__.py
 
 import numpy as np
 import pytest
