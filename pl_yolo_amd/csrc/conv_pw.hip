@@ -584,17 +584,18 @@ int conv_pw_dgrad(const plyolo_conv_desc* d, const void* dy, const void* wpd, vo
 }
 
 // ---- data gradient with the unit's BatchNorm + activation backward in the loader (plyolo_conv2d_dgrad_bn)
-static bool bnb_enabled() {
-  static const bool on = !(getenv("PLYOLO_FUSE_BNBWD") && atoi(getenv("PLYOLO_FUSE_BNBWD")) == 0);
-  return on;
-}
-
 // 1 when plyolo_conv2d_dgrad_bn covers this unit: pointwise stride-1 bf16, a cheap activation, every channel vector whole, and
 // at most two BN blocks per pixel tile (every block re-derives dz for the whole contraction length; beyond two the separate
 // bn_act_bwd_dz pass is cheaper)
 int conv_pw_dgrad_bn_fits(const plyolo_conv_desc* d, int act) {
-  if (!bnb_enabled() || !conv_pw_enabled() || d->dtype != PLYOLO_BF16 || d->ksize != 1 || d->stride != 1) return 0;
+  if (!conv_pw_enabled() || d->dtype != PLYOLO_BF16 || d->ksize != 1 || d->stride != 1) return 0;
   if (act < PLYOLO_ACT_NONE || act > PLYOLO_ACT_LRELU || d->Cout % 8 != 0 || d->Cout > 1024) return 0;
+  // ... and the output gradient is at most PLYOLO_FUSE_BNBWD_MB (default 64) MB: measured per launch on YOLOX-s (26 MB: 18.5 us
+  // against 23 for the two launches, 52 MB: 48 against 54, 105 MB: 102 against 95) and on the whole step of YOLOX-x at 1280x1280,
+  // whose layers are all above that (fused everywhere: 104.0 ms, never: 102.1) -- the big streams are better off in the
+  // lighter, higher-occupancy pair of kernels
+  static const double max_mb = getenv("PLYOLO_FUSE_BNBWD_MB") ? atof(getenv("PLYOLO_FUSE_BNBWD_MB")) : 64.0;
+  if ((double)d->N * d->H * d->W * d->Cout * 2.0 > max_mb * 1.0e6) return 0;
   const int bn = d->Cin > 64 ? 128 : (d->Cin > 32 ? 64 : 32);
   static const int maxblk = getenv("PLYOLO_FUSE_BNBWD_BLK") ? atoi(getenv("PLYOLO_FUSE_BNBWD_BLK")) : 2;
   return (d->Cin + bn - 1) / bn <= maxblk ? 1 : 0;

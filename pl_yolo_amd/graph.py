@@ -118,6 +118,10 @@ class Graph:
         # kernels (10.5 -> 12.2 ms/step): SiLU is 2 transcendental + ~6 plain VALU instructions per element, the whole
         # chip sustains ~3.8 T SiLU/s -- the same order as the HBM stream itself -- so inside a loader the work does not
         # disappear, it lengthens every workgroup's load -> stage -> MFMA chain
+        # PLYOLO_FUSE_BNBWD=1: pointwise units form dz inside their data gradient's loader (plyolo_conv2d_dgrad_bn: one launch and
+        # one pass over dout / z less per unit, bit-identical).  Off by default: 26 launches fewer per YOLOX-s step and no
+        # measurable change of the step time (profiles/r03_ab_bn_fusion.txt), 2 % slower on YOLOX-x at 1280x1280 without its size limit
+        self.fuse_bnbwd = os.environ.get("PLYOLO_FUSE_BNBWD", "0") == "1"
         self.lazy_acts = os.environ.get("PLYOLO_LAZY", "0") in ("1", "2") and training
         # PLYOLO_LAZY=2: selective -- only where EVERY reader is a pointwise (1x1 stride-1) convolution: those kernels (and their
         # 1x1 weight gradients) are HBM-bound with an idle VALU, and there is no halo to re-pay the activation on
@@ -802,7 +806,7 @@ class ConvUnitOp:
             bslots = g.bstat_arena.data_ptr() + self.slot_off * 8
             call("plyolo_bn_act_bwd_reduce", g.dtype, M, Cout, dout, self.out.ld, zt, Cout, self.coef.data_ptr(), self.act, bslots, None, None)
             # pointwise units: dz is formed inside the data gradient's loader (one launch and one pass over dout / z less)
-            fused = self.need_dgrad and _lib.lib().plyolo_conv2d_dgrad_bn_fits(C.byref(self.desc_d), self.act) == 1
+            fused = g.fuse_bnbwd and self.need_dgrad and _lib.lib().plyolo_conv2d_dgrad_bn_fits(C.byref(self.desc_d), self.act) == 1
             if fused:
                 f = BnBwdFuse()
                 f.dout, f.dout_ld, f.z, f.z_ld, f.coef, f.bslots = dout, self.out.ld, zt, Cout, self.coef.data_ptr(), bslots
@@ -925,7 +929,7 @@ class ConvPairOp:
              bslots, C.byref(dsp), None)
         plan, lanes, me = g.plan, g.use_lanes, self.lane
         dz, key = g.dz_buffer(self, M * Cout)
-        fused = _lib.lib().plyolo_conv2d_dgrad_bn_fits(C.byref(self.desc_d), self.act) == 1
+        fused = g.fuse_bnbwd and _lib.lib().plyolo_conv2d_dgrad_bn_fits(C.byref(self.desc_d), self.act) == 1
         if fused:    # pointwise pair (CSP conv1 || conv2): dz is formed inside the data gradient's loader
             f = BnBwdFuse()
             f.dout, f.dout_ld, f.dout2, f.dout2_ld, f.dout_split = g.gptr(self.out_a), self.out_a.ld, dsp.p2, dsp.ld2, self.Ca

@@ -605,6 +605,32 @@ def _step_with_env(env, dtype, g):
                 os.environ[k] = v
 
 
+def test_fused_bn_backward_and_lane_placements_match_default():
+    """Switches that only change HOW the same arithmetic is issued must not change a bit of the result: PLYOLO_FUSE_BNBWD=1 (dz of
+    the pointwise units formed inside their data gradient's loader) and every launch-lane placement of neck / head levels (the
+    cross-lane events are derived from the tensors the ops touch: a missing one shows up as a wrong or run-to-run different gradient)."""
+    g = load_golden("network_yolox_test")
+    l0, g0, _ = _step_with_env({"PLYOLO_FUSE_BNBWD": "0"}, "bf16", g)
+    import pl_yolo_amd.heads as heads_mod, pl_yolo_amd.necks as necks_mod
+    cases = [({"PLYOLO_FUSE_BNBWD": "1"}, None, None), ({}, [0, 2, 2], 0), ({}, [0, 1, 2], 2), ({}, [2, 0, 1], 1), ({}, [0, 0, 0], 0)]
+    old = (heads_mod._HEAD_LANES, heads_mod._HEAD_LANES_FWD, necks_mod._NECK_LANE)
+    try:
+        for env, hl, nl in cases:
+            if hl is not None:
+                heads_mod._HEAD_LANES = heads_mod._HEAD_LANES_FWD = hl
+                necks_mod._NECK_LANE = nl
+            for rep in range(2):
+                l1, g1, _ = _step_with_env(env, "bf16", g)
+                assert l1 == l0, (env, hl, nl, l0, l1)
+                for n in g0:
+                    if "_preds" in n and n.endswith(".bias"):   # fp32 atomics in bias_grad: run-to-run last-bit differences (DESIGN.md section 9)
+                        assert torch.allclose(g0[n], g1[n], rtol=1e-5, atol=1e-7), (env, hl, nl, n)
+                    else:
+                        assert torch.equal(g0[n], g1[n]), (env, hl, nl, n)
+    finally:
+        heads_mod._HEAD_LANES, heads_mod._HEAD_LANES_FWD, necks_mod._NECK_LANE = old
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_lazy_activations_match_materialised(dtype):
     """PLYOLO_LAZY=1: BaseConv outputs that only feed convolutions are never written; the consumers' loaders (pointwise

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """The other BASELINE configs on one MI355X (GPU box): bench line + per-family launch times -> a markdown table.
-   python tools/other_configs.py out.md [tree]      (tree: run bench.py of another checkout, e.g. _r1, for a same-box A/B)"""
+   python tools/other_configs.py out.md [ref]      (ref: directory of the other checkout of the same-box A/B, default the newest of _r2, _r1)"""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = sys.argv[1]
+REF = sys.argv[2] if len(sys.argv) > 2 else next((d for d in ("_r2", "_r1") if os.path.isdir(os.path.join(ROOT, d))), "_r2")
 CONFIGS = [("YOLOv7 640² B=32", ["--model", "yolov7", "--batch", "32"]),
            ("YOLOX-l 640² B=16", ["--model", "yolox_l", "--batch", "16"]),
            ("YOLOX-x 1280² B=16", ["--model", "yolox_x", "--size", "1280", "--batch", "16"])]
@@ -16,17 +17,17 @@ def run(tree, args, prof=None):
     return json.loads(lines[-1]) if lines else None
 
 
-md = ["# Other BASELINE configs, round 2 (one MI355X, bf16, synthetic): same-box A/B against the round-1 tree, and the per-family",
+md = ["# Other BASELINE configs (one MI355X, bf16, synthetic): same-box A/B against the tree in %s/, and the per-family" % REF,
       "# serialised launch time of one step of the current build", ""]
 for name, args in CONFIGS:
     prof = "/tmp/prof.json"
     rows = []
     for rep in range(2):
-        a = run(os.path.join(ROOT, "_r1"), args) if os.path.isdir(os.path.join(ROOT, "_r1")) else None
+        a = run(os.path.join(ROOT, REF), args) if os.path.isdir(os.path.join(ROOT, REF)) else None
         b = run(ROOT, args, prof)
         rows.append((a, b))
     fmt = lambda d: "n/a" if d is None else "%.0f img/s, %.2f ms" % (d["value"], d["ms_per_step"])
-    md.append("## %s — round-1 tree: %s — current: %s" % (name, " / ".join(fmt(a) for a, _ in rows), " / ".join(fmt(b) for _, b in rows)))
+    md.append("## %s — %s tree: %s — current: %s" % (name, REF, " / ".join(fmt(a) for a, _ in rows), " / ".join(fmt(b) for _, b in rows)))
     md.append("")
     try:
         pr = json.load(open(prof))
