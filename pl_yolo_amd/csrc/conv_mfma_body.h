@@ -92,11 +92,18 @@ DEVINL u32x4 pre_apply(u32x4 t, const float* __restrict__ pre, int pre_ld, int a
   return t;
 }
 
-template <int BN, int CK, int TH, bool OUT_F32, int ABL, bool DB = false, bool PRE = false>
+// MF16 (PLYOLO_MFMA16=1, A/B instances): the same tile on v_mfma_f32_16x16x32_bf16 -- per wave 2*MT pixel fragments of 16 (one image
+// row of the tile each) x two 16-channel halves, ONE 32-deep k-step per tap and 32-channel chunk.  Same MFMA cycles, same LDS
+// and L2 bytes; MI355X_MICROARCH.md (DVFS item 7) measured this shape holding a higher clock under load.  B fragments come from
+// the SAME weight pack (a 16-channel half x 32-deep fragment = four 256-byte pieces of two 32x16 fragments); the pixel pitch grows
+// to CK*2+32 bytes, which makes the 16-pixel x 4-k-group ds_read_b128 conflict-free.
+template <int BN, int CK, int TH, bool OUT_F32, int ABL, bool DB = false, bool PRE = false, bool MF16 = false>
 DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
+  static_assert(!MF16 || (CK == 32 && !OUT_F32 && !PRE && DB), "MF16 instances: 32-channel double-buffered bf16 tiles");
   constexpr int BM = TH * TW;
   constexpr int WN = BN / 32, WM = 4 / WN, MT = BM / (32 * WM);
-  constexpr int ROWB = CK * 2 + 16;  // LDS row pitch in bytes (pad: 16 B)
+  constexpr int MT16 = 2 * MT, HALF16 = MT;   // MF16: 16-pixel fragments per wave / per software-pipeline half
+  constexpr int ROWB = CK * 2 + (MF16 ? 32 : 16);  // LDS row pitch in bytes (pad: 16 B; MF16: 32 B)
   constexpr int CV = CK / 8;         // 16-byte vectors per row
   constexpr int KS = CK / 16;        // k-steps per chunk
   extern __shared__ __align__(16) unsigned char smem[];
@@ -128,11 +135,22 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
     arow[mt] = ((m >> 4) * p.si) * p.rowp + ((m & 15) * p.si) * ROWB + h * 16;
   }
 
-  f32x16 acc[MT];
+  f32x16 acc[MF16 ? 1 : MT];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
+  for (int mt = 0; mt < (MF16 ? 1 : MT); ++mt)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+  // MF16: fragment j of this wave = image row (wm*MT16 + j) of the tile, pixel lane&15, k-group lane>>4
+  [[maybe_unused]] int arow16[MF16 ? MT16 : 1];
+  [[maybe_unused]] f32x4 acc16[MF16 ? MT16 : 1][2];
+  if constexpr (MF16) {
+#pragma unroll
+    for (int j = 0; j < MT16; ++j) {
+      arow16[j] = ((wm * MT16 + j) * p.si) * p.rowp + ((lane & 15) * p.si) * ROWB + (lane >> 4) * 16;
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) acc16[j][hh] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
 
   const int nchunks = (p.Cin + CK - 1) / CK;
   const int total = nchunks * p.ntaps;
@@ -154,6 +172,19 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
   int pf_chunk = 0, pf_t = 0;
   auto load_b = [&](u32x4* dst) {
     const char* wt = wbase + (size_t)((tap_code(p, pf_t) >> 4) * wtapB);
+    if constexpr (MF16) {
+      // lane (n = lane&15, kq = lane>>4) of the 16-channel half hh needs W[co = nb*32 + hh*16 + n][ci = chunk*32 + kq*8 + j]:
+      // entry [nb][kb = 2*chunk + (kq>>1)][lane' = (kq&1)*32 + hh*16 + n] of the pack
+      const int kq = lane >> 4;
+      int kbl = pf_chunk * 2 + (kq >> 1);
+      kbl = kbl < p.nkb ? kbl : p.nkb - 1;     // beyond Cin: zero-filled halo columns (see below)
+      const unsigned base = (unsigned)((nb_ok ? nb : p.nnb - 1) * p.nkb + kbl) * 1024u + (unsigned)((kq & 1) * 32 + (lane & 15)) * 16u;
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) dst[hh] = *(const u32x4*)(wt + (size_t)(base + (unsigned)hh * 256u));
+      if (pf_t + 1 < p.ntaps) ++pf_t;
+      else if (pf_chunk + 1 < nchunks) { pf_t = 0; ++pf_chunk; }
+      return;
+    }
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
       const int kb = pf_chunk * KS + kk;
@@ -266,6 +297,38 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
     const int toff = boff + (int)(tc & 3u) * p.rowp + (int)((tc >> 2) & 3u) * ROWB;
     // software pipeline over the k-steps: the A fragments of step kk+1 are requested from LDS before the MFMAs
     // of step kk are issued, so that no MFMA waits on a ds_read issued just before it
+    if constexpr (MF16) {
+      // two halves of HALF16 fragments: the second half's A fragments are requested from LDS before the first half's MFMAs
+      bf16x8 a16[HALF16], an16[HALF16];
+      const bf16x8 b0 = *(const bf16x8*)&bq[0][0], b1 = *(const bf16x8*)&bq[0][1];
+#pragma unroll
+      for (int j = 0; j < HALF16; ++j) a16[j] = *(const bf16x8*)(smem + arow16[j] + toff);
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        if (half == 0) {
+#pragma unroll
+          for (int j = 0; j < HALF16; ++j) an16[j] = *(const bf16x8*)(smem + arow16[HALF16 + j] + toff);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < HALF16; ++j) {
+          acc16[half * HALF16 + j][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a16[j], b0, acc16[half * HALF16 + j][0], 0, 0, 0);
+          acc16[half * HALF16 + j][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a16[j], b1, acc16[half * HALF16 + j][1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (half == 0) {
+#pragma unroll
+          for (int j = 0; j < HALF16; ++j) a16[j] = an16[j];
+        }
+      }
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) {
+#pragma unroll
+        for (int d = 0; d < PD; ++d) bq[d][kk] = bq[d + 1][kk];
+      }
+      ++phase;
+      return;
+    }
     constexpr bool PIPE = MT <= 4;   // the 8-fragment tile has no registers left for a second fragment set
     bf16x8 a[MT], an[PIPE ? MT : 1];
 #pragma unroll
@@ -350,6 +413,46 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
   constexpr int SROW = OUT_F32 ? (BN + 4) * 4 : (BN * 2 + 16);  // staging row pitch (bytes)
   float* red = (float*)(smem + BM * SROW);                       // [WM][2][BN]
 
+  if constexpr (MF16) {
+    // accumulator (j, hh)[i]: pixel row (wm*MT16 + j) of the tile, pixel (lane>>4)*4 + i, channel wn*32 + hh*16 + (lane&15)
+    const int n = lane & 15, kq = lane >> 4;
+    if (p.stats != nullptr) {
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < MT16; ++j)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const bool valid = (oy0 + wm * MT16 + j < p.OHt) && (ox0 + kq * 4 + i < p.OWt);
+            const float v = valid ? acc16[j][hh][i] : 0.f;
+            s1 += v;
+            s2 = fmaf(v, v, s2);
+          }
+        s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+        if (kq == 0) {
+          red[(wm * 2 + 0) * BN + wn * 32 + hh * 16 + n] = s1;
+          red[(wm * 2 + 1) * BN + wn * 32 + hh * 16 + n] = s2;
+        }
+      }
+    }
+    const bool fused16 = p.ep_coef != nullptr;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int col = wn * 32 + hh * 16 + n;
+      float sc = 1.f, sh = 0.f;
+      if (fused16 && cout0 + col < p.Cout) { sc = p.ep_coef[cout0 + col]; sh = p.ep_coef[p.Cout + cout0 + col]; }
+#pragma unroll
+      for (int j = 0; j < MT16; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int m = (wm * MT16 + j) * 16 + kq * 4 + i;
+          const float v = acc16[j][hh][i];
+          *(bf16_t*)(smem + m * SROW + col * 2) = f2bf(fused16 ? act_fwd_core(fmaf(v, sc, sh), p.ep_act) : v);
+        }
+    }
+  } else {
   if (p.stats != nullptr && !(abl & 64)) {
     float s1 = 0.f, s2 = 0.f;
     if (oy0 + TH <= p.OHt && ox0 + TW <= p.OWt) {
@@ -400,6 +503,7 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
       else
         *(bf16_t*)(smem + m * SROW + col * 2) = f2bf(fused ? act_fwd_core(fmaf(acc[mt][i], ep_sc, ep_sh), p.ep_act) : acc[mt][i]);
     }
+  }   // !MF16
   __syncthreads();
 
   if (abl & 256) {
@@ -472,9 +576,24 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
   }
 }
 
-template <int BN, int CK, int TH, bool OUT_F32, int ABL = 0, bool DB = false, bool PRE = false>
+template <int BN, int CK, int TH, bool OUT_F32, int ABL = 0, bool DB = false, bool PRE = false, bool MF16 = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvP p) {
-  conv_mfma_body<BN, CK, TH, OUT_F32, ABL, DB, PRE>(p, (int)blockIdx.x, (int)gridDim.x);
+  conv_mfma_body<BN, CK, TH, OUT_F32, ABL, DB, PRE, MF16>(p, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// MF16 instances (stride-1 tiles of 8 rows, 32-channel double-buffered chunks, bf16 output): launch with the wider pixel pitch
+template <int BN>
+hipError_t launch_inst_mf16(ConvP p, hipStream_t s) {
+  constexpr int CK = 32, TH = 8, BM = TH * TW, WN = BN / 32, WM = 4 / WN;
+  constexpr int ROWB = CK * 2 + 32, SROW = BN * 2 + 16;
+  p.rowp = (p.ITW * ROWB + 255) & ~255;
+  p.bufsz = p.ITH * p.rowp;
+  const size_t lds_main = 2 * (size_t)p.bufsz, lds_epi = (size_t)BM * SROW + WM * 2 * BN * 4;
+  const size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+  auto kern = conv_mfma_kernel<BN, CK, TH, false, 0, true, false, true>;
+  if (hipError_t e = plyolo::ensure_dynamic_lds((const void*)kern, lds); e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(p.nmb, (p.Cout + BN - 1) / BN), dim3(256), lds, s, p);
+  return hipGetLastError();
 }
 
 template <int BN, int CK, int TH, bool DB = false>
@@ -498,7 +617,24 @@ hipError_t launch_inst(ConvP p, hipStream_t s) {
   auto kern = conv_mfma_kernel<BN, CK, TH, OUT_F32, 0, false, PRE>;
   // double-buffered halo tile: stride-1 tiles with more than one Cin chunk
   constexpr bool HAS_DB = !OUT_F32 && ((TH == 8 && (CK == 32 || CK == 64)) || (TH == 16 && CK == 32));
-  if constexpr (HAS_DB) {
+  if constexpr (!OUT_F32 && !PRE && TH == 8 && CK == 32 && (BN == 128 || BN == 64)) {
+    // default since round 3 (same box, three alternations: 9.31 -> 9.245 ms/step; forward launches of this shape -3.5 %, data
+    // gradients -7.7 %; profiles/r03_ab_mfma16.txt).  PLYOLO_MFMA16=0 restores the 32x32x16 instances in an OPTIN build (the
+    // shipped library does not carry both: co-compiled instances cost the hot kernels time, see the top of this file)
+#ifdef PLYOLO_OPTIN
+    static const bool mf16 = !(getenv("PLYOLO_MFMA16") && atoi(getenv("PLYOLO_MFMA16")) == 0);
+#else
+    constexpr bool mf16 = true;
+#endif
+    if (mf16 && p.db && p.si == 1 && p.Cin > CK && !p.ablate) return launch_inst_mf16<BN>(p, s);
+  }
+#ifndef PLYOLO_OPTIN
+  // the 32x32x16 double-buffered instances of the two MF16 shapes are never launched by the shipped library: do not instantiate them
+  constexpr bool MF16_SHAPE = !OUT_F32 && !PRE && TH == 8 && CK == 32 && (BN == 128 || BN == 64);
+#else
+  constexpr bool MF16_SHAPE = false;
+#endif
+  if constexpr (HAS_DB && !MF16_SHAPE) {
     if (p.db && p.si == 1 && p.Cin > CK && !p.ablate) {
       p.bufsz = p.ITH * p.rowp;
       lds_main = 2 * (size_t)p.bufsz;
