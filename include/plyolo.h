@@ -152,6 +152,17 @@ int plyolo_conv2d_wgrad_slabs(const plyolo_conv_desc* d);
 int plyolo_conv2d_wgrad(const plyolo_conv_desc* d, const void* x, const void* dy, float* dwp, void* stream);
 /* dbias[co] = sum over pixels of dy[m][co] (head prediction convs, decoupled_head.py:43-62). */
 int plyolo_bias_grad(int dtype, const void* dy, int M, int C, int ld, float* dbias, void* stream);
+/* The same sums for up to PLYOLO_BIAS_JOBS_MAX matrices in one launch pair (the prediction convs of all head levels).  `jobs` is a
+ * HOST array (copied into the launch); every matrix must satisfy the vector-path conditions: rows 16-byte aligned, ld a multiple of
+ * the 16-byte vector length and >= C rounded up to it.  nblk is filled by the library. */
+#define PLYOLO_BIAS_JOBS_MAX 8
+typedef struct plyolo_bias_job {
+  const void* dy;
+  int M, C, ld;
+  float* db;
+  int nblk;
+} plyolo_bias_job;
+int plyolo_bias_grad_multi(int dtype, const plyolo_bias_job* jobs, int njobs, void* stream);
 
 /* Weight (re)packing, one launch for a whole table of convolutions. The table
  * lives in DEVICE memory: n entries of plyolo_pack_entry. */
@@ -173,6 +184,8 @@ typedef struct plyolo_pack_entry {
   int Cout_p8;      /* Cout_total rounded up to 8 (dgrad contraction length) */
   int co_off;       /* first packed row of this entry */
   int nslab;        /* number of wgrad slabs to sum in unpack (>= 1) */
+  int blk0, nblk;   /* flat launches (plyolo_pack_plan): this entry owns workgroups [blk0, blk0 + nblk) -- its share of the
+                       work, so that the 512-channel layers do not run on 64 workgroups while the rest of the chip idles */
 } plyolo_pack_entry;
 int plyolo_pack_weights(const plyolo_pack_entry* table_dev, int n, int dtype, int max_elems, void* stream);
 /* Element counts of the two packs (the buffers must be zero-initialised ONCE: pad positions are
@@ -194,6 +207,12 @@ int plyolo_reduce_slabs_multi(const plyolo_reduce_job* jobs_dev, int njobs, int 
 
 /* dw (OIHW) (+)= permute(sum of the nslab slabs of dwp) for the whole table. */
 int plyolo_unpack_wgrads(const plyolo_pack_entry* table_dev, int n, int max_elems, int accumulate, void* stream);
+/* Load-balanced forms of the two launches above.  plyolo_pack_plan fills blk0 / nblk of a HOST copy of the table in
+ * proportion to each entry's element count and returns the total number of workgroups; the table is then uploaded and
+ * plyolo_pack_weights_flat / plyolo_unpack_wgrads_flat launch exactly that many (results identical to the unbalanced forms). */
+int plyolo_pack_plan(plyolo_pack_entry* table_host, int n);
+int plyolo_pack_weights_flat(const plyolo_pack_entry* table_dev, int n, int dtype, int total_blocks, void* stream);
+int plyolo_unpack_wgrads_flat(const plyolo_pack_entry* table_dev, int n, int total_blocks, int accumulate, void* stream);
 
 /* ------------------------------------------------- BatchNorm + activation
  * Replaces nn.BatchNorm2d(eps=1e-3, momentum=0.03) + SiLU of BaseConv

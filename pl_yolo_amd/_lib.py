@@ -55,9 +55,13 @@ class BnBwdFuse(C.Structure):      # plyolo_bn_bwd_fuse
                 ("dz", C.c_void_p), ("dz_ld", C.c_int)]
 
 
+class BiasJob(C.Structure):        # plyolo_bias_job
+    _fields_ = [("dy", C.c_void_p), ("M", C.c_int), ("C", C.c_int), ("ld", C.c_int), ("db", C.c_void_p), ("nblk", C.c_int)]
+
+
 class PackEntry(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("w", "wp", "wpd", "dwp", "dw", "b", "bp", "dbp", "db")] + [
-        (n, C.c_int) for n in ("Cout", "Cin", "Cin_p", "ksize", "Cout_total", "Cout_p8", "co_off", "nslab")
+        (n, C.c_int) for n in ("Cout", "Cin", "Cin_p", "ksize", "Cout_total", "Cout_p8", "co_off", "nslab", "blk0", "nblk")
     ]
 
 
@@ -162,6 +166,7 @@ SIGNATURES = {
     "plyolo_conv2d_dgrad_bn": (_i, [_P(ConvDesc), _P(BnBwdFuse), _vp, _vp, _i, _vp]),
     "plyolo_conv2d_wgrad_slabs": (_i, [_P(ConvDesc)]),
     "plyolo_bias_grad": (_i, [_i, _vp, _i, _i, _i, _vp, _vp]),
+    "plyolo_bias_grad_multi": (_i, [_i, _vp, _i, _vp]),
     "plyolo_pack_weights": (_i, [_vp, _i, _i, _i, _vp]),
     "plyolo_reduce_slabs": (_i, [_vp, _i, _sz, _vp]),
     "plyolo_lnw_act_fwd": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _f, _i, _vp, _i, _vp, _vp]),
@@ -174,6 +179,9 @@ SIGNATURES = {
     "plyolo_reduce_slabs_multi": (_i, [_vp, _i, _i, _i, _d, _vp]),
     "plyolo_pack_elems": (_i, [_i, _i, _i, _i, _P(_sz), _P(_sz)]),
     "plyolo_unpack_wgrads": (_i, [_vp, _i, _i, _i, _vp]),
+    "plyolo_pack_plan": (_i, [_vp, _i]),
+    "plyolo_pack_weights_flat": (_i, [_vp, _i, _i, _i, _vp]),
+    "plyolo_unpack_wgrads_flat": (_i, [_vp, _i, _i, _i, _vp]),
     "plyolo_bn_finalize": (_i, [_P(BnStats), _i, _vp, _vp]),
     "plyolo_bn_eval_coef": (_i, [_i, _vp, _vp, _vp, _vp, _f, _vp, _vp]),
     "plyolo_dwconv3x3_fwd": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp]),

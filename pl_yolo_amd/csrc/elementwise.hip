@@ -508,9 +508,31 @@ __global__ void nchw_to_nhwc_kernel(int N, int H, int W, int C, const float* in,
 //   wp  fragment (tap, nb, kb) = 64 lanes x 8 values, lane (r = l&31, h = l>>5), j  <-  W[nb*32+r][kb*16+h*8+j][tap]
 //   wpd fragment (tap, nb, kb)                                                      <-  W[kb*16+h*8+j][nb*32+r][tap]
 // Pad positions are never written (the arenas are zero-initialised once).
+// workgroup -> (table entry, slice, slices of that entry): the legacy 2-D launch (entry = blockIdx.x, gridDim.y slices for everyone)
+// or a flat launch planned by plyolo_pack_plan (entry i owns workgroups [blk0, blk0 + nblk): slices in proportion to its size)
+DEVINL void pack_block(const plyolo_pack_entry* table, int n_flat, int* ent, int* slice, int* nslice) {
+  if (n_flat <= 0) { *ent = blockIdx.x; *slice = blockIdx.y; *nslice = gridDim.y; return; }
+  __shared__ int s_e;
+  if (threadIdx.x == 0) {
+    int lo = 0, hi = n_flat - 1;
+    const int b = (int)blockIdx.x;
+    while (lo < hi) {           // last entry with blk0 <= b
+      const int mid = (lo + hi + 1) >> 1;
+      if (table[mid].blk0 <= b) lo = mid; else hi = mid - 1;
+    }
+    s_e = lo;
+  }
+  __syncthreads();
+  *ent = s_e;
+  *slice = (int)blockIdx.x - table[s_e].blk0;
+  *nslice = table[s_e].nblk;
+}
+
 template <typename T>
-__global__ void pack_weights_kernel(const plyolo_pack_entry* table) {
-  const plyolo_pack_entry e = table[blockIdx.x];
+__global__ void pack_weights_kernel(const plyolo_pack_entry* table, int n_flat) {
+  int ent, slice, nslice;
+  pack_block(table, n_flat, &ent, &slice, &nslice);
+  const plyolo_pack_entry e = table[ent];
   const int taps = e.ksize * e.ksize;
   const int nf = taps * e.Cout * e.Cin_p;
   T* wp = (T*)e.wp;
@@ -522,7 +544,7 @@ __global__ void pack_weights_kernel(const plyolo_pack_entry* table) {
     // one 16-byte fragment chunk (8 consecutive j) per thread.  fwd chunk (co, kb, h, t): ci = kb*16 + h*8 + j
     const int nck = nkb_f * 2;
     const int nfw = e.Cout * nck * taps;
-    for (int idx = blockIdx.y * blockDim.x + threadIdx.x; idx < nfw; idx += gridDim.y * blockDim.x) {
+    for (int idx = slice * blockDim.x + threadIdx.x; idx < nfw; idx += nslice * blockDim.x) {
       const int t = idx % taps, ck = (idx / taps) % nck, co = idx / (taps * nck);
       const int kb = ck >> 1, h = ck & 1, ci0 = kb * 16 + h * 8, cot = e.co_off + co;
       const float* src = e.w + ((size_t)co * e.Cin + ci0) * taps + t;
@@ -538,7 +560,7 @@ __global__ void pack_weights_kernel(const plyolo_pack_entry* table) {
       // dgrad chunk (ci, kbd, h, t): cot = kbd*16 + h*8 + j, restricted to this entry's rows
       const int c8 = (e.Cout + 7) / 8;
       const int ndg = e.Cin_p * c8 * taps;
-      for (int idx = blockIdx.y * blockDim.x + threadIdx.x; idx < ndg; idx += gridDim.y * blockDim.x) {
+      for (int idx = slice * blockDim.x + threadIdx.x; idx < ndg; idx += nslice * blockDim.x) {
         const int t = idx % taps, ci = (idx / taps) % e.Cin_p, g8 = idx / (taps * e.Cin_p);
         const int co0 = g8 * 8, cot0 = e.co_off + co0;
         float f[8];
@@ -557,7 +579,7 @@ __global__ void pack_weights_kernel(const plyolo_pack_entry* table) {
       }
     }
   } else
-  for (int idx = blockIdx.y * blockDim.x + threadIdx.x; idx < nf; idx += gridDim.y * blockDim.x) {
+  for (int idx = slice * blockDim.x + threadIdx.x; idx < nf; idx += nslice * blockDim.x) {
     const int ci = idx % e.Cin_p;
     const int co = (idx / e.Cin_p) % e.Cout;
     const int t = idx / (e.Cin_p * e.Cout);
@@ -577,7 +599,7 @@ __global__ void pack_weights_kernel(const plyolo_pack_entry* table) {
       if (wpd) ActT<T>::st(wpd + ((size_t)t * e.Cin_p + ci) * e.Cout_p8 + cot, v);
     }
   }
-  if (e.b && blockIdx.y == 0)
+  if (e.b && slice == 0)
     for (int i = threadIdx.x; i < e.Cout; i += blockDim.x) e.bp[e.co_off + i] = e.b[i];
 }
 
@@ -629,8 +651,10 @@ __global__ void reduce_slabs_multi_kernel(const plyolo_reduce_job* jobs, int sta
   }
 }
 
-__global__ void unpack_wgrads_kernel(const plyolo_pack_entry* table, int accumulate) {
-  const plyolo_pack_entry e = table[blockIdx.x];
+__global__ void unpack_wgrads_kernel(const plyolo_pack_entry* table, int accumulate, int n_flat) {
+  int ent, slice, nslice;
+  pack_block(table, n_flat, &ent, &slice, &nslice);
+  const plyolo_pack_entry e = table[ent];
   if (!e.dw) return;
   const int taps = e.ksize * e.ksize;
   // one thread per (co, ci): the slab reads are coalesced along ci for every tap, and the thread's taps are
@@ -639,7 +663,7 @@ __global__ void unpack_wgrads_kernel(const plyolo_pack_entry* table, int accumul
   const size_t plane = (size_t)e.Cout_total * e.Cin_p;
   const size_t slab = (size_t)taps * plane;
   const int n2 = e.Cout * e.Cin;
-  for (int idx = blockIdx.y * blockDim.x + threadIdx.x; idx < n2; idx += gridDim.y * blockDim.x) {
+  for (int idx = slice * blockDim.x + threadIdx.x; idx < n2; idx += nslice * blockDim.x) {
     const int ci = idx % e.Cin, co = idx / e.Cin;
     const float* src = e.dwp + (size_t)(e.co_off + co) * e.Cin_p + ci;
     float* dst = e.dw + (size_t)idx * taps;
@@ -649,7 +673,7 @@ __global__ void unpack_wgrads_kernel(const plyolo_pack_entry* table, int accumul
       dst[t] = (accumulate ? dst[t] : 0.f) + g;
     }
   }
-  if (e.db && blockIdx.y == 0)
+  if (e.db && slice == 0)
     for (int i = threadIdx.x; i < e.Cout; i += blockDim.x) e.db[i] = (accumulate ? e.db[i] : 0.f) + e.dbp[e.co_off + i];
 }
 
@@ -709,6 +733,58 @@ __global__ __launch_bounds__(256) void bias_grad_vec_kernel(const T* __restrict_
         atomicAdd(db + c, t);
       }
     }
+  }
+}
+
+// several bias gradients in one launch (the six prediction convs of a DecoupledHead: 2 launches instead of 12)
+struct BiasJobs {
+  plyolo_bias_job j[PLYOLO_BIAS_JOBS_MAX];
+  int n;
+};
+__global__ void bias_zero_multi_kernel(const BiasJobs jobs) {
+  const plyolo_bias_job j = jobs.j[blockIdx.x];
+  for (int i = threadIdx.x; i < j.C; i += blockDim.x) j.db[i] = 0.f;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void bias_grad_vec_multi_kernel(const BiasJobs jobs) {
+  constexpr int V = Vec<T>::N;
+  const plyolo_bias_job jb = jobs.j[blockIdx.y];
+  const T* __restrict__ dy = (const T*)jb.dy;
+  const int M = jb.M, C = jb.C, ld = jb.ld;
+  float* db = jb.db;
+  const int nblk = jb.nblk;                 // workgroups of THIS job (the launch has the maximum over the jobs)
+  if ((int)blockIdx.x >= nblk) return;
+  __shared__ float red[256 * V];
+  const int cvn = (C + V - 1) / V;
+  const int cols = cvn < 256 ? cvn : 256, rg = 256 / cols;
+  const int tcol = threadIdx.x % cols, trow = threadIdx.x / cols;
+  for (int cv0 = 0; cv0 < cvn; cv0 += cols) {
+    const int cv = cv0 + tcol;
+    float s[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) s[i] = 0.f;
+    if (trow < rg && cv < cvn) {
+#pragma unroll 4
+      for (int m = blockIdx.x * rg + trow; m < M; m += nblk * rg) {
+        float f[V];
+        Vec<T>::load(dy + (size_t)m * ld + cv * V, f);
+#pragma unroll
+        for (int i = 0; i < V; ++i) s[i] += f[i];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < V; ++i) red[threadIdx.x * V + i] = s[i];
+    __syncthreads();
+    for (int j = threadIdx.x; j < cols * V; j += 256) {
+      const int col = j / V, i = j - col * V, c = (cv0 + col) * V + i;
+      if (cv0 + col < cvn && c < C) {
+        float t = 0.f;
+        for (int k = 0; k < rg; ++k) t += red[(k * cols + col) * V + i];
+        atomicAdd(db + c, t);
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -962,7 +1038,7 @@ int plyolo_pack_weights(const plyolo_pack_entry* table_dev, int n, int dtype, in
   if (gy < 1) gy = 1;
   if (gy > 64) gy = 64;
   return submit(stream, [=](hipStream_t s) -> hipError_t {
-    DISPATCH_T(dtype, hipLaunchKernelGGL(pack_weights_kernel<T>, dim3(n, gy), dim3(256), 0, s, table_dev);)
+    DISPATCH_T(dtype, hipLaunchKernelGGL(pack_weights_kernel<T>, dim3(n, gy), dim3(256), 0, s, table_dev, 0);)
     return hipGetLastError();
   });
 }
@@ -1021,7 +1097,40 @@ int plyolo_unpack_wgrads(const plyolo_pack_entry* table_dev, int n, int max_elem
   if (gy < 1) gy = 1;
   if (gy > 64) gy = 64;
   return submit(stream, [=](hipStream_t s) -> hipError_t {
-    hipLaunchKernelGGL(unpack_wgrads_kernel, dim3(n, gy), dim3(256), 0, s, table_dev, accumulate);
+    hipLaunchKernelGGL(unpack_wgrads_kernel, dim3(n, gy), dim3(256), 0, s, table_dev, accumulate, 0);
+    return hipGetLastError();
+  });
+}
+
+// Balanced launches: an entry gets one workgroup per 2048 weights (pack: 8 per thread and pass; a 512x512x3x3 layer gets 1152
+// workgroups, a 32-channel one a single one) instead of the same gridDim.y for every entry.
+int plyolo_pack_plan(plyolo_pack_entry* t, int n) {
+  PLY_CHECK_ARG(t && n > 0, "pack_plan: empty table");
+  int total = 0;
+  for (int i = 0; i < n; ++i) {
+    const long long elems = (long long)t[i].ksize * t[i].ksize * t[i].Cout * t[i].Cin_p;
+    long long nb = (elems + 2047) / 2048;
+    if (nb < 1) nb = 1;
+    if (nb > 4096) nb = 4096;
+    t[i].blk0 = total;
+    t[i].nblk = (int)nb;
+    total += (int)nb;
+  }
+  return total;
+}
+int plyolo_pack_weights_flat(const plyolo_pack_entry* table_dev, int n, int dtype, int total_blocks, void* stream) {
+  PLY_CHECK_ARG(table_dev && n > 0 && total_blocks >= n, "pack_weights_flat: run plyolo_pack_plan on the host table first");
+  plyolo::annotate("pack_weights", 0.0, 0.0);
+  return submit(stream, [=](hipStream_t s) -> hipError_t {
+    DISPATCH_T(dtype, hipLaunchKernelGGL(pack_weights_kernel<T>, dim3(total_blocks), dim3(256), 0, s, table_dev, n);)
+    return hipGetLastError();
+  });
+}
+int plyolo_unpack_wgrads_flat(const plyolo_pack_entry* table_dev, int n, int total_blocks, int accumulate, void* stream) {
+  PLY_CHECK_ARG(table_dev && n > 0 && total_blocks >= n, "unpack_wgrads_flat: run plyolo_pack_plan on the host table first");
+  plyolo::annotate("unpack_wgrads", 0.0, 0.0);
+  return submit(stream, [=](hipStream_t s) -> hipError_t {
+    hipLaunchKernelGGL(unpack_wgrads_kernel, dim3(total_blocks), dim3(256), 0, s, table_dev, accumulate, n);
     return hipGetLastError();
   });
 }
@@ -1044,6 +1153,33 @@ int plyolo_bias_grad(int dtype, const void* dy, int M, int C, int ld, float* dbi
     if (nb < 1) nb = 1;
     if (nb > 1024) nb = 1024;
     DISPATCH_T(dtype, hipLaunchKernelGGL(bias_grad_kernel<T>, dim3(nb), dim3(256), 0, s, (const T*)dy, M, C, ld, dbias);)
+    return hipGetLastError();
+  });
+}
+
+int plyolo_bias_grad_multi(int dtype, const plyolo_bias_job* jobs, int njobs, void* stream) {
+  PLY_CHECK_ARG(jobs && njobs >= 1 && njobs <= PLYOLO_BIAS_JOBS_MAX, "bias_grad_multi: 1..%d jobs", PLYOLO_BIAS_JOBS_MAX);
+  const int V = dtype == PLYOLO_BF16 ? 8 : 4;
+  BiasJobs bj{};
+  bj.n = njobs;
+  int nbmax = 1;
+  double bytes = 0.0;
+  for (int i = 0; i < njobs; ++i) {
+    plyolo_bias_job j = jobs[i];
+    const int cvn = (j.C + V - 1) / V;
+    PLY_CHECK_ARG(j.dy && j.db && j.M > 0 && j.C > 0 && j.ld % V == 0 && cvn * V <= j.ld && ((uintptr_t)j.dy & 15) == 0,
+                  "bias_grad_multi: job %d needs 16-byte aligned rows that hold C rounded up to %d channels (use plyolo_bias_grad)", i, V);
+    long nb = (long)j.M * cvn / 2048;
+    nb = nb < 1 ? 1 : (nb > 512 ? 512 : nb);     // the grid plyolo_bias_grad gives the same matrix
+    j.nblk = (int)nb;
+    nbmax = nb > nbmax ? (int)nb : nbmax;
+    bytes += (double)j.M * j.C * (dtype == PLYOLO_BF16 ? 2.0 : 4.0);
+    bj.j[i] = j;
+  }
+  plyolo::annotate("bias_grad", 0.0, bytes);
+  return submit(stream, [=](hipStream_t s) -> hipError_t {
+    hipLaunchKernelGGL(bias_zero_multi_kernel, dim3(njobs), dim3(128), 0, s, bj);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bias_grad_vec_multi_kernel<T>, dim3(nbmax, njobs), dim3(256), 0, s, bj);)
     return hipGetLastError();
   });
 }

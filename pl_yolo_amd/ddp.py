@@ -214,8 +214,8 @@ class BucketSchedule:
         todo = [i for i in self.entries_left if self.entry_op[i] >= done_idx]
         if todo:
             self.entries_left = [i for i in self.entries_left if self.entry_op[i] < done_idx]
-            t = g.pack_subtable(todo)
-            call("plyolo_unpack_wgrads", t.data_ptr(), len(todo), g.max_pack_elems, 0, None)
+            t, nblk = g.pack_subtable(todo)
+            call("plyolo_unpack_wgrads_flat", t.data_ptr(), len(todo), nblk, 0, None)
         for op in [o for o in self.post_left if o.index >= done_idx]:
             op.post_unpack()
             self.post_left.remove(op)

@@ -375,13 +375,15 @@ class Graph:
         call("plyolo_memset_async", self.bstat_arena.data_ptr(), 0, self.bstat_arena.numel() * 8, None)
 
     def pack_subtable(self, indices):
-        """Device table of a subset of the pack entries (build_pack_table must have filled the gradient pointers)."""
+        """Device table of a subset of the pack entries (build_pack_table must have filled the gradient pointers), planned for a
+        balanced launch of its own.  Returns (device table, total workgroups)."""
         arr = (PackEntry * max(len(indices), 1))()
         for j, i in enumerate(indices):
             arr[j] = self.pack_entries[i][0]
+        total = _lib.lib().plyolo_pack_plan(C.cast(arr, C.c_void_p), max(len(indices), 1))
         t = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
         self.keep.append(t)
-        return t
+        return t, total
 
     def build_pack_table(self, grad_ptr_of):
         """Device copy of the PackEntry table; `grad_ptr_of(param)` -> device address of
@@ -392,10 +394,18 @@ class Graph:
             e.dw = grad_ptr_of(w)
             e.db = grad_ptr_of(b) if b is not None else None
             arr[i] = e
+        # workgroups of the one-launch weight packing / gradient unpacking in proportion to every entry's size
+        self.pack_blocks = _lib.lib().plyolo_pack_plan(C.cast(arr, C.c_void_p), max(n, 1)) if n else 0
         raw = bytes(arr)
         host = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
         self.pack_table = host.to(self.device)
         self.n_pack = n
+
+    def pack_weights(self):
+        call("plyolo_pack_weights_flat", self.pack_table.data_ptr(), self.n_pack, self.dtype, self.pack_blocks, None)
+
+    def unpack_wgrads(self):
+        call("plyolo_unpack_wgrads_flat", self.pack_table.data_ptr(), self.n_pack, self.pack_blocks, 0, None)
 
     # ----------------------------------------------------------------- gradients
     def grad_storage(self, st):
@@ -1413,7 +1423,20 @@ class HeadPredOp:
         if g.dtype == BF16:
             self.pc_ro.set_slabs(conv_desc(g, N, H, W, Cin, 5, 1, 1, Cin, 16, 0))
             self.pc_cls.set_slabs(conv_desc(g, N, H, W, Cin, self.nc, 1, 1, Cin, head.cls_ld, 0))
+        if not hasattr(head, "pred_ops"):
+            head.pred_ops = []
+        head.pred_ops.append(self)
         g.add_op(self)
+
+    def bias_jobs(self):
+        """(dy pointer, rows, channels, pitch, packed bias gradient) of the reg+obj and of the cls prediction conv of this level."""
+        g, hd = self.g, self.head
+        row0, M = hd.lvl_row[self.level], self.cls_feat.M
+        if g.dtype == BF16:
+            return [(hd.d_regobj.data_ptr() + row0 * 16 * 2, M, 5, 16, self.pc_ro.dbp),
+                    (hd.d_cls.data_ptr() + row0 * hd.cls_ld * 2, M, self.nc, hd.cls_ld, self.pc_cls.dbp)]
+        base = hd.draw.data_ptr() + row0 * hd.nch * 4
+        return [(base, M, 5, hd.nch, self.pc_ro.dbp), (base + 5 * 4, M, self.nc, hd.nch, self.pc_cls.dbp)]
 
     def fwd(self):
         g, hd = self.g, self.head
@@ -1459,8 +1482,9 @@ class HeadPredOp:
         call("plyolo_conv2d_dgrad", C.byref(d_cl), dcl, self.pc_cls.wpd, g.gptr(self.cls_feat), acc, None)
 
         def param_grads():
-            call("plyolo_bias_grad", g.dtype, dro, M, 5, ld_ro, self.pc_ro.dbp, None)
-            call("plyolo_bias_grad", g.dtype, dcl, M, self.nc, ld_cl, self.pc_cls.dbp, None)
+            if not getattr(hd, "bias_fused", False):     # else: one launch for every level, behind the loss backward (YoloxLossOp.bwd)
+                call("plyolo_bias_grad", g.dtype, dro, M, 5, ld_ro, self.pc_ro.dbp, None)
+                call("plyolo_bias_grad", g.dtype, dcl, M, self.nc, ld_cl, self.pc_cls.dbp, None)
             call("plyolo_conv2d_wgrad", C.byref(w_ro), self.x_ro, dro, self.pc_ro.dwp, None)
             self.pc_ro.reduce_slabs()
             call("plyolo_conv2d_wgrad", C.byref(w_cl), self.x_cls, dcl, self.pc_cls.dwp, None)
@@ -1558,10 +1582,29 @@ class YoloxLossOp:
              hd.mgt.data_ptr(), hd.miou.data_ptr(), hd.losses.data_ptr(), hd.ws.data_ptr(), hd.ws_bytes, None)
 
     def bwd(self):
-        hd = self.head
+        hd, g = self.head, self.g
         call("plyolo_yolox_loss_bwd", C.byref(hd.desc), hd.raw.data_ptr(), hd.labels.data_ptr(), hd.fg.data_ptr(),
              hd.mgt.data_ptr(), hd.miou.data_ptr(), hd.losses.data_ptr(), hd.gout.data_ptr(), ptr(hd.draw),
              ptr(hd.d_regobj), ptr(hd.d_cls), hd.cls_ld, None)
+        # the bias gradients of every level's prediction convs only need the loss gradient just written: ONE launch pair for all
+        # of them (12 launches as two per conv), on the weight-gradient lane
+        ops = getattr(hd, "pred_ops", [])
+        jobs = [j for op in ops for j in op.bias_jobs()]
+        V = g.vec
+        hd.bias_fused = bool(jobs) and len(jobs) <= 8 and all(ld % V == 0 and (c + V - 1) // V * V <= ld and p % 16 == 0 for (p, m, c, ld, d) in jobs)
+        if hd.bias_fused:
+            from ._lib import BiasJob
+            arr = (BiasJob * len(jobs))()
+            for i, (p, m, c, ld, d) in enumerate(jobs):
+                arr[i].dy, arr[i].M, arr[i].C, arr[i].ld, arr[i].db = p, m, c, ld, d
+
+            def bias_grads():
+                call("plyolo_bias_grad_multi", g.dtype, C.cast(arr, C.c_void_p), len(jobs), None)
+
+            if g.use_lanes:
+                g.defer_param_grads(self.lane, bias_grads)
+            else:
+                bias_grads()
 
 
 class YoloxEvalDecodeOp:

@@ -170,7 +170,7 @@ class DetectorRunner:
         s.fwd.is_fwd = True
         with s.fwd:
             g.plan = s.fwd
-            call("plyolo_pack_weights", g.pack_table.data_ptr(), g.n_pack, g.dtype, g.max_pack_elems, None)
+            g.pack_weights()
             g.zero_fwd_stats()
             # PLYOLO_FWD_LANES=0 records the forward on one lane, which then replays as ONE hipGraph: measured 2 %
             # slower than the eager replay with the head levels side by side (a dependent launch costs ~1.8 us in a
@@ -198,7 +198,7 @@ class DetectorRunner:
                 else:
                     G.record_ops(g, s.bwd, list(reversed(g.ops)), "bwd")
                     g.join_lanes()
-                    call("plyolo_unpack_wgrads", g.pack_table.data_ptr(), g.n_pack, g.max_pack_elems, 0, None)
+                    g.unpack_wgrads()
                     for op in g.post_unpack:
                         op.post_unpack()
             if s.sched is not None:
