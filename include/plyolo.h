@@ -249,6 +249,12 @@ typedef struct plyolo_split {
   int split;
   void* p2;
   int ld2;
+  /* plyolo_bn_act_bwd_dz only: the incoming gradient dout also flows to a second consumer -- the shortcut of a Bottleneck
+   * (network_blocks.py:89-90: y = conv2(conv1(x)) + x) -- and is copied (fwd_acc == 0) or added (fwd_acc != 0) into fwd_to
+   * [M][C] (pitch fwd_ld) by the same pass that reads it; NULL: nothing.  Not combined with a channel split. */
+  void* fwd_to;
+  int fwd_ld;
+  int fwd_acc;
 } plyolo_split;
 /* Standalone reduction of the slots -> coef[0:C]=scale, [C:2C]=shift, [2C:3C]=mean, [3C:4C]=invstd
  * (+ running statistics).  Not needed when plyolo_bn_act_fwd is given `st`. */

@@ -40,7 +40,7 @@ class BnParams(C.Structure):
 
 
 class Split(C.Structure):          # plyolo_split
-    _fields_ = [("split", C.c_int), ("p2", C.c_void_p), ("ld2", C.c_int)]
+    _fields_ = [("split", C.c_int), ("p2", C.c_void_p), ("ld2", C.c_int), ("fwd_to", C.c_void_p), ("fwd_ld", C.c_int), ("fwd_acc", C.c_int)]
 
 
 class BnBwdSplit(C.Structure):     # plyolo_bn_bwd_split

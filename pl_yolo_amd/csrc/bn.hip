@@ -265,6 +265,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_dz_kernel(int M, int C, const 
     const bool second = sp.split > 0 && c >= sp.split;
     const T* db = second ? (const T*)sp.p2 + (c - sp.split) : dout + c;
     const int dl = second ? sp.ld2 : d_ld;
+    T* fwd = (T*)sp.fwd_to;
 #pragma unroll UNR
     for (int m = blockIdx.x * cm.rpb + cm.trow; m < M; m += step) {
       float d[V], zz[V];
@@ -277,6 +278,17 @@ __global__ __launch_bounds__(256) void bn_act_bwd_dz_kernel(int M, int C, const 
         d[i] = fmaf(A[i], du, fmaf(B[i], zz[i], Cc[i]));
       }
       Vec<T>::store(dz + (size_t)m * dz_ld + c, d);
+      if (fwd) {   // the shortcut's share of dout: copied / added by the pass that read it (no plyolo_copy_add launch)
+        float e[V];
+        Vec<T>::load(db + (size_t)m * dl, e);     // (an L1 hit: the vector was just loaded)
+        if (sp.fwd_acc) {
+          float o[V];
+          Vec<T>::load(fwd + (size_t)m * sp.fwd_ld + c, o);
+#pragma unroll
+          for (int i = 0; i < V; ++i) e[i] += o[i];
+        }
+        Vec<T>::store(fwd + (size_t)m * sp.fwd_ld + c, e);
+      }
     }
   }
 }
@@ -687,6 +699,7 @@ int plyolo_bn_act_bwd_dz(int dtype, int M, int C, const void* dout, int d_ld, co
   if (check_split(dsp, C, V, "bn_act_bwd_dz")) return -1;
   plyolo_split sp{};
   if (dsp) sp = *dsp;
+  PLY_CHECK_ARG(!sp.fwd_to || (sp.split == 0 && sp.fwd_ld % V == 0 && sp.fwd_ld >= C), "bn_act_bwd_dz: the forwarded gradient needs fwd_ld %% %d == 0, fwd_ld >= C and no channel split", V);
   plyolo_bn_bwd_split p2{};
   if (par2) p2 = *par2;
   const int grid = stream_grid(M, C / V);

@@ -122,6 +122,7 @@ class Graph:
         # one pass over dout / z less per unit, bit-identical).  Off by default: 26 launches fewer per YOLOX-s step and no
         # measurable change of the step time (profiles/r03_ab_bn_fusion.txt), 2 % slower on YOLOX-x at 1280x1280 without its size limit
         self.fuse_bnbwd = os.environ.get("PLYOLO_FUSE_BNBWD", "0") == "1"
+        self.fwd_res_in_dz = os.environ.get("PLYOLO_RES_IN_DZ", "1") == "1"    # A/B switch: 0 = a copy_add launch per shortcut
         self.lazy_acts = os.environ.get("PLYOLO_LAZY", "0") in ("1", "2") and training
         # PLYOLO_LAZY=2: selective -- only where EVERY reader is a pointwise (1x1 stride-1) convolution: those kernels (and their
         # 1x1 weight gradients) are HBM-bound with an idle VALU, and there is no halo to re-pay the activation on
@@ -803,12 +804,17 @@ class ConvUnitOp:
             raise NotImplementedError("training the deploy form (conv + bias, BatchNorm folded) is not supported by the HIP plan")
         M, Cout = self.out.M, self.Cout
         dout, zt = g.gptr(self.out), self.z.tensor.data_ptr()
-        if self.res is not None:
-            acc = g.grad_mode(self.res)
-            call("plyolo_copy_add", g.dtype, M, Cout, dout, self.out.ld, g.gptr(self.res), self.res.ld, acc, None)
         plan, lanes, me = g.plan, g.use_lanes, self.lane
         dz, key = g.dz_buffer(self, M * Cout)
         fused = False
+        # the shortcut's share of the gradient (network_blocks.py:89-90): forwarded by the bn_act_bwd_dz pass that reads dout anyway;
+        # units without that pass (no BatchNorm, fused pointwise path) copy it with a launch of its own
+        res_in_dz = (self.res is not None and bn is not None and g.fwd_res_in_dz
+                     and not (g.fuse_bnbwd and self.need_dgrad and _lib.lib().plyolo_conv2d_dgrad_bn_fits(C.byref(self.desc_d), self.act) == 1))
+        if self.res is not None:
+            acc_res = g.grad_mode(self.res)
+            if not res_in_dz:
+                call("plyolo_copy_add", g.dtype, M, Cout, dout, self.out.ld, g.gptr(self.res), self.res.ld, acc_res, None)
         if bn is None:
             # BaseConv(norm=None): out = act(z)  (ecmnet.py:158 Bottleneck.conv1) -> dz = dout * act'(z)
             call("plyolo_act_bwd", g.dtype, M, Cout, dout, self.out.ld, zt, Cout, self.act, dz, Cout, 0, None)
@@ -824,8 +830,12 @@ class ConvUnitOp:
                 f.act, f.dz, f.dz_ld = self.act, dz, Cout
                 self.keep_f = f
             else:
+                sp = None
+                if res_in_dz:
+                    sp = Split()
+                    sp.fwd_to, sp.fwd_ld, sp.fwd_acc = g.gptr(self.res), self.res.ld, acc_res
                 call("plyolo_bn_act_bwd_dz", g.dtype, M, Cout, dout, self.out.ld, zt, Cout, self.coef.data_ptr(), bslots, ptr(bn.weight),
-                     g.grad_ptr_of(bn.weight), g.grad_ptr_of(bn.bias), 0, self.act, dz, Cout, None, None, None)
+                     g.grad_ptr_of(bn.weight), g.grad_ptr_of(bn.bias), 0, self.act, dz, Cout, C.byref(sp) if sp is not None else None, None, None)
         def dgrad():
             if self.need_dgrad:
                 acc = g.grad_mode(self.x)

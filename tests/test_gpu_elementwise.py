@@ -91,6 +91,19 @@ def test_bn_act_fwd_bwd(dt, act):
     e1, e2, e3 = hu.relerr(hu.from_nhwc(dz, N, H, W, Cc), gz), hu.relerr(dg, gg), hu.relerr(db, gb)
     print("bn_act_bwd", act, "dz %.3g dgamma %.3g dbeta %.3g" % (e1, e2, e3))
     assert e1 <= _tol(dt, 5e-5) and e2 <= 1e-4 and e3 <= 1e-4
+    # the shortcut's share of dout forwarded by the same pass (plyolo_split.fwd_to) == a plyolo_copy_add launch, copy and accumulate
+    from pl_yolo_amd._lib import Split
+    for acc in (0, 1):
+        base = torch.randn(M, Cc + 16, device=hu.DEV).to(hu.tdtype(dt))
+        want = base.clone()
+        call("plyolo_copy_add", dt, M, Cc, dm.data_ptr(), Cc + 8, want.data_ptr(), Cc + 16, acc, hu.stream())
+        got, dz2 = base.clone(), torch.zeros_like(dz)
+        sp = Split()
+        sp.fwd_to, sp.fwd_ld, sp.fwd_acc = got.data_ptr(), Cc + 16, acc
+        call("plyolo_bn_act_bwd_dz", dt, M, Cc, dm.data_ptr(), Cc + 8, zm.data_ptr(), Cc, coef.data_ptr(), bslots.data_ptr(), gamma.data_ptr(),
+             dg.data_ptr(), db.data_ptr(), 0, hu._lib.ACT[act], dz2.data_ptr(), Cc, C.byref(sp), None, hu.stream())
+        torch.cuda.synchronize()
+        assert torch.equal(got, want) and torch.equal(dz2, dz)
 
 
 @pytest.mark.parametrize("dt", DTS, ids=IDS)
