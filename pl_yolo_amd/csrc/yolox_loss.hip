@@ -107,29 +107,33 @@ DEVINL float pair_cost(const float* delta_a, const float* dec_a, float S_a, cons
 // thread then owns one anchor: decode, candidate test, the class-independent cost term S, and -- for
 // candidates -- the pair cost / IoU against every GT of the image, written to the [G, A] matrices that
 // k_topk and k_resolve read (one definition of the cost, computed once).
-constexpr int PREP_T = 128;
+constexpr int PREP_A = 128;   // anchors per workgroup
+constexpr int PREP_T = 256;   // threads: TWO per anchor (round 3) -- the halves split the classes of the BCE term and the GTs of the
+                              // pair-cost loop, so a candidate anchor's serial chain is half as long and a CU holds twice the waves
+                              // for the same LDS (the 43 KB row tile limits a CU to three workgroups): 95 -> ~60 us at B=32
 __global__ __launch_bounds__(PREP_T) void k_prep(const plyolo_yolox_desc d, const float* raw, const float* labels, LossWs ws) {
   extern __shared__ __align__(16) float prep_smem[];
   const int nch = 5 + d.C;
-  float* rows = prep_smem;                 // [PREP_T][nch]
-  float* lab = prep_smem + PREP_T * nch;   // [M][5]
+  float* rows = prep_smem;                 // [PREP_A][nch]
+  float* lab = prep_smem + PREP_A * nch;   // [M][5]
+  float* spart = lab + d.M * 5;            // [2][PREP_A] partial class sums of the two halves
   __shared__ int sG;
   const int b = blockIdx.y, tid = threadIdx.x;
   // level and chunk of this workgroup
   int l = 0, chunk = blockIdx.x;
   for (; l < d.nlevels; ++l) {
-    const int nc = (d.lvl_h[l] * d.lvl_w[l] + PREP_T - 1) / PREP_T;
+    const int nc = (d.lvl_h[l] * d.lvl_w[l] + PREP_A - 1) / PREP_A;
     if (chunk < nc) break;
     chunk -= nc;
   }
   if (l >= d.nlevels) return;
   const int hw = d.lvl_h[l] * d.lvl_w[l];
-  const int f0 = chunk * PREP_T, n = min(PREP_T, hw - f0);
+  const int f0 = chunk * PREP_A, n = min(PREP_A, hw - f0);
   const float* src = raw + ((size_t)d.lvl_row[l] + (size_t)b * hw + f0) * nch;
   {
     // batched copy: BATCH loads in flight per thread before the first LDS store (a load -> store loop
     // serialises the round trips), 16-byte vectors when the block of rows is 16-byte aligned
-    constexpr int BATCH = 8;
+    constexpr int BATCH = 4;
     const int total = n * nch;
     if ((((size_t)src) & 15) == 0) {
       const int nv = total >> 2;
@@ -179,18 +183,18 @@ __global__ __launch_bounds__(PREP_T) void k_prep(const plyolo_yolox_desc d, cons
   __syncthreads();
   const int G = sG;
   if (blockIdx.x == 0 && tid == 0) ws.G[b] = G;
-  if (tid >= n) return;
-  const int a = d.lvl_off[l] + f0 + tid;
-  const size_t ba = (size_t)b * d.A + a;
-  float* r = rows + tid * nch;
+  const int la = tid & (PREP_A - 1), half = tid / PREP_A;   // anchor of this thread inside the tile, which half of the work
+  const bool live = la < n;
+  const int a = d.lvl_off[l] + f0 + la;
+  const size_t ba = (size_t)b * d.A + (live ? a : d.lvl_off[l] + f0);
+  float* r = rows + (live ? la : 0) * nch;
   float xs, ys, st;
-  anchor_geom(d, a, &xs, &ys, &st);
+  anchor_geom(d, live ? a : d.lvl_off[l] + f0, &xs, &ys, &st);
   float dec[4];
   dec[0] = (r[0] + xs) * st;
   dec[1] = (r[1] + ys) * st;
   dec[2] = expf(r[2]) * st;
   dec[3] = expf(r[3]) * st;
-  *(f32x4*)(ws.dec + ba * 4) = f32x4{dec[0], dec[1], dec[2], dec[3]};
   const float xc = xs * st + 0.5f * st, yc = ys * st + 0.5f * st;
   bool any_box = false, any_ctr = false;
   for (int g = 0; g < G; ++g) {
@@ -199,19 +203,29 @@ __global__ __launch_bounds__(PREP_T) void k_prep(const plyolo_yolox_desc d, cons
     any_box |= ib;
     any_ctr |= ic;
   }
-  const bool cand = any_box || any_ctr;
-  ws.cand[ba] = cand ? 1 : 0;
-  float S = 0.f;
+  const bool cand = live && (any_box || any_ctr);
+  if (live && half == 0) {
+    *(f32x4*)(ws.dec + ba * 4) = f32x4{dec[0], dec[1], dec[2], dec[3]};
+    ws.cand[ba] = cand ? 1 : 0;
+  }
+  // class-independent BCE term: this half's classes (sequential partial sums; S = first half + second half)
+  const int c_mid = (d.C + 1) / 2, c_lo = half ? c_mid : 0, c_hi = half ? d.C : c_mid;
+  float Sp = 0.f;
   if (cand) {
     const float so = sig_fast(r[4]);
-    for (int c = 0; c < d.C; ++c) {
+    for (int c = c_lo; c < c_hi; ++c) {
       const float p = __fsqrt_rn(sig_fast(r[5 + c]) * so);
       const float t0 = -fmaxf(__logf(1.0f - p), -100.0f);
       const float t1 = -fmaxf(__logf(p), -100.0f);
-      S += t0;
-      r[5 + c] = t1 - t0;   // the raw class logit of this (private) LDS row is not needed again
+      Sp += t0;
+      r[5 + c] = t1 - t0;   // the raw class logit of this anchor's LDS row is not needed again (each half owns its classes)
     }
-    for (int g = 0; g < G; ++g) {
+  }
+  spart[half * PREP_A + la] = Sp;
+  __syncthreads();
+  const float S = spart[la] + spart[PREP_A + la];
+  if (cand) {
+    for (int g = half; g < G; g += 2) {     // this half's GTs
       float iou;
       const float cost = pair_cost(r + 5, dec, S, lab + g * 5, xc, yc, st, &iou);
       const size_t o = ((size_t)b * d.M + g) * d.A + a;
@@ -219,7 +233,7 @@ __global__ __launch_bounds__(PREP_T) void k_prep(const plyolo_yolox_desc d, cons
       ws.ioum[o] = iou;
     }
   }
-  ws.S[ba] = S;
+  if (live && half == 0) ws.S[ba] = S;
 }
 
 DEVINL unsigned orderable(float c) {
@@ -735,8 +749,8 @@ int plyolo_yolox_loss_fwd(const plyolo_yolox_desc* dp, const float* raw, const f
     hipError_t e = plyolo::fill_async(ws.cnt, 0, BA * 4, s);
     if (e != hipSuccess) return e;
     int nchunk = 0;
-    for (int l = 0; l < d.nlevels; ++l) nchunk += cdiv(d.lvl_h[l] * d.lvl_w[l], PREP_T);
-    const size_t prep_lds = ((size_t)PREP_T * (5 + d.C) + (size_t)d.M * 5) * 4;
+    for (int l = 0; l < d.nlevels; ++l) nchunk += cdiv(d.lvl_h[l] * d.lvl_w[l], PREP_A);
+    const size_t prep_lds = ((size_t)PREP_A * (5 + d.C) + (size_t)d.M * 5 + 2 * PREP_A) * 4;
     if (hipError_t ea = plyolo::ensure_dynamic_lds((const void*)k_prep, prep_lds); ea != hipSuccess) return ea;
     hipLaunchKernelGGL(k_prep, dim3(nchunk, d.B), dim3(PREP_T), prep_lds, s, d, raw, labels, ws);
     hipLaunchKernelGGL(k_topk, dim3(d.M, d.B), dim3(256), 0, s, d, raw, labels, ws);
