@@ -414,7 +414,7 @@ def main():
             "config": {"workload": "%s %dx%d, batch %d per GPU, 30 GT/img, fwd + SimOTA/loss + bwd%s" % (
                 args.model, args.size, args.size, args.batch, " + RCCL grad all-reduce" if world > 1 else ""),
                 "global_batch": world * args.batch, "parallelism": "dp%d" % world,
-                "replay": "hipgraph" if args.graph else "eager multi-stream (weight-gradient + head-level lanes)",
+                "replay": "hipgraph" if args.graph else "eager multi-stream (main, weight-gradient and neck/head side lane)",
                 "loss": loss},
             "roofline": roof,
             "lib_md5": lib_md5(),
