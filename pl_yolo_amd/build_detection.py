@@ -34,7 +34,9 @@ def build_model(cfg_models, num_classes):
     neck = _plugin(cn['name'])(cn)
     head = _plugin(ch['name'])(ch, num_classes)
     loss = _plugin(cl['name'])(cl, num_classes)
-    return OneStageD(backbone, neck, head, loss)
+    # optional key of the model YAML (the reference has no such key: it always computes in fp32, train.py:40-42):
+    #   compute_dtype: bf16 | fp32      -- bf16 = the MFMA kernels (default), fp32 = the parity mode
+    return OneStageD(backbone, neck, head, loss, compute_dtype=cfg_models.get('compute_dtype'))
 
 
 class OneStageD(nn.Module):
@@ -42,13 +44,15 @@ class OneStageD(nn.Module):
     plans on one MI355X.  `compute_dtype`: "bf16" (MFMA path, default) or "fp32"
     (parity mode); env PLYOLO_DTYPE overrides the default."""
 
-    def __init__(self, backbone=None, neck=None, head=None, loss=None):
+    def __init__(self, backbone=None, neck=None, head=None, loss=None, compute_dtype=None):
         super().__init__()
         self.backbone = backbone
         self.neck = neck
         self.head = head
         self.loss = loss
-        self.compute_dtype = os.environ.get("PLYOLO_DTYPE", "bf16")
+        if compute_dtype is not None and compute_dtype not in ("bf16", "fp32"):
+            raise PlyoloError("compute_dtype must be 'bf16' or 'fp32' (got %r)" % (compute_dtype,))
+        self.compute_dtype = compute_dtype or os.environ.get("PLYOLO_DTYPE", "bf16")
         self.__dict__['_runner'] = None
         self.__dict__['_ddp'] = None
 

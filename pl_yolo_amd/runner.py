@@ -127,7 +127,6 @@ class DetectorRunner:
         s = _Session()
         s.g, s.mode, s.B, s.H, s.W, s.M = g, mode, B, H, W, M
         s.generation = 0          # bumped by every forward of this session (see _check_generation)
-        s.published_version = None
         s.stem_kind = getattr(model.backbone, "stem_kind", "focus")
         if s.stem_kind == "focus":   # CSPDarkNet: space-to-depth gather (12 real channels)
             image = g.new_act(B, H // 2, W // 2, 16 if self.dtype == BF16 else 12, "focus")
@@ -351,28 +350,29 @@ def _check_generation(ctx, s):
     if ctx.generation != s.generation:
         raise PlyoloError("backward of a stale forward: another forward with the same (batch, size, label rows, mode) ran after "
                           "the one this loss came from, and the HIP launch plan keeps ONE set of activation buffers per shape; "
-                          "run forward -> backward pairs back to back (micro-batch accumulation is not supported)")
+                          "run forward -> backward pairs back to back (gradient accumulation over such pairs is supported)")
 
 
-def _check_not_accumulating(s):
-    """`.grad` still being the flat view AND untouched since the last backward means the caller neither dropped nor
-    zeroed the gradients: autograd would ADD the new gradient, the backward plan overwrites the flat buffer."""
-    if not s.used_params or s.published_version is None:
-        return
+def _accumulating(runner, s):
+    """`.grad` still being the flat view AND untouched since the last backward means the caller neither dropped nor zeroed the
+    gradients (gradient accumulation over micro-batches, Lightning's accumulate_grad_batches): autograd would ADD the new
+    gradient, while the backward plan overwrites the flat buffer.  The published version is kept per RUNNER -- every traced
+    shape of a model shares the one flat gradient buffer (multi-scale training)."""
+    pv = runner.flat.get("published") if runner.flat else None
+    if not s.used_params or pv is None:
+        return False
     p, gv = s.used_params[0], s.grad_views[0]
     g = p.grad
-    if g is not None and g.data_ptr() == gv.data_ptr() and g._version == s.published_version:
-        raise PlyoloError("gradient accumulation across backward() calls is not supported by the HIP launch plan (it writes the "
-                          "flat gradient buffer, it does not add to it): call optimizer.zero_grad() / model.zero_grad() between steps")
+    return g is not None and g.data_ptr() == gv.data_ptr() and pv == (id(p), g._version)
 
 
-def _publish_grads(s):
+def _publish_grads(runner, s):
     """The backward plan has written every parameter gradient into the runner's flat
     buffer; expose them as `.grad` WITHOUT a copy (returning them through autograd would
     make AccumulateGrad clone all ~240 tensors every step).  Semantics match autograd
     for the reference's loop (optimizer.zero_grad() -> .grad is None, or zeroed in place, before
     backward); a pre-existing foreign .grad tensor is accumulated into, like autograd would;
-    a second backward without zero_grad is refused (_check_not_accumulating)."""
+    a second backward without zero_grad accumulates too (_Accumulate)."""
     for p, gv in zip(s.used_params, s.grad_views):
         g = p.grad
         if g is None or g.data_ptr() == gv.data_ptr():
@@ -380,7 +380,29 @@ def _publish_grads(s):
         else:
             g.add_(gv)
     if s.used_params and s.used_params[0].grad is not None:
-        s.published_version = s.used_params[0].grad._version
+        runner.flat["published"] = (id(s.used_params[0]), s.used_params[0].grad._version)
+
+
+class _Accumulate:
+    """Around a backward replay: when the caller is accumulating (see _accumulating) the gradient of the previous micro-batches
+    is set aside before the plan overwrites the flat buffer and added back behind it -- two extra passes over the 4 bytes per
+    parameter (36 MB for YOLOX-s), only on accumulating steps; `.grad` keeps pointing at the flat buffer.  In a process group
+    the plan's buckets average the NEW gradient only; the part set aside is already the cross-rank mean."""
+
+    def __init__(self, runner, s):
+        self.runner, self.prev = runner, None
+        self.acc = _accumulating(runner, s)
+
+    def __enter__(self):
+        if self.acc:
+            self.prev = self.runner.flat["g"].clone()
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if self.acc and et is None:
+            self.runner.flat["g"].add_(self.prev)
+        self.prev = None
+        return False
 
 
 class _TrainStep(torch.autograd.Function):
@@ -397,9 +419,9 @@ class _TrainStep(torch.autograd.Function):
     def backward(ctx, gout):
         runner, s = ctx.runner, ctx.session
         _check_generation(ctx, s)
-        _check_not_accumulating(s)
-        runner.backward_train(s, gout.contiguous().float())
-        _publish_grads(s)
+        with _Accumulate(runner, s):
+            runner.backward_train(s, gout.contiguous().float())
+        _publish_grads(runner, s)
         return (None, None, None) + (None,) * len(s.used_params)
 
 
@@ -416,9 +438,9 @@ class _MapsStep(torch.autograd.Function):
     def backward(ctx, *grads):
         runner, s = ctx.runner, ctx.session
         _check_generation(ctx, s)
-        _check_not_accumulating(s)
-        runner.backward_maps(s, [g.contiguous().float() for g in grads])
-        _publish_grads(s)
+        with _Accumulate(runner, s):
+            runner.backward_maps(s, [g.contiguous().float() for g in grads])
+        _publish_grads(runner, s)
         return (None, None) + (None,) * len(s.used_params)
 
 

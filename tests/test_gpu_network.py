@@ -556,9 +556,10 @@ def test_warm_yolox_s_bf16_gradients_vs_emulating_oracle():
     assert allc >= 0.9995 and worst_cos >= 0.995 and allr <= 2.5e-2    # measured 0.99994 / 0.99981 / 0.0107
 
 
-def test_stale_forward_and_gradient_accumulation_are_refused():
-    """One set of activation buffers per traced shape: a backward is only valid for the LAST forward of its session,
-    and the backward plan overwrites (does not add to) the flat gradient buffer -- both misuse patterns raise."""
+def test_stale_forward_is_refused_and_gradients_accumulate():
+    """One set of activation buffers per traced shape: a backward is only valid for the LAST forward of its session (raises
+    otherwise).  A backward without zero_grad in between ACCUMULATES like autograd does (Lightning's accumulate_grad_batches):
+    the plan overwrites the flat gradient buffer, the runner sets the previous gradient aside and adds it back."""
     from pl_yolo_amd._lib import PlyoloError
     g, model = _golden_model("fp32")
     model.train()
@@ -571,13 +572,32 @@ def test_stale_forward_and_gradient_accumulation_are_refused():
     out2["loss"].backward()
     g2 = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
     out3 = model(x, labels)
-    with pytest.raises(PlyoloError, match="accumulation"):
-        out3["loss"].backward()             # .grad still holds the previous step: autograd would add, the plan overwrites
+    out3["loss"].backward()                 # .grad still holds the previous micro-batch: the same batch again doubles it
+    torch.cuda.synchronize()
+    for n, p in model.named_parameters():   # (the fp32 parity weight gradient sums with atomics: equal up to summation order)
+        if p.grad is not None:
+            assert float((p.grad - 2.0 * g2[n]).abs().max()) <= 2e-5 * max(float(g2[n].abs().max()), 1e-6), n
+    # another traced shape shares the flat buffer: its backward accumulates as well
+    x2, l2 = x[:1].contiguous(), labels[:1].contiguous()
+    before = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    out5 = model(x2, l2)
+    out5["loss"].backward()
+    torch.cuda.synchronize()
+    _, solo = _golden_model("fp32")
+    solo.train()
+    o = solo(x2, l2)
+    o["loss"].backward()
+    torch.cuda.synchronize()
+    gs = {n: p.grad for n, p in solo.named_parameters() if p.grad is not None}
+    for n, p in model.named_parameters():
+        if p.grad is not None:
+            want = before[n] + gs[n]
+            assert float((p.grad - want).abs().max()) <= 2e-5 * max(float(want.abs().max()), 1e-6), n
     model.zero_grad(set_to_none=False)      # zeroed in place: the views stay, overwrite == add-to-zero
     out4 = model(x, labels)
     out4["loss"].backward()
     torch.cuda.synchronize()
-    for n, p in model.named_parameters():   # (the fp32 parity weight gradient sums with atomics: equal up to summation order)
+    for n, p in model.named_parameters():
         if p.grad is not None:
             assert float((p.grad - g2[n]).abs().max()) <= 1e-5 * max(float(g2[n].abs().max()), 1e-6), n
 

@@ -52,6 +52,11 @@ def test_plugin_surface_and_state_dict_layout():
     # prior-probability bias init of the head (decoupled_head.py:64-75)
     import math
     assert torch.allclose(m.head.cls_preds[0].bias, torch.full((80,), -math.log(99.0)))
+    # compute_dtype: constructor argument / optional YAML key (default bf16, PLYOLO_DTYPE overrides the default)
+    assert pl_yolo_amd.build_model(dict(_cfg("yolox_test"), compute_dtype="fp32"), 3).compute_dtype == "fp32"
+    assert pl_yolo_amd.OneStageD(compute_dtype="bf16").compute_dtype == "bf16"
+    with pytest.raises(pl_yolo_amd.PlyoloError):
+        pl_yolo_amd.OneStageD(compute_dtype="fp16")
     with pytest.raises(NameError):
         pl_yolo_amd.build_model(dict(_cfg("yolox_test"), backbone=dict(_cfg("yolox_test")["backbone"], name="nosuch")), 3)
     with pytest.raises(KeyError):
