@@ -438,6 +438,11 @@ int plyolo_maxpool_s1_bwd(int dtype, int N, int H, int W, int C, int k, const vo
  * launch: din (+)= sum_j scatter_kj(douts[j]) with ATen's first-maximum rule.  douts[j] may be NULL
  * (that pool's output received no gradient).  Requires plyolo_spp_pools_bwd_fits(dtype,H,W). */
 int plyolo_spp_pools_bwd_fits(int dtype, int H, int W);
+/* Forward of the same block in ONE launch: outs[j] = MaxPool2d(ks[j], 1, ks[j]/2)(in) for an increasing cascade of odd windows
+ * (5, 9, 13), computed as pool_5 o pool_5 o pool_5 on an (image, 16-byte channel vector) plane in LDS.  _fits: 1 if the plane fits. */
+int plyolo_spp_pools_fwd_fits(int dtype, int H, int W, int C, int nk, const int* ks);
+int plyolo_spp_pools_fwd(int dtype, int N, int H, int W, int C, int nk, const int* ks, const void* in, int i_ld, void* const* outs,
+                         const int* o_lds, void* stream);
 int plyolo_spp_pools_bwd(int dtype, int N, int H, int W, int C, int nk, const int* ks, const void* in, int i_ld,
                          const void* const* douts, const int* d_lds, void* din, int di_ld, int accumulate, void* stream);
 int plyolo_maxpool2x2_fwd(int dtype, int N, int H, int W, int C, const void* in, int i_ld, void* out, int o_ld,

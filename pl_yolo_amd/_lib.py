@@ -206,6 +206,8 @@ SIGNATURES = {
     "plyolo_maxpool_s1_fwd": (_i, [_i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
     "plyolo_maxpool_s1_bwd": (_i, [_i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp]),
     "plyolo_spp_pools_bwd_fits": (_i, [_i, _i, _i]),
+    "plyolo_spp_pools_fwd_fits": (_i, [_i, _i, _i, _i, _i, _vp]),
+    "plyolo_spp_pools_fwd": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "plyolo_spp_pools_bwd": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "plyolo_maxpool2x2_fwd": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
     "plyolo_maxpool2x2_bwd": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp]),

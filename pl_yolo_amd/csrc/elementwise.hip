@@ -197,6 +197,59 @@ template <typename T, int CG> DEVINL void spp_st(T* q, const float* f) {
   }
 }
 
+// Forward of the same block in ONE launch: the exact cascade pool_k = pool_(k - k_prev + 1)(pool_k_prev) (5 -> 9 -> 13: three 5x5
+// pools) on an (image, CG-channel) plane in LDS, every pool separable (row maximum, then column maximum); one thread = one pixel
+// with its CG channels as a 16- / 8-byte vector.  Replaces three plyolo_maxpool_s1_fwd launches (~20 us each on 20x20 maps, each
+// re-reading the previous pool's output from memory).
+template <typename T, int SPP_CG>
+__global__ __launch_bounds__(256) void spp_pools_fwd_kernel(int H, int W, int C, int nk, int w0, int w1, int w2, const T* __restrict__ in,
+                                                            int i_ld, T* o0, T* o1, T* o2, int ol0, int ol1, int ol2) {
+  extern __shared__ __align__(16) unsigned char spp_smem[];
+  const int HW = H * W, n = blockIdx.x, c0 = blockIdx.y * SPP_CG;
+  T* cur = (T*)spp_smem;                 // [HW][CG] the plane being pooled
+  T* row = cur + (size_t)HW * SPP_CG;    // [HW][CG] its row-pass maximum
+  for (int p = threadIdx.x; p < HW; p += 256) {
+    float v[SPP_CG];
+    spp_ld<T, SPP_CG>(in + ((size_t)n * HW + p) * i_ld + c0, v);
+    spp_st<T, SPP_CG>(cur + p * SPP_CG, v);
+  }
+  __syncthreads();
+  for (int j = 0; j < nk; ++j) {
+    const int rad = (j == 0 ? w0 : (j == 1 ? w1 : w2)) / 2;
+    T* out = j == 0 ? o0 : (j == 1 ? o1 : o2);
+    const int ol = j == 0 ? ol0 : (j == 1 ? ol1 : ol2);
+    for (int p = threadIdx.x; p < HW; p += 256) {
+      const int y = p / W, x = p - y * W;
+      const int xa = max(x - rad, 0), xb = min(x + rad, W - 1);
+      float best[SPP_CG];
+      spp_ld<T, SPP_CG>(cur + (y * W + xa) * SPP_CG, best);
+      for (int xi = xa + 1; xi <= xb; ++xi) {
+        float v[SPP_CG];
+        spp_ld<T, SPP_CG>(cur + (y * W + xi) * SPP_CG, v);
+#pragma unroll
+        for (int ch = 0; ch < SPP_CG; ++ch) best[ch] = fmaxf(best[ch], v[ch]);
+      }
+      spp_st<T, SPP_CG>(row + p * SPP_CG, best);
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < HW; p += 256) {
+      const int y = p / W, x = p - y * W;
+      const int ya = max(y - rad, 0), yb = min(y + rad, H - 1);
+      float best[SPP_CG];
+      spp_ld<T, SPP_CG>(row + (ya * W + x) * SPP_CG, best);
+      for (int yi = ya + 1; yi <= yb; ++yi) {
+        float v[SPP_CG];
+        spp_ld<T, SPP_CG>(row + (yi * W + x) * SPP_CG, v);
+#pragma unroll
+        for (int ch = 0; ch < SPP_CG; ++ch) best[ch] = fmaxf(best[ch], v[ch]);
+      }
+      spp_st<T, SPP_CG>(cur + p * SPP_CG, best);      // the next pool of the cascade reads it (nobody reads `cur` in this phase)
+      spp_st<T, SPP_CG>(out + ((size_t)n * HW + p) * ol + c0, best);
+    }
+    __syncthreads();
+  }
+}
+
 template <typename T, int SPP_CG>
 __global__ __launch_bounds__(256) void spp_pools_bwd_kernel(int H, int W, int C, int nk, int k0, int k1, int k2, const T* __restrict__ in,
                                                             int i_ld, const T* d0, const T* d1, const T* d2, int dl0, int dl1, int dl2,
@@ -911,6 +964,44 @@ static int spp_bwd_cg(int dtype, int H, int W) {
 }
 
 int plyolo_spp_pools_bwd_fits(int dtype, int H, int W) { return spp_bwd_cg(dtype, H, W) ? 1 : 0; }
+
+// forward cascade in one launch: two planes of [H*W][CG] elements in LDS (CG = one 16-byte vector of channels)
+int plyolo_spp_pools_fwd_fits(int dtype, int H, int W, int C, int nk, const int* ks) {
+  if (nk < 1 || nk > 3 || !ks) return 0;
+  const int cg = dtype == PLYOLO_BF16 ? 8 : 4, esz = dtype == PLYOLO_BF16 ? 2 : 4;
+  if (C % cg != 0 || (size_t)2 * H * W * cg * esz > 64 * 1024) return 0;
+  int prev = 1;
+  for (int j = 0; j < nk; ++j) {     // a cascade: odd, increasing windows
+    if (!(ks[j] & 1) || ks[j] < prev) return 0;
+    prev = ks[j];
+  }
+  return 1;
+}
+int plyolo_spp_pools_fwd(int dtype, int N, int H, int W, int C, int nk, const int* ks, const void* in, int i_ld, void* const* outs,
+                         const int* o_lds, void* stream) {
+  PLY_CHECK_ARG(in && outs && o_lds && plyolo_spp_pools_fwd_fits(dtype, H, W, C, nk, ks), "spp_pools_fwd: not a cascade of 1..3 odd windows on a plane that fits in LDS (use plyolo_maxpool_s1_fwd)");
+  const int V = dtype == PLYOLO_BF16 ? 8 : 4;
+  int w[3] = {1, 1, 1}, ol[3] = {0, 0, 0};
+  void* o[3] = {nullptr, nullptr, nullptr};
+  int prev = 1;
+  for (int j = 0; j < nk; ++j) {
+    PLY_CHECK_ARG(outs[j] && o_lds[j] % V == 0 && i_ld % V == 0, "spp_pools_fwd: pitches must be multiples of %d", V);
+    w[j] = ks[j] - prev + 1;       // pool_k(x) == pool_(k - prev + 1)(pool_prev(x)) for stride-1 max pools
+    prev = ks[j];
+    o[j] = outs[j]; ol[j] = o_lds[j];
+  }
+  const size_t lds = (size_t)2 * H * W * V * (dtype == PLYOLO_BF16 ? 2 : 4);
+  plyolo::annotate("spp_pools_fwd", 0.0, (double)N * H * W * C * (dtype == PLYOLO_BF16 ? 2.0 : 4.0) * (1.0 + nk));
+  return submit(stream, [=](hipStream_t s) -> hipError_t {
+    DISPATCH_T(dtype, {
+      auto kern = spp_pools_fwd_kernel<T, Vec<T>::N>;
+      if (hipError_t e = plyolo::ensure_dynamic_lds((const void*)kern, lds); e != hipSuccess) return e;
+      hipLaunchKernelGGL(kern, dim3(N, C / V), dim3(256), lds, s, H, W, C, nk, w[0], w[1], w[2], (const T*)in, i_ld, (T*)o[0], (T*)o[1], (T*)o[2],
+                         ol[0], ol[1], ol[2]);
+    })
+    return hipGetLastError();
+  });
+}
 
 int plyolo_spp_pools_bwd(int dtype, int N, int H, int W, int C, int nk, const int* ks, const void* in, int i_ld,
                          const void* const* douts, const int* d_lds, void* din, int di_ld, int accumulate, void* stream) {

@@ -1221,6 +1221,13 @@ class SppPoolsOp:
 
     def fwd(self):
         g, x = self.g, self.x
+        nk = len(self.ks)
+        ks = (C.c_int * nk)(*self.ks)
+        if nk <= 3 and _lib.lib().plyolo_spp_pools_fwd_fits(g.dtype, x.H, x.W, x.C, nk, ks) == 1:
+            outs = (C.c_void_p * nk)(*[g.aptr(o) for o in self.outs])
+            olds = (C.c_int * nk)(*[o.ld for o in self.outs])
+            call("plyolo_spp_pools_fwd", g.dtype, x.N, x.H, x.W, x.C, nk, ks, g.aptr(x), x.ld, outs, olds, None)
+            return
         src, prev_k = x, 1
         for k, o in zip(self.ks, self.outs):
             # pool_k(x) == pool_{k-prev+1}(pool_prev(x)) for stride-1 max pools

@@ -202,6 +202,18 @@ def test_copy_upsample_pool(dt):
     call("plyolo_maxpool_s1_fwd", dt, N, H, W, Cc, 5, xm.data_ptr(), Cc + 8, p5.data_ptr(), Cc, hu.stream())
     call("plyolo_maxpool_s1_fwd", dt, N, H, W, Cc, 5, p5.data_ptr(), Cc, p9.data_ptr(), Cc, hu.stream())
     assert torch.equal(hu.from_nhwc(p9, N, H, W, Cc), F.max_pool2d(x, 9, 1, 4))
+    # ... and the three pools of the SPP forward in ONE launch (plyolo_spp_pools_fwd): bit-identical to F.max_pool2d, pad columns untouched
+    ks3 = (C.c_int * 3)(5, 9, 13)
+    if hu._lib.lib().plyolo_spp_pools_fwd_fits(dt, H, W, Cc, 3, ks3) == 1:
+        outs = [torch.full((N * H * W, Cc + 16), 3.0, dtype=hu.tdtype(dt), device=hu.DEV) for _ in range(3)]
+        call("plyolo_spp_pools_fwd", dt, N, H, W, Cc, 3, ks3, xm.data_ptr(), Cc + 8, (C.c_void_p * 3)(*[t.data_ptr() for t in outs]),
+             (C.c_int * 3)(Cc + 16, Cc + 16, Cc + 16), hu.stream())
+        torch.cuda.synchronize()
+        for k, o in zip((5, 9, 13), outs):
+            assert torch.equal(hu.from_nhwc(o, N, H, W, Cc), F.max_pool2d(x, k, 1, k // 2)), k
+            assert torch.all(o[:, Cc:].float() == 3.0)
+    else:
+        assert Cc % (8 if dt == BF16 else 4) != 0
     # f32 -> act conversion with accumulate, layout converters
     f = torch.randn(N * H * W, Cc, device=hu.DEV)
     tgt = hu.to_nhwc(x, dt, Cc + 8)
