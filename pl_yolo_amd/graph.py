@@ -105,7 +105,7 @@ class Graph:
         # weight gradients on their own lane (PLYOLO_LANES=0 keeps every launch on lane 0)
         self.use_lanes = os.environ.get("PLYOLO_LANES", "1") != "0"
         self.reduce_slabs = os.environ.get("PLYOLO_REDUCE_SLABS", "1") == "1"
-        self.reduce_batch = int(os.environ.get("PLYOLO_REDUCE_BATCH", "2"))   # layers per batched slab-fold launch (1 = one launch per layer)
+        self.reduce_batch = int(os.environ.get("PLYOLO_REDUCE_BATCH", "4"))   # layers per batched slab-fold launch (1 = one launch per layer; round 3, four alternations: 2 -> 9.055, 3 -> 9.03, 4 -> 9.02 ms)
         self.reduce_queue = []
         # merge same-input conv pairs (ConvPairOp) in training plans; inference plans fuse BatchNorm + activation
         # into each convolution's epilogue instead (ConvUnitOp.fwd), which needs one output matrix per conv
