@@ -34,6 +34,8 @@ d["build"] = {"tag": tag, "lib_md5": hashlib.md5(open("pl_yolo_amd/libplyolo_hip
 json.dump(d, open(p, "w"), indent=1)
 PY
 rm -rf "$O/${tag}_trace" "$O/${tag}_pmc_fetch" "$O/${tag}_pmc_write" "$O/${tag}_pmc_mfma"
+# the bench line below reads its `roofline.traffic` from profiles/ and refuses a summary of another build: hand it this one
+cp "$O/${tag}_pmc.json" "$R/profiles/${tag}_pmc_hbm_traffic.json"
 python bench.py --profile-out "$O/${tag}_plan_profile.json" > "$O/${tag}_bench.json" 2> "$O/${tag}_bench.err"
 tail -1 "$O/${tag}_bench.json" | cut -c1-400
 python tools/lane_times.py 2>/dev/null | tail -2 | tee "$O/${tag}_lane_times.txt"
