@@ -480,6 +480,7 @@ typedef struct plyolo_yolox_desc {
   int lvl_h[8], lvl_w[8], lvl_stride[8];
   int lvl_off[8];       /* first anchor of the level in the per-image anchor order */
   int lvl_row[8];       /* first row of the level's dense [B, h*w, 5+C] block (level-major raw) */
+  int use_l1;           /* YOLOXLoss(use_l1=True), yolox_loss.py:128-135,157-158: + L1 of the raw box outputs against get_l1_type */
 } plyolo_yolox_desc;
 size_t plyolo_yolox_workspace(const plyolo_yolox_desc* d);
 /* raw: fp32 head output (tx,ty,tw,th,obj,cls..), LEVEL-major: level l is the dense NHWC
@@ -488,11 +489,11 @@ size_t plyolo_yolox_workspace(const plyolo_yolox_desc* d);
  * labels [B,M,5] fp32 rows (cls,cx,cy,w,h), zero padded.
  * Outputs (batch-major, anchor order of the reference): fg u8[B,A]; matched_gt i32[B,A]
  * (-1 bg); matched_iou f32[B,A];
- * losses f32[8] = {loss, loss_iou, loss_obj, loss_cls, num_fg, num_gt, proportion, 0}. */
+ * losses f32[8] = {loss, loss_iou, loss_obj, loss_cls, num_fg, num_gt, proportion, loss_l1 (0 without use_l1)}. */
 int plyolo_yolox_loss_fwd(const plyolo_yolox_desc* d, const float* raw, const float* labels, uint8_t* fg,
                           int32_t* matched_gt, float* matched_iou, float* losses, void* workspace,
                           size_t ws_bytes, void* stream);
-/* d(sum_i gout[i]*losses[i])/d(raw), gout fp32[4] on the device or NULL (= d loss).
+/* d(sum_i gout[i]*losses[i])/d(raw), gout fp32[8] on the device (entries 0..3 and 7 are read) or NULL (= d loss).
  * Level-major rows like raw.  Exactly one of the two forms is written:
  *   draw_f32 [rows,5+C]                                  (parity mode), or
  *   d_regobj bf16 [rows,16] (5 used) + d_cls bf16 [rows,cls_ld]   (MFMA mode). */

@@ -8,7 +8,7 @@ import torch
 from . import net, yolox_loss
 
 
-def forward(state, cfg, num_classes, x, labels=None, training=True, return_assign=False):
+def forward(state, cfg, num_classes, x, labels=None, training=True, return_assign=False, use_l1=False):
     if cfg["backbone"]["name"] not in ("cspdarknet", "ecmnet") or cfg["head"]["name"] != "decoupled_head":
         raise NameError("oracle.detector covers the cspdarknet/csppafpn and ecmnet/al_pafpn + decoupled_head/yolox paths")
     if cfg["backbone"]["name"] == "ecmnet":
@@ -21,16 +21,16 @@ def forward(state, cfg, num_classes, x, labels=None, training=True, return_assig
     strides = cfg["loss"]["stride"]
     if not training:
         return yolox_loss.eval_decode(maps, strides, num_classes)
-    return yolox_loss.yolox_loss(maps, labels, strides, num_classes, return_assign=return_assign)
+    return yolox_loss.yolox_loss(maps, labels, strides, num_classes, return_assign=return_assign, use_l1=use_l1)
 
 
-def train_step_grads(state, cfg, num_classes, x, labels):
+def train_step_grads(state, cfg, num_classes, x, labels, use_l1=False):
     """fwd + loss + bwd; returns (loss dict, {param name: grad})."""
     names = net.param_names(state)
     for k in names:
         state[k].requires_grad_(True)
         state[k].grad = None
-    out = forward(state, cfg, num_classes, x, labels, training=True, return_assign=True)
+    out = forward(state, cfg, num_classes, x, labels, training=True, return_assign=True, use_l1=use_l1)
     out["loss"].backward()
     grads = {k: state[k].grad for k in names if state[k].grad is not None}
     return out, grads

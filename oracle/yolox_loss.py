@@ -163,13 +163,20 @@ def giou_loss_quirk(pred, target):
     return 1 - giou.clamp(min=-1.0, max=1.0)
 
 
-def yolox_loss(head_maps, labels, strides, num_classes, return_assign=False):
+def l1_targets(gt, stride, x_shifts, y_shifts, eps=1e-8):
+    """get_l1_type (yolox_loss.py:373-378): the matched GT boxes [n,4] (cx,cy,w,h in pixels) expressed in the raw output
+    space of their anchors (grid offsets, log of the size in stride units)."""
+    return torch.stack([gt[:, 0] / stride - x_shifts, gt[:, 1] / stride - y_shifts,
+                        torch.log(gt[:, 2] / stride + eps), torch.log(gt[:, 3] / stride + eps)], 1)
+
+
+def yolox_loss(head_maps, labels, strides, num_classes, return_assign=False, use_l1=False):
     """Training branch of YOLOXLoss.__call__ (yolox_loss.py:38-173).
 
     labels [B,M,5] rows (cls,cx,cy,w,h), zero padded.  Returns the loss dict
-    (same keys as the reference; `loss_l1` is the python float 0.0 because
-    use_l1 is never enabled, build_detection.py:137-139)."""
-    preds, _, xs, ys, ss = decode(head_maps, strides, num_classes)
+    (same keys as the reference; `loss_l1` is the python float 0.0 unless use_l1 -- a constructor argument of the
+    reference class that its plugin factory never sets, build_detection.py:137-139)."""
+    preds, raws, xs, ys, ss = decode(head_maps, strides, num_classes)
     B, A, _ = preds.shape
     nlabel = (labels.sum(dim=2) > 0).sum(dim=1)
     fg_all, mg_all, mi_all = [], [], []
@@ -202,13 +209,17 @@ def yolox_loss(head_maps, labels, strides, num_classes, return_assign=False):
     loss_iou = giou_loss_quirk(preds[bidx, aidx, :4], reg_t).sum() / n
     loss_obj = F.binary_cross_entropy_with_logits(preds[..., 4], obj_t, reduction="none").sum() / n
     loss_cls = F.binary_cross_entropy_with_logits(preds[bidx, aidx, 5:], cls_t, reduction="none").sum() / n
-    loss = 5.0 * loss_iou + loss_obj + loss_cls + 0.0
+    # yolox_loss.py:128-135,157-160: L1 of the RAW box outputs of the foreground anchors against get_l1_type
+    loss_l1 = 0.0
+    if use_l1:
+        loss_l1 = F.l1_loss(raws[bidx, aidx], l1_targets(reg_t, ss[0][aidx], xs[0][aidx], ys[0][aidx]), reduction="none").sum() / n
+    loss = 5.0 * loss_iou + loss_obj + loss_cls + loss_l1
     out = {
         "loss": loss,
         "loss_iou": loss_iou,
         "loss_obj": loss_obj,
         "loss_cls": loss_cls,
-        "loss_l1": 0.0,
+        "loss_l1": loss_l1,
         "proportion": n / max(num_gts, 1),
     }
     if return_assign:

@@ -69,7 +69,7 @@ class YoloxDesc(C.Structure):
     _fields_ = [
         ("B", C.c_int), ("A", C.c_int), ("C", C.c_int), ("M", C.c_int), ("nlevels", C.c_int),
         ("lvl_h", C.c_int * 8), ("lvl_w", C.c_int * 8), ("lvl_stride", C.c_int * 8),
-        ("lvl_off", C.c_int * 8), ("lvl_row", C.c_int * 8),
+        ("lvl_off", C.c_int * 8), ("lvl_row", C.c_int * 8), ("use_l1", C.c_int),
     ]
 
 

@@ -99,7 +99,7 @@ class OneStageD(nn.Module):
             "loss_iou": out[1],
             "loss_obj": out[2],
             "loss_cls": out[3],
-            "loss_l1": 0.0,
+            "loss_l1": out[7] if self.loss.use_l1 else 0.0,   # the python float 0.0 without use_l1, as the reference (yolox_loss.py:159-160)
             "proportion": out[6].detach(),
         }
 

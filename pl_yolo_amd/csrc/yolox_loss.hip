@@ -32,12 +32,13 @@ struct LossWs {
   int* cnt;        // [B,A]
   int* lastg;      // [B,A]
   int* G;          // [B]
-  float* partial;  // [nblk,4]
+  float* partial;  // [nblk,NPART]
   float* costm;    // [B,M,A] pair cost of (GT g, anchor a), written for candidate anchors only
   float* ioum;     // [B,M,A] pair IoU
 };
 
 constexpr int MAXM = 256;  // label rows per image supported by the LDS staging
+constexpr int NPART = 5;   // block partials of k_loss: iou, obj, cls, num_fg, l1
 
 DEVINL float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 // Hardware-rate versions for the SimOTA cost only (v_exp / v_log / v_rcp / v_sqrt: ~1-2 ulp).  The cost
@@ -455,21 +456,35 @@ DEVINL float bce_logits(float x, float t) {
   return (1.0f - t) * x - (fminf(x, 0.0f) - log1pf(expf(-fabsf(x))));
 }
 
+// get_l1_type (yolox_loss.py:373-378): the regression target in the RAW output space of the matched anchor
+DEVINL void l1_target(const float* gt_box, float xs, float ys, float st, float* t) {
+  t[0] = gt_box[0] / st - xs;
+  t[1] = gt_box[1] / st - ys;
+  t[2] = logf(gt_box[2] / st + 1e-8f);
+  t[3] = logf(gt_box[3] / st + 1e-8f);
+}
+
 __global__ __launch_bounds__(256) void k_loss(const plyolo_yolox_desc d, const float* raw, const float* labels, LossWs ws,
                                               const uint8_t* fg, const int32_t* mgt, const float* miou) {
   const size_t total = (size_t)d.B * d.A;
   const int nch = 5 + d.C;
-  float s_iou = 0.f, s_obj = 0.f, s_cls = 0.f, s_fg = 0.f;
+  float s_iou = 0.f, s_obj = 0.f, s_cls = 0.f, s_fg = 0.f, s_l1 = 0.f;
   const size_t ba = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (ba < total) {
-    const int b = (int)(ba / d.A);
-    const float* r = raw + raw_row(d, b, (int)(ba - (size_t)b * d.A)) * nch;
+    const int b = (int)(ba / d.A), a = (int)(ba - (size_t)b * d.A);
+    const float* r = raw + raw_row(d, b, a) * nch;
     const bool f = fg[ba] != 0;
     s_obj = bce_logits(r[4], f ? 1.0f : 0.0f);
     if (f) {
       const float* lg = labels + ((size_t)b * d.M + mgt[ba]) * 5;
       s_fg = 1.f;
       s_iou = giou_loss(ws.dec + ba * 4, lg + 1, nullptr);
+      if (d.use_l1) {   // nn.L1Loss(reduction="none") of the raw box outputs against get_l1_type (yolox_loss.py:157-158)
+        float xs, ys, st, t[4];
+        anchor_geom(d, a, &xs, &ys, &st);
+        l1_target(lg + 1, xs, ys, st, t);
+        s_l1 = fabsf(r[0] - t[0]) + fabsf(r[1] - t[1]) + fabsf(r[2] - t[2]) + fabsf(r[3] - t[3]);
+      }
     }
   }
   {
@@ -492,29 +507,29 @@ __global__ __launch_bounds__(256) void k_loss(const plyolo_yolox_desc d, const f
       s_cls += part;   // every lane carries a share; the block reduction below sums them all
     }
   }
-  __shared__ float red[4][4];
-  float v[4] = {s_iou, s_obj, s_cls, s_fg};
+  __shared__ float red[4][NPART];
+  float v[NPART] = {s_iou, s_obj, s_cls, s_fg, s_l1};
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NPART; ++i) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v[i] += __shfl_xor(v[i], o);
   }
   if ((threadIdx.x & 63) == 0)
-    for (int i = 0; i < 4; ++i) red[threadIdx.x >> 6][i] = v[i];
+    for (int i = 0; i < NPART; ++i) red[threadIdx.x >> 6][i] = v[i];
   __syncthreads();
-  if (threadIdx.x < 4) ws.partial[(size_t)blockIdx.x * 4 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  if (threadIdx.x < NPART) ws.partial[(size_t)blockIdx.x * NPART + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
 __global__ void k_final(int nblk, int B, LossWs ws, float* losses) {
-  __shared__ double red[256][4];
-  double s[4] = {0, 0, 0, 0};
+  __shared__ double red[256][NPART];
+  double s[NPART] = {0, 0, 0, 0, 0};
   for (int i = threadIdx.x; i < nblk; i += 256)
-    for (int j = 0; j < 4; ++j) s[j] += ws.partial[(size_t)i * 4 + j];
-  for (int j = 0; j < 4; ++j) red[threadIdx.x][j] = s[j];
+    for (int j = 0; j < NPART; ++j) s[j] += ws.partial[(size_t)i * NPART + j];
+  for (int j = 0; j < NPART; ++j) red[threadIdx.x][j] = s[j];
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if ((int)threadIdx.x < o)
-      for (int j = 0; j < 4; ++j) red[threadIdx.x][j] += red[threadIdx.x + o][j];
+      for (int j = 0; j < NPART; ++j) red[threadIdx.x][j] += red[threadIdx.x + o][j];
     __syncthreads();
   }
   if (threadIdx.x == 0) {
@@ -523,19 +538,20 @@ __global__ void k_final(int nblk, int B, LossWs ws, float* losses) {
     const double nfg = red[0][3];
     const double N = nfg > 1.0 ? nfg : 1.0;
     const float li = (float)(red[0][0] / N), lo = (float)(red[0][1] / N), lc = (float)(red[0][2] / N);
-    losses[0] = 5.0f * li + lo + lc;
+    const float l1 = (float)(red[0][4] / N);   // 0 without use_l1 (yolox_loss.py:157-160)
+    losses[0] = 5.0f * li + lo + lc + l1;
     losses[1] = li;
     losses[2] = lo;
     losses[3] = lc;
     losses[4] = (float)nfg;
     losses[5] = (float)ngt;
     losses[6] = (float)(N / (ngt > 1 ? (double)ngt : 1.0));  // proportion (yolox_loss.py:171)
-    losses[7] = 0.f;
+    losses[7] = l1;
   }
 }
 
-// d(sum_i gout[i]*losses[i]) / d(raw): losses[0] = 5*iou + obj + cls, so the three terms carry
-// w_iou = 5*g0+g1, w_obj = g0+g2, w_cls = g0+g3.  One thread per (level-major row, channel).
+// d(sum_i gout[i]*losses[i]) / d(raw): losses[0] = 5*iou + obj + cls (+ l1), so the terms carry
+// w_iou = 5*g0+g1, w_obj = g0+g2, w_cls = g0+g3, w_l1 = g0+g7.  One thread per (level-major row, channel).
 template <bool BF16OUT>
 __global__ void k_bwd(const plyolo_yolox_desc d, const float* raw, const float* labels, const uint8_t* fg, const int32_t* mgt,
                       const float* miou, const float* losses, const float* gout, float* draw, bf16_t* d_regobj, bf16_t* d_cls,
@@ -578,6 +594,12 @@ __global__ void k_bwd(const plyolo_yolox_desc d, const float* raw, const float* 
       giou_loss(p, lg + 1, gr);
       const float chain = (c < 2) ? st : p[c];  // d cx/d tx = s ; d w/d tw = w
       g = w_iou * gr[c] * chain * invN;
+      if (d.use_l1) {   // d|r - t| = sign(r - t), 0 at equality (torch's l1_loss backward)
+        float t[4];
+        l1_target(lg + 1, xs, ys, st, t);
+        const float df = r[c] - t[c];
+        g += (gout ? g0 + gout[7] : 1.0f) * ((df > 0.f) ? 1.f : (df < 0.f ? -1.f : 0.f)) * invN;
+      }
     }
   }
   if (BF16OUT) {
@@ -630,6 +652,16 @@ __global__ __launch_bounds__(256) void k_bwd_vec(const plyolo_yolox_desc d, cons
       giou_loss(p, lg + 1, gr);
 #pragma unroll
       for (int c = 0; c < 4; ++c) g[c] = w_iou * gr[c] * ((c < 2) ? st : p[c]) * invN;
+      if (d.use_l1) {
+        float t[4];
+        l1_target(lg + 1, xs, ys, st, t);
+        const float w_l1 = (gout ? g0 + gout[7] : 1.0f) * invN;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float df = r[c] - t[c];
+          g[c] += w_l1 * ((df > 0.f) ? 1.f : (df < 0.f ? -1.f : 0.f));
+        }
+      }
     }
   } else if (f) {
     const float* lg = labels + ((size_t)b * d.M + mgt[ba]) * 5;
@@ -715,7 +747,7 @@ LossWs carve(const plyolo_yolox_desc* d, void* workspace, size_t* used) {
   ws.cand = (uint8_t*)(p + off); off += align256(BA);
   ws.G = (int*)(p + off); off += align256((size_t)d->B * 4);
   const size_t nblk = (BA + 255) / 256;
-  ws.partial = (float*)(p + off); off += align256(nblk * 16);
+  ws.partial = (float*)(p + off); off += align256(nblk * NPART * 4);
   ws.costm = (float*)(p + off); off += align256(BA * d->M * 4);
   ws.ioum = (float*)(p + off); off += align256(BA * d->M * 4);
   *used = off;

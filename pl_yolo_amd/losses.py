@@ -11,8 +11,6 @@ from . import graph as G
 class YOLOXLoss(nn.Module):
     def __init__(self, num_classes, strides, use_l1=False):
         super().__init__()
-        if use_l1:
-            raise NotImplementedError("use_l1 is never enabled by the reference (build_detection.py:137-139)")
         self.num_classes = num_classes
         self.strides = strides
         self.n_anchors = 1
@@ -24,6 +22,9 @@ class YOLOXLoss(nn.Module):
 
     def emit(self, g, head_buffers, training):
         if training:
+            # use_l1 (yolox_loss.py:128-135,157-158; a constructor argument the plugin factory never sets): the L1 term of the
+            # raw box outputs rides the same loss / gradient kernels
+            head_buffers.desc.use_l1 = 1 if self.use_l1 else 0
             G.YoloxLossOp(g, head_buffers)
         else:
             G.YoloxEvalDecodeOp(g, head_buffers)

@@ -110,7 +110,8 @@ class DetectorRunner:
     def _session(self, B, H, W, M, mode, device):
         if not self._adopted_ok(device):
             self.adopt(device)
-        key = (B, H, W, M, mode, self.dtype, self.model_ref.training)
+        # use_l1 is baked into the recorded loss launches: flipping it on a live model (YOLOX's last epochs) traces a new session
+        key = (B, H, W, M, mode, self.dtype, self.model_ref.training, bool(getattr(self.model_ref.loss, "use_l1", False)))
         s = self.sessions.get(key)
         if s is None:
             s = self._build(B, H, W, M, mode, device)

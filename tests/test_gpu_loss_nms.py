@@ -18,10 +18,11 @@ from conftest import load_golden  # noqa: E402
 from oracle import yolox_loss as ol, nms as onms  # noqa: E402
 
 
-def run_loss(maps, labels, strides, C_, gout=None, bf16_grads=False):
+def run_loss(maps, labels, strides, C_, gout=None, bf16_grads=False, use_l1=False):
     B = maps[0].shape[0]
     sizes = [tuple(m.shape[2:]) for m in maps]
     d, rows = hu.yolox_desc(B, C_, labels.shape[1], sizes, strides)
+    d.use_l1 = 1 if use_l1 else 0
     raw = hu.maps_to_raw([m.to(hu.DEV) for m in maps])
     lab = labels.to(hu.DEV).float().contiguous()
     BA = B * d.A
@@ -76,6 +77,44 @@ def test_loss_vs_golden(case):
         ref = g["grad%d" % i]
         assert float(np.abs(gr.numpy() - ref).max()) <= 1e-5 * max(1e-3, float(np.abs(ref).max())), i
     np.testing.assert_allclose(r["eval"].numpy(), g["eval_decode"], rtol=2e-6, atol=2e-5)
+
+
+@pytest.mark.parametrize("case", ["F", "G"])
+def test_use_l1_vs_golden(case):
+    """YOLOXLoss(use_l1=True), yolox_loss.py:128-135,157-160, against the reference-generated vectors."""
+    g, maps, labels, strides, C_ = _load(case)
+    r = run_loss(maps, labels, strides, C_, use_l1=True)
+    assert np.array_equal(r["fg"].numpy().astype(bool), g["fg"])
+    assert np.array_equal(r["mgt"].numpy().astype(np.int64), g["matched_gt"])
+    L = r["losses"].numpy()
+    for i, k in ((0, "loss"), (1, "loss_iou"), (2, "loss_obj"), (3, "loss_cls"), (7, "loss_l1")):
+        print(case, k, L[i], float(g[k]))
+        assert abs(L[i] - float(g[k])) <= 1e-4 * max(1.0, abs(float(g[k]))), k
+    for i, gr in enumerate(r["grads"]):
+        ref = g["grad%d" % i]
+        assert float(np.abs(gr.numpy() - ref).max()) <= 1e-5 * max(1e-3, float(np.abs(ref).max())), i
+    # without the flag the same inputs give the case A / E numbers: loss_l1 slot 0, loss smaller by exactly that term
+    r0 = run_loss(maps, labels, strides, C_)
+    assert float(r0["losses"][7]) == 0.0
+    assert abs(float(r0["losses"][0]) + float(L[7]) - float(L[0])) <= 1e-4 * float(L[0])
+
+
+def test_use_l1_weighted_gradients_vs_oracle():
+    """gout[7] is the upstream gradient of loss_l1; both gradient forms (fp32 rows, bf16 matrices)."""
+    maps, lab, strides = _rand_case(14, 3, 20, 256, [25, 0, 6])
+    gout = torch.tensor([1.0, 0.3, -0.2, 0.5, 0.0, 0.0, 0.0, 0.7])
+    leafs = [m.clone().requires_grad_(True) for m in maps]
+    out = ol.yolox_loss(leafs, lab, strides, 20, return_assign=True, use_l1=True)
+    (gout[0] * out["loss"] + gout[1] * out["loss_iou"] + gout[2] * out["loss_obj"] + gout[3] * out["loss_cls"] + gout[7] * out["loss_l1"]).backward()
+    r = run_loss(maps, lab, strides, 20, gout=gout, use_l1=True)
+    assert torch.equal(r["fg"].bool(), out["_assign"]["fg"]) or out["_assign"]["boundary_gap"] < 1e-5
+    if torch.equal(r["fg"].bool(), out["_assign"]["fg"]):
+        assert abs(float(r["losses"][7]) - float(out["loss_l1"].detach())) <= 1e-4 * max(1.0, float(out["loss_l1"].detach()))
+        for gr, l in zip(r["grads"], leafs):
+            assert float((gr - l.grad).abs().max()) <= 1e-5 * max(1e-3, float(l.grad.abs().max()))
+    r2 = run_loss(maps, lab, strides, 20, gout=gout, bf16_grads=True, use_l1=True)
+    for g32, g16 in zip(r["grads"], r2["grads"]):
+        assert torch.equal(g32.to(torch.bfloat16).float(), g16)
 
 
 def _rand_case(seed, B, C_, size, counts):

@@ -426,6 +426,38 @@ def test_warm_weights_fp32_vs_reference():
             assert err <= 2e-4 * max(float(np.abs(v).max()), 1e-3 * gmax), (k, err)
 
 
+def test_use_l1_flipped_on_a_live_model_vs_oracle():
+    """YOLOXLoss.use_l1 (yolox_loss.py:14,128-135,157-160) switched on after the model has already stepped -- what YOLOX does for
+    its last epochs: the runner traces a new session (the flag is baked into the recorded loss launches), the dict carries
+    `loss_l1` as a tensor, losses and every parameter gradient match the oracle detector (pinned against the reference by
+    loss_case_F / G) on the warm weights."""
+    from oracle import detector as od
+    g, model = _warm_model("fp32")
+    x, labels = torch.from_numpy(g["x"]), torch.from_numpy(g["labels"])
+    out0 = model(x.to(hu.DEV), labels.to(hu.DEV))
+    assert out0["loss_l1"] == 0.0
+    out0["loss"].backward()
+    model.zero_grad()
+    model.loss.use_l1 = True
+    out = model(x.to(hu.DEV), labels.to(hu.DEV))
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    cfg, nc = _cfg("yolox_test"), int(g["num_classes"])
+    state = {k[6:]: torch.from_numpy(v.copy()) for k, v in g.items() if k.startswith("state/")}
+    ref, rgrads = od.train_step_grads(state, cfg, nc, x, labels, use_l1=True)
+    assert float(ref["loss_l1"]) > 0.05
+    for k in ("loss", "loss_iou", "loss_obj", "loss_cls", "loss_l1"):
+        got, want = float(out[k]), float(ref[k])
+        print("use_l1", k, got, want)
+        assert abs(got - want) <= 1e-4 * max(1.0, abs(want)), (k, got, want)
+    assert abs(float(out["loss"]) - float(out0["loss"]) - float(out["loss_l1"])) <= 1e-4 * float(out["loss"])
+    params = dict(model.named_parameters())
+    gmax = max(float(v.abs().max()) for v in rgrads.values())
+    for k, v in rgrads.items():
+        err = float((params[k].grad.cpu() - v).abs().max())
+        assert err <= 2e-4 * max(float(v.abs().max()), 1e-3 * gmax), (k, err)
+
+
 def test_warm_weights_bf16_end_to_end():
     """bf16 MFMA mode on the warm weights, the WHOLE training step (SimOTA included) against the reference's fp32
     numbers: a net that has trained for a while is not the perturbation amplifier a random-initialised one is, so

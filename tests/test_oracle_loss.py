@@ -8,6 +8,7 @@ from oracle import yolox_loss as ol
 from conftest import load_golden
 
 CASES = ["A", "B", "C", "D", "E"]
+L1_CASES = ["F", "G"]     # YOLOXLoss(use_l1=True) on the inputs of A and E
 
 
 def _load(case):
@@ -40,6 +41,23 @@ def test_losses_and_grads(case):
         np.testing.assert_allclose(l.grad.numpy(), g["grad%d" % i], rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("case", L1_CASES)
+def test_use_l1_losses_and_grads(case):
+    """yolox_loss.py:128-135,157-160: same assignment, + L1 of the raw box outputs of the foreground anchors."""
+    g, maps, labels, strides, C = _load(case)
+    assert int(g["use_l1"]) == 1
+    leafs = [m.clone().requires_grad_(True) for m in maps]
+    out = ol.yolox_loss(leafs, labels, strides, C, return_assign=True, use_l1=True)
+    assert np.array_equal(out["_assign"]["fg"].numpy(), g["fg"])
+    assert np.array_equal(out["_assign"]["matched_gt"].numpy(), g["matched_gt"])
+    for k in ("loss", "loss_iou", "loss_obj", "loss_cls", "loss_l1"):
+        assert abs(float(out[k].detach()) - float(g[k])) <= 1e-5 * max(1.0, abs(float(g[k]))), k
+    assert float(g["loss_l1"]) > 0.1
+    out["loss"].backward()
+    for i, l in enumerate(leafs):
+        np.testing.assert_allclose(l.grad.numpy(), g["grad%d" % i], rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("case", CASES)
 def test_eval_decode(case):
     g, maps, labels, strides, C = _load(case)
@@ -50,7 +68,7 @@ def test_eval_decode(case):
 def test_fixtures_are_tie_free():
     # the reference's sort is unstable; fixtures are only valid pins if the
     # k-th boundary is not tied
-    for case in CASES:
+    for case in CASES + L1_CASES:
         g = load_golden("loss_case_" + case)
         assert float(g["boundary_gap"]) > 1e-6, case
 

@@ -75,10 +75,10 @@ def _dk_spy(fg_mask, cost, pair_wise_ious, gt_classes, num_gt):
 ref_loss_mod.dynamic_k_matching = _dk_spy
 
 
-def run_ref_loss(maps, labels, strides, num_classes):
+def run_ref_loss(maps, labels, strides, num_classes, use_l1=False):
     """maps: list of leaf-less tensors; returns dict of outputs incl. dense assignment."""
     _calls.clear()
-    loss_fn = YOLOXLoss(num_classes, strides)
+    loss_fn = YOLOXLoss(num_classes, strides, use_l1=use_l1)
     loss_fn.train()
     leafs = [m.clone().requires_grad_(True) for m in maps]
     # the loss writes through views of its inputs: hand it non-leaf copies
@@ -106,6 +106,9 @@ def run_ref_loss(maps, labels, strides, num_classes):
         loss=out["loss"], loss_iou=out["loss_iou"], loss_obj=out["loss_obj"], loss_cls=out["loss_cls"],
         proportion=float(out["proportion"]), fg=fg, matched_gt=mg, matched_iou=mi, boundary_gap=gap,
     )
+    if use_l1:
+        res["loss_l1"] = out["loss_l1"]
+        res["use_l1"] = np.asarray(1)
     for i, l in enumerate(leafs):
         res["grad%d" % i] = l.grad
     loss_fn.eval()
@@ -134,7 +137,7 @@ def rand_labels(gen, counts, C, size, max_gt, min_wh=8.0):
     return lab
 
 
-def gen_loss_cases():
+def gen_loss_cases(only=None):
     cases = {}
     # A: realistic multi-level case incl. an image with zero GTs
     gen = torch.Generator().manual_seed(101)
@@ -182,8 +185,14 @@ def gen_loss_cases():
     labels = rand_labels(gen, [60, 17], 80, 256, 64, min_wh=6.0)
     cases["E"] = (maps, labels, [8, 16, 32], 80)
 
-    for name, (maps, labels, strides, C) in cases.items():
-        r = run_ref_loss(maps, labels, strides, C)
+    # F, G: YOLOXLoss(use_l1=True) (yolox_loss.py:128-135,157-158) on the inputs of A and E
+    cases["F"] = cases["A"] + (True,)
+    cases["G"] = cases["E"] + (True,)
+    for name, case in cases.items():
+        if only is not None and name not in only:
+            continue
+        maps, labels, strides, C = case[:4]
+        r = run_ref_loss(maps, labels, strides, C, use_l1=len(case) > 4)
         d = dict(labels=labels, strides=np.asarray(strides), num_classes=C, nmaps=len(maps))
         for i, m in enumerate(maps):
             d["map%d" % i] = m
@@ -895,6 +904,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "repconv":
         gen_repconv()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "loss_l1":
+        gen_loss_cases(only=("F", "G"))
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "v7loss":
         gen_v7loss_cases()
