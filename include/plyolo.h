@@ -313,6 +313,10 @@ int plyolo_mosaic4(const plyolo_mosaic_tile* tiles_host, int canvas_h, int canva
 /* cv2.warpAffine(src, M, dsize=(dw, dh), borderValue=border) with inv6_host = the INVERSE of M (cv::invertAffineTransform, 6 doubles) */
 int plyolo_warp_affine_u8(const unsigned char* src, int sh, int sw, const double* inv6_host, unsigned char* dst, int dh, int dw, int border,
                           void* stream);
+/* cv2.warpPerspective(src, M, dsize=(dw, dh), borderValue=border) with inv9_host = the INVERSE of the 3x3 M (cv::invert, 9 doubles):
+ * what random_perspective calls when `perspective` is non-zero (mosaic_detection.py:319-323) */
+int plyolo_warp_perspective_u8(const unsigned char* src, int sh, int sw, const double* inv9_host, unsigned char* dst, int dh, int dw, int border,
+                               void* stream);
 /* dst [out_h, out_w, 3]: cv2.resize(src, (dw, dh)) in the top-left corner, `pad` elsewhere */
 int plyolo_resize_pad_u8(const unsigned char* src, int h, int w, int dh, int dw, unsigned char* dst, int out_h, int out_w, int pad, void* stream);
 /* out [th, tw, 3] = uint8(0.5 * origin + 0.5 * crop): `other` [bh, bw, 3] (mirrored if flip), zero-padded to >= th x tw, cut at (y_off, x_off) */

@@ -155,13 +155,18 @@ class TrainTransform:
 
 
 class ValTransform:
-    """data_augments.py:51-85 (legacy=False)."""
+    """data_augments.py:51-85."""
 
     def __init__(self, swap=(2, 0, 1), legacy=False, max_labels=50):
         self.swap, self.legacy, self.max_labels = swap, legacy, max_labels
 
     def __call__(self, img, targets, input_size):
         img, _ = preproc(img, input_size, self.swap)
+        if self.legacy:      # :72-76: BGR -> RGB, /255, ImageNet mean / std; float32 array, float64 constants (numpy rounds per step)
+            img = img[::-1, :, :].copy()
+            img /= 255.0
+            img -= np.array([0.485, 0.456, 0.406]).reshape(3, 1, 1)
+            img /= np.array([0.229, 0.224, 0.225]).reshape(3, 1, 1)
         boxes = xyxy2cxcywh(targets[:, :4].copy())
         labels = np.expand_dims(targets[:, 4].copy(), 1)
         targets_t = np.hstack((labels, boxes))

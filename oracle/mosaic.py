@@ -86,6 +86,67 @@ def warp_affine_u8(img, M, dsize, border_value=(114, 114, 114)):
     return np.clip(out, 0, 255).astype(np.uint8)
 
 
+def invert_3x3(M):
+    """cv::invert of a 3x3 double matrix (the closed form OpenCV uses up to 3x3: cofactors times 1 / det3)."""
+    S = np.asarray(M, dtype=np.float64).reshape(3, 3)
+    d = (S[0, 0] * (S[1, 1] * S[2, 2] - S[1, 2] * S[2, 1]) - S[0, 1] * (S[1, 0] * S[2, 2] - S[1, 2] * S[2, 0])
+         + S[0, 2] * (S[1, 0] * S[2, 1] - S[1, 1] * S[2, 0]))
+    if d == 0.0:
+        return np.zeros(9)
+    d = 1.0 / d
+    return np.array([
+        (S[1, 1] * S[2, 2] - S[1, 2] * S[2, 1]) * d, (S[0, 2] * S[2, 1] - S[0, 1] * S[2, 2]) * d, (S[0, 1] * S[1, 2] - S[0, 2] * S[1, 1]) * d,
+        (S[1, 2] * S[2, 0] - S[1, 0] * S[2, 2]) * d, (S[0, 0] * S[2, 2] - S[0, 2] * S[2, 0]) * d, (S[0, 2] * S[1, 0] - S[0, 0] * S[1, 2]) * d,
+        (S[1, 0] * S[2, 1] - S[1, 1] * S[2, 0]) * d, (S[0, 1] * S[2, 0] - S[0, 0] * S[2, 1]) * d, (S[0, 0] * S[1, 1] - S[0, 1] * S[1, 0]) * d])
+
+
+def warp_perspective_u8(img, M, dsize, border_value=(114, 114, 114)):
+    """cv2.warpPerspective(img, M, dsize=(width, height), borderValue=...) for uint8 HWC, INTER_LINEAR, BORDER_CONSTANT
+    (mosaic_detection.py:320-323 calls it with the AFFINE 3x3 matrix whenever `perspective` is non-zero).  OpenCV's
+    WarpPerspectiveInvoker, restated: M is inverted, destination blocks are 64 columns wide, inside a block
+    X0 = M0*x_block + M1*y + M2 (doubles, left to right), per pixel W = W0 + M6*x1, W = W ? 32/W : 0,
+    X = cvRound(clamp((X0 + M0*x1) * W)); integer part X >> 5, 5-bit bilinear fractions, the same 15-bit weights and
+    rounding as warpAffine's remap.  Parity unpinned (cv2 is absent), like warp_affine_u8."""
+    width, height = int(dsize[0]), int(dsize[1])
+    sh, sw = img.shape[:2]
+    m = invert_3x3(M)
+    bw = min(64, width)
+    xs = np.arange(width, dtype=np.int64)
+    xb = ((xs // bw) * bw).astype(np.float64)[None, :]
+    x1 = (xs % bw).astype(np.float64)[None, :]
+    ys = np.arange(height, dtype=np.float64)[:, None]
+    X0 = m[0] * xb + m[1] * ys + m[2]
+    Y0 = m[3] * xb + m[4] * ys + m[5]
+    W0 = m[6] * xb + m[7] * ys + m[8]
+    W = W0 + m[6] * x1
+    with np.errstate(divide="ignore"):
+        W = np.where(W != 0.0, 32.0 / np.where(W != 0.0, W, 1.0), 0.0)
+    lim_lo, lim_hi = float(-2 ** 31), float(2 ** 31 - 1)
+    fX = np.maximum(lim_lo, np.minimum(lim_hi, (X0 + m[0] * x1) * W))
+    fY = np.maximum(lim_lo, np.minimum(lim_hi, (Y0 + m[3] * x1) * W))
+    X = np.clip(_rint(fX), -2 ** 31, 2 ** 31 - 1)
+    Y = np.clip(_rint(fY), -2 ** 31, 2 ** 31 - 1)
+    sx = np.clip(X >> 5, -32768, 32767)
+    sy = np.clip(Y >> 5, -32768, 32767)
+    fx, fy = X & 31, Y & 31
+    w00 = (32 - fy) * (32 - fx) * 32
+    w01 = (32 - fy) * fx * 32
+    w10 = fy * (32 - fx) * 32
+    w11 = fy * fx * 32
+    src = img.astype(np.int64)
+    cval = np.asarray(border_value, dtype=np.int64)[: img.shape[2]]
+
+    def tap(yy, xx):
+        ok = (yy >= 0) & (yy < sh) & (xx >= 0) & (xx < sw)
+        v = src[np.clip(yy, 0, sh - 1), np.clip(xx, 0, sw - 1)]
+        return np.where(ok[..., None], v, cval[None, None, :])
+
+    acc = (tap(sy, sx) * w00[..., None] + tap(sy, sx + 1) * w01[..., None]
+           + tap(sy + 1, sx) * w10[..., None] + tap(sy + 1, sx + 1) * w11[..., None])
+    out = (acc + (1 << 14)) >> 15
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
 def resize(img, dsize):
     """cv2.resize(img, (w, h), interpolation=INTER_LINEAR) for uint8 HWC."""
     return resize_linear_u8(img, int(dsize[0]), int(dsize[1]))
@@ -157,11 +218,14 @@ def affine_labels(targets, M, s, width, height):
 
 
 def random_perspective(img, targets=(), degrees=10, translate=0.1, scale=(0.5, 1.5), shear=10, perspective=0.0, border=(0, 0)):
-    if perspective:
-        raise NotImplementedError("perspective != 0 (cv2.warpPerspective) is not restated")
+    """mosaic_detection.py:269-371.  `perspective` only selects the OpenCV entry point (:319-327): the matrix stays the affine
+    T S R C, so the box arithmetic (division by a third coordinate that is exactly 1, :341-342) is unchanged."""
     M, s, width, height = affine_decision(img.shape[:2], degrees, translate, scale, shear, border)
     if (border[0] != 0) or (border[1] != 0) or (M != np.eye(3)).any():
-        img = warp_affine_u8(img, M[:2], (width, height), (114, 114, 114))
+        if perspective:
+            img = warp_perspective_u8(img, M, (width, height), (114, 114, 114))
+        else:
+            img = warp_affine_u8(img, M[:2], (width, height), (114, 114, 114))
     return img, affine_labels(targets, M, s, width, height)
 
 

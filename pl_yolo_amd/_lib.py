@@ -173,6 +173,7 @@ SIGNATURES = {
     "plyolo_lnw_act_bwd": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _vp]),
     "plyolo_mosaic4": (_i, [_vp, _i, _i, _vp, _vp]),
     "plyolo_warp_affine_u8": (_i, [_vp, _i, _i, _P(_d), _vp, _i, _i, _i, _vp]),
+    "plyolo_warp_perspective_u8": (_i, [_vp, _i, _i, _P(_d), _vp, _i, _i, _i, _vp]),
     "plyolo_resize_pad_u8": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
     "plyolo_mixup_blend_u8": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "plyolo_reduce_slabs_plan": (_i, [_i, _sz, _P(_i), _P(_i)]),

@@ -199,6 +199,51 @@ __global__ void k_warp_affine(const unsigned char* src, int SH, int SW, const Af
   }
 }
 
+// cv2.warpPerspective(INTER_LINEAR, BORDER_CONSTANT): OpenCV's WarpPerspectiveInvoker restated -- destination blocks of 64 columns,
+// X0 = M0*x_block + M1*y + M2 in doubles, per pixel W = W0 + M6*x1, W = W ? 32/W : 0, X = cvRound(clamp((X0 + M0*x1)*W)); the
+// integer / 5-bit fraction split and the 15-bit bilinear weights are the remap warpAffine shares.
+struct Persp9 { double m[9]; };    // the INVERTED 3x3 matrix (dst -> src)
+
+__global__ void k_warp_perspective(const unsigned char* src, int SH, int SW, const Persp9 a, unsigned char* dst, int DH, int DW, int border) {
+  const int bw = DW < 64 ? DW : 64;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < DH * DW; idx += gridDim.x * blockDim.x) {
+    const int y = idx / DW, x = idx - y * DW;
+    long long X, Y;
+    {
+#pragma clang fp contract(off)   // every product and sum rounded, as in OpenCV's scalar code and in the numpy oracle
+      const double xb = (double)((x / bw) * bw), x1 = (double)(x % bw), yd = (double)y;
+      const double X0 = a.m[0] * xb + a.m[1] * yd + a.m[2];
+      const double Y0 = a.m[3] * xb + a.m[4] * yd + a.m[5];
+      const double W0 = a.m[6] * xb + a.m[7] * yd + a.m[8];
+      double W = W0 + a.m[6] * x1;
+      W = W != 0.0 ? 32.0 / W : 0.0;
+      const double lo = -2147483648.0, hi = 2147483647.0;
+      const double fX = fmax(lo, fmin(hi, (X0 + a.m[0] * x1) * W));
+      const double fY = fmax(lo, fmin(hi, (Y0 + a.m[3] * x1) * W));
+      X = __double2ll_rn(fX);
+      Y = __double2ll_rn(fY);
+    }
+    long long sxl = X >> 5, syl = Y >> 5;
+    sxl = sxl < -32768 ? -32768 : (sxl > 32767 ? 32767 : sxl);     // saturate_cast<short>
+    syl = syl < -32768 ? -32768 : (syl > 32767 ? 32767 : syl);
+    const int sx = (int)sxl, sy = (int)syl, fx = (int)(X & 31), fy = (int)(Y & 31);
+    const int w00 = (32 - fy) * (32 - fx) * 32, w01 = (32 - fy) * fx * 32, w10 = fy * (32 - fx) * 32, w11 = fy * fx * 32;
+    const bool y0ok = sy >= 0 && sy < SH, y1ok = sy + 1 >= 0 && sy + 1 < SH, x0ok = sx >= 0 && sx < SW, x1ok = sx + 1 >= 0 && sx + 1 < SW;
+    const unsigned char* p00 = src + ((size_t)(y0ok ? sy : 0) * SW + (x0ok ? sx : 0)) * 3;
+    const unsigned char* p01 = src + ((size_t)(y0ok ? sy : 0) * SW + (x1ok ? sx + 1 : 0)) * 3;
+    const unsigned char* p10 = src + ((size_t)(y1ok ? sy + 1 : 0) * SW + (x0ok ? sx : 0)) * 3;
+    const unsigned char* p11 = src + ((size_t)(y1ok ? sy + 1 : 0) * SW + (x1ok ? sx + 1 : 0)) * 3;
+    unsigned char* o = dst + (size_t)idx * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int v00 = y0ok && x0ok ? p00[c] : border, v01 = y0ok && x1ok ? p01[c] : border;
+      const int v10 = y1ok && x0ok ? p10[c] : border, v11 = y1ok && x1ok ? p11[c] : border;
+      const int q = (v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11 + (1 << 14)) >> 15;
+      o[c] = (unsigned char)(q < 0 ? 0 : (q > 255 ? 255 : q));
+    }
+  }
+}
+
 // dst [OH, OW, 3]: the resized image in the top-left dh x dw, `pad` elsewhere
 __global__ void k_resize_pad(const unsigned char* src, int h, int w, int dh, int dw, unsigned char* dst, int OH, int OW, int pad) {
   const double sx_scale = (double)w / dw, sy_scale = (double)h / dh;
@@ -267,6 +312,18 @@ int plyolo_warp_affine_u8(const unsigned char* src, int sh, int sw, const double
   plyolo::annotate("warp_affine_u8", 0.0, (double)dh * dw * 3 * 5.0);
   return submit(stream, [=](hipStream_t s) -> hipError_t {
     hipLaunchKernelGGL(k_warp_affine, dim3((unsigned)cdiv(dh * dw, 256)), dim3(256), 0, s, src, sh, sw, a, dst, dh, dw, border);
+    return hipGetLastError();
+  });
+}
+
+int plyolo_warp_perspective_u8(const unsigned char* src, int sh, int sw, const double* inv9_host, unsigned char* dst, int dh, int dw, int border,
+                               void* stream) {
+  PLY_CHECK_ARG(src && dst && inv9_host && sh > 0 && sw > 0 && dh > 0 && dw > 0 && border >= 0 && border <= 255, "warp_perspective_u8: bad arguments");
+  Persp9 a;
+  for (int i = 0; i < 9; ++i) a.m[i] = inv9_host[i];
+  plyolo::annotate("warp_perspective_u8", 0.0, (double)dh * dw * 3 * 5.0);
+  return submit(stream, [=](hipStream_t s) -> hipError_t {
+    hipLaunchKernelGGL(k_warp_perspective, dim3((unsigned)cdiv(dh * dw, 256)), dim3(256), 0, s, src, sh, sw, a, dst, dh, dw, border);
     return hipGetLastError();
   });
 }

@@ -131,8 +131,6 @@ class ValTransform:
     """data_augments.py:51-85."""
 
     def __init__(self, swap=(2, 0, 1), legacy=False, max_labels=50):
-        if legacy:
-            raise NotImplementedError("ValTransform(legacy=True) (RGB + ImageNet normalisation) is not built")
         self.swap, self.legacy, self.max_labels = swap, legacy, max_labels
 
     def _labels(self, targets):
@@ -145,6 +143,16 @@ class ValTransform:
 
     def batch(self, images, targets_list, input_size):
         out, _ = preproc_batch(images, input_size)
+        if self.legacy:
+            # data_augments.py:72-76: BGR -> RGB, /255 in fp32, then ImageNet mean / std as float64 constants on the fp32 array
+            # (numpy computes those two steps in double and rounds each back to fp32)
+            # (the /255 through fp64 as well: torch turns a division by a scalar into a multiplication by its reciprocal on the
+            # device; pixel values are integers, for which rounding the fp64 quotient equals the fp32 division numpy performs)
+            out = (out.flip(1).double() / 255.0).float()
+            mean = torch.tensor([0.485, 0.456, 0.406], dtype=torch.float64, device=out.device).view(1, 3, 1, 1)
+            std = torch.tensor([0.229, 0.224, 0.225], dtype=torch.float64, device=out.device).view(1, 3, 1, 1)
+            out = (out.double() - mean).float()
+            out = (out.double() / std).float()
         return out, np.stack([self._labels(t) for t in targets_list], 0)
 
     def __call__(self, img, targets, input_size):
@@ -196,6 +204,30 @@ def warp_affine(img, M, dsize, border_value=114):
     return out
 
 
+def invert_3x3(M):
+    """cv::invert of a 3x3 double matrix (OpenCV's closed form up to 3x3: cofactors times 1 / det), what cv2.warpPerspective
+    does to M before sampling."""
+    S = [[float(v) for v in row] for row in np.asarray(M, dtype=np.float64).reshape(3, 3)]
+    d = (S[0][0] * (S[1][1] * S[2][2] - S[1][2] * S[2][1]) - S[0][1] * (S[1][0] * S[2][2] - S[1][2] * S[2][0])
+         + S[0][2] * (S[1][0] * S[2][1] - S[1][1] * S[2][0]))
+    if d == 0.0:
+        return [0.0] * 9
+    d = 1.0 / d
+    return [(S[1][1] * S[2][2] - S[1][2] * S[2][1]) * d, (S[0][2] * S[2][1] - S[0][1] * S[2][2]) * d, (S[0][1] * S[1][2] - S[0][2] * S[1][1]) * d,
+            (S[1][2] * S[2][0] - S[1][0] * S[2][2]) * d, (S[0][0] * S[2][2] - S[0][2] * S[2][0]) * d, (S[0][2] * S[1][0] - S[0][0] * S[1][2]) * d,
+            (S[1][0] * S[2][1] - S[1][1] * S[2][0]) * d, (S[0][1] * S[2][0] - S[0][0] * S[2][1]) * d, (S[0][0] * S[1][1] - S[0][1] * S[1][0]) * d]
+
+
+def warp_perspective(img, M, dsize, border_value=114):
+    """cv2.warpPerspective(img, M, dsize=(width, height), borderValue=(v, v, v)) on a uint8 HWC device tensor, M 3x3."""
+    img = _check_image(img)
+    width, height = int(dsize[0]), int(dsize[1])
+    out = torch.empty(height, width, 3, dtype=torch.uint8, device=img.device)
+    inv = (C.c_double * 9)(*invert_3x3(M))
+    call("plyolo_warp_perspective_u8", img.data_ptr(), int(img.shape[0]), int(img.shape[1]), inv, out.data_ptr(), height, width, int(border_value), _stream())
+    return out
+
+
 def resize_pad(img, dsize, out_hw=None, pad=114):
     """cv2.resize(img, (w, h)) into the top-left corner of a [out_h, out_w, 3] image filled with `pad` (default: no padding)."""
     img = _check_image(img)
@@ -214,10 +246,9 @@ def _box_candidates(box1, box2, wh_thr=2, ar_thr=20, area_thr=0.2):   # mosaic_d
 
 
 def random_perspective(img, targets=(), degrees=10, translate=0.1, scale=(0.5, 1.5), shear=10, perspective=0.0, border=(0, 0)):
-    """mosaic_detection.py:277-371 with perspective = 0: five draws, M = T S R C, warpAffine with border 114, boxes through M,
+    """mosaic_detection.py:269-371: five draws, M = T S R C, warpAffine -- or, when `perspective` is non-zero, warpPerspective with
+    the same (affine) matrix, :319-327 -- with border 114, boxes through M (the perspective division :341-342 divides by exactly 1),
     clipped, filtered by box_candidates."""
-    if perspective:
-        raise NotImplementedError("perspective != 0 (cv2.warpPerspective) is not built")
     sh, sw = int(img.shape[0]), int(img.shape[1])
     height, width = sh + border[0] * 2, sw + border[1] * 2
     Cm = np.eye(3)
@@ -235,7 +266,7 @@ def random_perspective(img, targets=(), degrees=10, translate=0.1, scale=(0.5, 1
     T[1, 2] = random.uniform(0.5 - translate, 0.5 + translate) * height
     M = T @ S @ R @ Cm
     if (border[0] != 0) or (border[1] != 0) or (M != np.eye(3)).any():
-        img = warp_affine(img, M[:2], (width, height), 114)
+        img = warp_perspective(img, M, (width, height), 114) if perspective else warp_affine(img, M[:2], (width, height), 114)
     n = len(targets)
     if n:
         xy = np.ones((n * 4, 3))
@@ -264,8 +295,6 @@ class MosaicDetection:
                  copypaste_scale=(0.5, 1.5), cutpaste_prob=0.0, cutoutR_prob=0.0):
         if copypaste_prob or cutpaste_prob or cutoutR_prob:
             raise NotImplementedError("copy-paste / cut-paste / rounding cut-out (probability 0 in every shipped config) are not built")
-        if perspective:
-            raise NotImplementedError("perspective != 0 (cv2.warpPerspective) is not built")
         self._dataset, self.img_size, self.preprocess = dataset, img_size, preprocess
         self.mosaic_prob, self.scale = mosaic_prob, mosaic_scale
         self.degrees, self.translate, self.shear, self.perspective = degrees, translate, shear, perspective

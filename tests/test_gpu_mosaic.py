@@ -20,7 +20,8 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 FIX = np.load(os.path.join(ROOT, "tests", "golden", "mosaic_samples.npz"))
 CASES = {"mix": dict(mosaic_prob=1.0, mixup_prob=1.0), "nomix": dict(mosaic_prob=1.0, mixup_prob=0.0),
-         "plain": dict(mosaic_prob=0.0, mixup_prob=1.0), "coin": dict(mosaic_prob=0.5, mixup_prob=0.5)}
+         "plain": dict(mosaic_prob=0.0, mixup_prob=1.0), "coin": dict(mosaic_prob=0.5, mixup_prob=0.5),
+         "persp": dict(mosaic_prob=1.0, mixup_prob=0.0, perspective=0.001)}      # cv2.warpPerspective with the affine matrix
 
 
 class ToyDataset:
@@ -93,6 +94,27 @@ def test_warp_affine_vs_oracle_random_matrices(shape, dsize):
     assert pdata.invert_affine(M[:2]) == list(om.invert_affine(M[:2]))
 
 
+@pytest.mark.parametrize("shape,dsize", [((37, 53), (64, 48)), ((96, 128), (200, 48)), ((20, 20), (31, 57)), ((640, 480), (320, 320))])
+def test_warp_perspective_vs_oracle_random_matrices(shape, dsize):
+    """plyolo_warp_perspective_u8 == oracle bit for bit: the affine matrices the reference passes AND true projective ones."""
+    rng = np.random.RandomState(shape[0] * 5 + dsize[0])
+    img = rng.randint(0, 256, shape + (3,)).astype(np.uint8)
+    random.seed(shape[1] + 1)
+    for rep in range(6):
+        M, s, width, height = om.affine_decision(shape, degrees=25, translate=0.2, scale=(0.4, 1.8), shear=8, border=(0, 0))
+        if rep >= 3:      # a real perspective row
+            M = M.copy()
+            M[2, 0], M[2, 1] = rng.uniform(-2e-3, 2e-3, 2)
+        got = pdata.warp_perspective(dev(img), M, dsize, 114).cpu().numpy()
+        want = om.warp_perspective_u8(img, M, dsize, (114, 114, 114))
+        assert np.array_equal(got, want), (rep, np.abs(got.astype(int) - want.astype(int)).max())
+        assert pdata.invert_3x3(M) == list(om.invert_3x3(M))
+    assert np.array_equal(pdata.warp_perspective(dev(img), np.eye(3), (shape[1], shape[0]), 0).cpu().numpy(), img)
+    sing = np.zeros((3, 3))                                       # singular: cv::invert returns zeros, W = 0 everywhere -> pixel (0, 0)
+    got = pdata.warp_perspective(dev(img), sing, dsize, 9).cpu().numpy()
+    assert np.array_equal(got, om.warp_perspective_u8(img, sing, dsize, (9, 9, 9)))
+
+
 @pytest.mark.parametrize("shape,dsize,out_hw", [((40, 60), (30, 20), (48, 64)), ((17, 91), (91, 17), None), ((50, 50), (125, 124), (130, 130))])
 def test_resize_pad_vs_oracle(shape, dsize, out_hw):
     rng = np.random.RandomState(shape[0])
@@ -123,8 +145,6 @@ def test_mixup_offsets_flip_and_zero_padding():
 def test_refusals():
     with pytest.raises(NotImplementedError):
         pdata.MosaicDetection(ToyDataset(DEV), (48, 64), cutpaste_prob=0.1)
-    with pytest.raises(NotImplementedError):
-        pdata.MosaicDetection(ToyDataset(DEV), (48, 64), perspective=0.001)
     md = pdata.MosaicDetection(ToyDataset(None), (48, 64), preprocess=pdata.TrainTransform())   # host arrays: no CPU path
     with pytest.raises(PlyoloError):
         md[0]

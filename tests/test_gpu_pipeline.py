@@ -87,6 +87,13 @@ def test_transforms_labels_and_pixels_follow_the_oracle_under_the_same_seeds():
         wi, wl = v_ref(im, t, (96, 96))
         assert np.array_equal(out[i].cpu().numpy(), wi)
         np.testing.assert_array_equal(labels[i], wl)
+    # legacy=True (data_augments.py:72-76): RGB + /255 + ImageNet mean / std, bit for bit what numpy leaves in the fp32 array
+    v_ref, v_hip = oa.ValTransform(legacy=True, max_labels=8), pdata.ValTransform(legacy=True, max_labels=8)
+    out, labels = v_hip.batch([torch.from_numpy(im).to(hu.DEV) for im in imgs], tgts, (96, 96))
+    for i, (im, t) in enumerate(zip(imgs, tgts)):
+        wi, wl = v_ref(im, t, (96, 96))
+        assert np.array_equal(out[i].cpu().numpy(), wi)
+        np.testing.assert_array_equal(labels[i], wl)
     with pytest.raises(pl_yolo_amd.PlyoloError):
         pdata.preproc(torch.zeros(8, 8, 3, dtype=torch.uint8), (32, 32))          # CPU tensor: no fallback
 

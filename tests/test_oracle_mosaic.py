@@ -15,7 +15,8 @@ from oracle import augment as oa, mosaic as om  # noqa: E402
 
 FIX = np.load(os.path.join(ROOT, "tests", "golden", "mosaic_samples.npz"))
 CASES = {"mix": dict(mosaic_prob=1.0, mixup_prob=1.0), "nomix": dict(mosaic_prob=1.0, mixup_prob=0.0),
-         "plain": dict(mosaic_prob=0.0, mixup_prob=1.0), "coin": dict(mosaic_prob=0.5, mixup_prob=0.5)}
+         "plain": dict(mosaic_prob=0.0, mixup_prob=1.0), "coin": dict(mosaic_prob=0.5, mixup_prob=0.5),
+         "persp": dict(mosaic_prob=1.0, mixup_prob=0.0, perspective=0.001)}      # cv2.warpPerspective with the affine matrix
 
 
 class ToyDataset:
@@ -86,6 +87,48 @@ def test_warp_affine_structure():
     assert np.allclose(om.invert_affine(inv).reshape(2, 3), M, atol=1e-12)
     R = om.get_rotation_matrix_2d((0, 0), 90.0, 2.0)
     assert np.allclose(R, [[0, 2, 0], [-2, 0, 0]], atol=1e-12)
+
+
+def test_warp_perspective_structure():
+    """The warpPerspective restatement: exact on identity / integer shifts, the projective division is honoured, and on an
+    AFFINE matrix (all the reference ever passes, mosaic_detection.py:319-323) it lands within one coordinate quantum
+    (1/32 px) of warpAffine -- same picture, different rounding path."""
+    rng = np.random.RandomState(1)
+    img = rng.randint(0, 256, (40, 150, 3)).astype(np.uint8)        # wider than two 64-column blocks
+    assert np.array_equal(om.warp_perspective_u8(img, np.eye(3), (150, 40)), img)
+    T = np.eye(3); T[0, 2], T[1, 2] = 7.0, 2.0
+    out = om.warp_perspective_u8(img, T, (150, 40), (114, 114, 114))
+    assert np.array_equal(out[2:, 7:], img[:-2, :-7]) and (out[:2] == 114).all() and (out[:, :7] == 114).all()
+    # a uniform scale written into the projective row: M = diag(1, 1, 0.5) doubles every coordinate
+    P = np.diag([1.0, 1.0, 0.5])
+    out = om.warp_perspective_u8(img, P, (150, 40), (0, 0, 0))
+    S2 = np.diag([2.0, 2.0, 1.0])
+    assert np.array_equal(out, om.warp_perspective_u8(img, S2, (150, 40), (0, 0, 0)))
+    assert np.array_equal(out[::2, ::2][:20, :75], img[:20, :75])
+    # smooth image + affine matrix: the two entry points agree to the interpolation quantum
+    yy, xx = np.mgrid[0:40, 0:150]
+    smooth = np.stack([xx + yy, 2 * yy + 40, 255 - xx], -1).astype(np.uint8)
+    random.seed(3)
+    for _ in range(4):
+        M, s, width, height = om.affine_decision((40, 150), degrees=10, translate=0.1, scale=(0.7, 1.3), shear=4, border=(0, 0))
+        a = om.warp_affine_u8(smooth, M[:2], (150, 40), (114, 114, 114)).astype(int)
+        b = om.warp_perspective_u8(smooth, M, (150, 40), (114, 114, 114)).astype(int)
+        inner = np.abs(a - b)[(a != 114).all(-1) & (b != 114).all(-1)]
+        assert np.percentile(inner, 99) <= 2, np.percentile(inner, 99)
+    inv = om.invert_3x3(M).reshape(3, 3)
+    assert np.allclose(inv @ M, np.eye(3), atol=1e-12)
+
+
+def test_legacy_val_transform():
+    """data_augments.py:72-76: RGB order, /255, ImageNet mean / std."""
+    rng = np.random.RandomState(2)
+    img = rng.randint(0, 256, (30, 40, 3)).astype(np.uint8)
+    t = np.array([[2.0, 3, 20, 25, 1]])
+    plain, lab = oa.ValTransform(max_labels=4)(img, t, (32, 48))
+    leg, lab2 = oa.ValTransform(legacy=True, max_labels=4)(img, t, (32, 48))
+    assert np.array_equal(lab, lab2) and leg.dtype == np.float32
+    mean, std = np.array([0.485, 0.456, 0.406]).reshape(3, 1, 1), np.array([0.229, 0.224, 0.225]).reshape(3, 1, 1)
+    np.testing.assert_allclose(leg, (plain[::-1] / 255.0 - mean) / std, rtol=0, atol=2e-6)
 
 
 def test_affine_labels_keep_boxes_under_identity_and_drop_slivers():

@@ -838,6 +838,7 @@ def gen_mosaic():
     cv2.INTER_LINEAR, cv2.COLOR_BGR2HSV, cv2.COLOR_HSV2BGR = 1, 40, 54
     cv2.resize = lambda img, dsize, interpolation=1: om.resize(img, dsize)
     cv2.warpAffine = lambda img, M, dsize=None, borderValue=(0, 0, 0): om.warp_affine_u8(img, M, dsize, borderValue)
+    cv2.warpPerspective = lambda img, M, dsize=None, borderValue=(0, 0, 0): om.warp_perspective_u8(img, M, dsize, borderValue)
     cv2.getRotationMatrix2D = lambda angle=0, center=(0, 0), scale=1: om.get_rotation_matrix_2d(center, angle, scale)
     cv2.split = lambda a: [a[..., i] for i in range(a.shape[-1])]
     cv2.merge = lambda chans: np.stack(chans, -1)
@@ -857,7 +858,9 @@ def gen_mosaic():
     from models.data.augmentation.data_augments import TrainTransform
     d = {}
     cases = [("mix", dict(mosaic_prob=1.0, mixup_prob=1.0), 11), ("nomix", dict(mosaic_prob=1.0, mixup_prob=0.0), 12),
-             ("plain", dict(mosaic_prob=0.0, mixup_prob=1.0), 13), ("coin", dict(mosaic_prob=0.5, mixup_prob=0.5), 14)]
+             ("plain", dict(mosaic_prob=0.0, mixup_prob=1.0), 13), ("coin", dict(mosaic_prob=0.5, mixup_prob=0.5), 14),
+             # perspective != 0: the reference switches to cv2.warpPerspective with the same affine matrix (:319-327)
+             ("persp", dict(mosaic_prob=1.0, mixup_prob=0.0, perspective=0.001), 15)]
     for tag, kw, seed in cases:
         ds = toy_detection_dataset()
         md = MosaicDetection(ds, (48, 64), preprocess=TrainTransform(max_labels=20, flip_prob=0.5, hsv_prob=1.0), **kw)
