@@ -112,11 +112,26 @@ class DetectorRunner:
             self.adopt(device)
         # use_l1 is baked into the recorded loss launches: flipping it on a live model (YOLOX's last epochs) traces a new session
         key = (B, H, W, M, mode, self.dtype, self.model_ref.training, bool(getattr(self.model_ref.loss, "use_l1", False)))
-        s = self.sessions.get(key)
+        s = self.sessions.pop(key, None)
         if s is None:
+            before = torch.cuda.memory_allocated(device)
             s = self._build(B, H, W, M, mode, device)
-            self.sessions[key] = s
+            s.bytes = max(torch.cuda.memory_allocated(device) - before, 0)
+            self._evict(device, s.bytes)
+        self.sessions[key] = s          # dicts keep insertion order: the most recently used session is last
         return s
+
+    def _evict(self, device, incoming):
+        """Multi-scale training (the reference resizes its batches every few iterations) traces one session -- activations,
+        gradients, weight-gradient slabs, plans -- per input shape.  They stay resident while they fit: when the sessions would
+        hold more than PLYOLO_SESSION_BUDGET (fraction of the device memory, default 0.5) the least recently used ones are
+        dropped (an autograd node that still refers to one keeps it alive until its backward has run)."""
+        frac = float(os.environ.get("PLYOLO_SESSION_BUDGET", "0.5"))
+        budget = frac * torch.cuda.get_device_properties(device).total_memory
+        held = incoming + sum(getattr(v, "bytes", 0) for v in self.sessions.values())
+        while held > budget and self.sessions:
+            k = next(iter(self.sessions))
+            held -= getattr(self.sessions.pop(k), "bytes", 0)
 
     def _build(self, B, H, W, M, mode, device):
         model = self.model_ref

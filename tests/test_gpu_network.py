@@ -445,9 +445,9 @@ def test_use_l1_flipped_on_a_live_model_vs_oracle():
     cfg, nc = _cfg("yolox_test"), int(g["num_classes"])
     state = {k[6:]: torch.from_numpy(v.copy()) for k, v in g.items() if k.startswith("state/")}
     ref, rgrads = od.train_step_grads(state, cfg, nc, x, labels, use_l1=True)
-    assert float(ref["loss_l1"]) > 0.05
+    assert float(ref["loss_l1"].detach()) > 0.05
     for k in ("loss", "loss_iou", "loss_obj", "loss_cls", "loss_l1"):
-        got, want = float(out[k]), float(ref[k])
+        got, want = float(out[k].detach()), float(ref[k].detach())
         print("use_l1", k, got, want)
         assert abs(got - want) <= 1e-4 * max(1.0, abs(want)), (k, got, want)
     assert abs(float(out["loss"]) - float(out0["loss"]) - float(out["loss_l1"])) <= 1e-4 * float(out["loss"])
@@ -586,6 +586,57 @@ def test_warm_yolox_s_bf16_gradients_vs_emulating_oracle():
         assert r <= 1e-2
     allc, allr, worst_rms, worst_cos = _grad_report("warm yolox_s bf16 vs bf16-emulating oracle", grads, emu_grads)
     assert allc >= 0.9995 and worst_cos >= 0.995 and allr <= 2.5e-2    # measured 0.99994 / 0.99981 / 0.0107
+
+
+def test_multi_scale_sessions_are_evicted_and_retraced(monkeypatch):
+    """Multi-scale training: one traced session per input shape, least recently used ones dropped beyond the memory budget
+    (PLYOLO_SESSION_BUDGET).  With a budget of ~nothing every new shape evicts the previous one; coming back to a shape
+    retraces it and gives the same numbers; a backward whose session was evicted in between still runs (autograd holds it)."""
+    g, model = _golden_model("fp32")
+    model.train()
+    gen = torch.Generator().manual_seed(5)
+    batches = {}
+    for size in (64, 96, 128):
+        x = torch.rand(2, 3, size, size, generator=gen) * 255
+        lab = torch.zeros(2, 4, 5)
+        lab[:, :2, 0] = torch.randint(0, int(g["num_classes"]), (2, 2), generator=gen).float()
+        lab[:, :2, 1:3] = (0.3 + 0.4 * torch.rand(2, 2, 2, generator=gen)) * size
+        lab[:, :2, 3:5] = 8 + torch.rand(2, 2, 2, generator=gen) * 0.3 * size
+        batches[size] = (x.to(hu.DEV), lab.to(hu.DEV))
+
+    def step(size):
+        model.zero_grad(set_to_none=True)
+        out = model(*batches[size])
+        out["loss"].backward()
+        torch.cuda.synchronize()
+        return float(out["loss"]), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    ref = {size: step(size) for size in (64, 96, 128)}           # default budget: all three stay resident
+    r = model.runner()
+    assert len(r.sessions) == 3 and all(v.bytes > 0 for v in r.sessions.values())
+    monkeypatch.setenv("PLYOLO_SESSION_BUDGET", "1e-12")
+    r.sessions.clear()
+    for size in (64, 96, 128, 64, 128, 96):
+        loss, grads = step(size)
+        assert len(r.sessions) == 1                               # only the shape just used
+        assert loss == ref[size][0]
+        for n, v in grads.items():
+            assert float((v - ref[size][1][n]).abs().max()) <= 2e-5 * max(float(ref[size][1][n].abs().max()), 1e-6), (size, n)
+    # forward at 64, forward at 96 (evicts the 64 session), THEN the backward of the 64 forward
+    model.zero_grad(set_to_none=True)
+    out_a = model(*batches[64])
+    out_b = model(*batches[96])
+    assert [k[1] for k in r.sessions] == [96]
+    out_a["loss"].backward()
+    torch.cuda.synchronize()
+    for n, p in model.named_parameters():
+        if p.grad is not None:
+            assert float((p.grad - ref[64][1][n]).abs().max()) <= 2e-5 * max(float(ref[64][1][n].abs().max()), 1e-6), n
+    monkeypatch.delenv("PLYOLO_SESSION_BUDGET")
+    # recently used shapes move to the back of the queue
+    r.sessions.clear()
+    for size in (64, 96, 64):
+        step(size)
+    assert [k[1] for k in r.sessions] == [96, 64]
 
 
 def test_stale_forward_is_refused_and_gradients_accumulate():
