@@ -286,22 +286,39 @@ __global__ __launch_bounds__(256) void k_topk(const plyolo_yolox_desc d, const f
   int nc = 0, nboth = 0;
 #pragma unroll
   for (int i = 0; i < 10; ++i) { top_ik[i] = 0ull; top_key[i] = ~0ull; }
-  for (int a = tid; a < d.A; a += 256) {
-    if (!cnd[a]) continue;
-    ++nc;
-    const float iou = irow[a], cost = crow[a];   // computed once by k_prep
-    if (iou > 0.f) {
-      unsigned long long x = iou_key(iou, a);
+  // The scan is a chain of dependent round trips when written "flag, then (if set) the two values": 33 anchors per thread x two
+  // latencies = the whole 50 us of this kernel.  The flag and both values of TKB anchors are requested together instead (the
+  // [G, A] rows hold stale bytes for non-candidates -- allocated, never used: the flag decides).
+  constexpr int TKB = 4;
+  for (int a0 = tid; a0 < d.A; a0 += 256 * TKB) {
+    uint8_t cf[TKB];
+    float iv[TKB], cv[TKB];
 #pragma unroll
-      for (int i = 0; i < 10; ++i)
-        if (x > top_ik[i]) { const unsigned long long t = top_ik[i]; top_ik[i] = x; x = t; }
+    for (int j = 0; j < TKB; ++j) {
+      const int a = a0 + j * 256, ac = a < d.A ? a : d.A - 1;
+      cf[j] = a < d.A ? cnd[ac] : (uint8_t)0;
+      iv[j] = irow[ac];
+      cv[j] = crow[ac];
     }
-    if (cost < 100000.0f) {
-      ++nboth;
-      unsigned long long k = cost_key(cost, a);
 #pragma unroll
-      for (int i = 0; i < 10; ++i)
-        if (k < top_key[i]) { const unsigned long long t = top_key[i]; top_key[i] = k; k = t; }
+    for (int j = 0; j < TKB; ++j) {
+      if (!cf[j]) continue;
+      const int a = a0 + j * 256;
+      ++nc;
+      const float iou = iv[j], cost = cv[j];   // computed once by k_prep
+      if (iou > 0.f) {
+        unsigned long long x = iou_key(iou, a);
+#pragma unroll
+        for (int i = 0; i < 10; ++i)
+          if (x > top_ik[i]) { const unsigned long long t = top_ik[i]; top_ik[i] = x; x = t; }
+      }
+      if (cost < 100000.0f) {
+        ++nboth;
+        unsigned long long k = cost_key(cost, a);
+#pragma unroll
+        for (int i = 0; i < 10; ++i)
+          if (k < top_key[i]) { const unsigned long long t = top_key[i]; top_key[i] = k; k = t; }
+      }
     }
   }
   {
