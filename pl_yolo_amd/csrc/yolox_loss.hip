@@ -15,9 +15,9 @@
 //   k_topk    one workgroup per (image, GT): streams the candidates once, keeps the
 //             10 largest IoUs and the 10 cheapest (cost, anchor) pairs per thread,
 //             merges them with wavefront reductions, derives dynamic k and votes
-//   k_resolve one thread per anchor: 0 votes -> background, 1 vote -> that GT,
-//             >1 votes -> argmin over ALL GTs of the recomputed cost (lowest GT wins ties)
-//   k_loss    per-anchor loss terms, block partials;  k_final: fixed-order sum
+//   k_loss    one thread per anchor: vote resolution (0 votes -> background, 1 vote -> that GT, >1 votes -> argmin over
+//             ALL GTs of the pair cost, lowest GT wins ties), then the per-anchor loss terms and block partials;
+//   k_final   fixed-order sum
 //   k_bwd     d(loss)/d(raw) for every (anchor, channel), coalesced
 // Tie rule: equal costs are ordered by lowest anchor index (the reference's
 // torch.sort is unstable there).
@@ -208,6 +208,7 @@ __global__ __launch_bounds__(PREP_T) void k_prep(const plyolo_yolox_desc d, cons
   if (live && half == 0) {
     *(f32x4*)(ws.dec + ba * 4) = f32x4{dec[0], dec[1], dec[2], dec[3]};
     ws.cand[ba] = cand ? 1 : 0;
+    ws.cnt[ba] = 0;      // votes of k_topk (every anchor belongs to exactly one workgroup here: no separate fill launch)
   }
   // class-independent BCE term: this half's classes (sequential partial sums; S = first half + second half)
   const int c_mid = (d.C + 1) / 2, c_lo = half ? c_mid : 0, c_hi = half ? d.C : c_mid;
@@ -402,35 +403,6 @@ __global__ __launch_bounds__(256) void k_topk(const plyolo_yolox_desc d, const f
   }
 }
 
-__global__ void k_resolve(const plyolo_yolox_desc d, const float* raw, const float* labels, LossWs ws, uint8_t* fg, int32_t* mgt,
-                          float* miou) {
-  const int b = blockIdx.y;
-  const int a = blockIdx.x * blockDim.x + threadIdx.x;
-  if (a >= d.A) return;
-  const size_t ba = (size_t)b * d.A + a;
-  const int c = ws.cnt[ba];
-  if (c == 0) {
-    fg[ba] = 0;
-    mgt[ba] = -1;
-    miou[ba] = 0.f;
-    return;
-  }
-  int g = ws.lastg[ba];
-  if (c > 1) {   // several GTs voted for this anchor: it goes to the cheapest one (first minimum)
-    const int G = ws.G[b];
-    float best = INFINITY;
-    g = 0;
-    for (int gg = 0; gg < G; ++gg) {
-      const float cost = ws.costm[((size_t)b * d.M + gg) * d.A + a];
-      if (cost < best) { best = cost; g = gg; }
-    }
-  }
-  const float iou = ws.ioum[((size_t)b * d.M + g) * d.A + a];
-  fg[ba] = 1;
-  mgt[ba] = g;
-  miou[ba] = iou;
-}
-
 // IOUloss(loss_type="giou") of iou_loss.py:13-43 (note the (area_c - area_i)/area_c penalty) and its gradient
 DEVINL float giou_loss(const float* p, const float* t, float* grad /* d loss / d(cx,cy,w,h) or null */) {
   const float plx = p[0] - p[2] / 2, ply = p[1] - p[3] / 2, phx = p[0] + p[2] / 2, phy = p[1] + p[3] / 2;
@@ -481,19 +453,49 @@ DEVINL void l1_target(const float* gt_box, float xs, float ys, float st, float* 
   t[3] = logf(gt_box[3] / st + 1e-8f);
 }
 
+// One thread per anchor.  First the vote resolution (0 votes -> background, 1 vote -> that GT, > 1 votes -> argmin over ALL GTs of
+// the pair cost, lowest GT wins ties), then the anchor's loss terms and the block partials.  (Round 3: resolution and loss were
+// two launches; the class term walked the foreground lanes of a wave one after the other through THREE dependent round trips each
+// -- matched GT -> label row -> logits; now every foreground lane fetches its own metadata up front and the rows of two
+// foreground anchors are in flight per step.)
 __global__ __launch_bounds__(256) void k_loss(const plyolo_yolox_desc d, const float* raw, const float* labels, LossWs ws,
-                                              const uint8_t* fg, const int32_t* mgt, const float* miou) {
+                                              uint8_t* fg, int32_t* mgt, float* miou) {
   const size_t total = (size_t)d.B * d.A;
   const int nch = 5 + d.C;
   float s_iou = 0.f, s_obj = 0.f, s_cls = 0.f, s_fg = 0.f, s_l1 = 0.f;
   const size_t ba = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool f = false;
+  int cg = 0;          // class of the matched GT (foreground lanes)
+  float io = 0.f;      // matched IoU
+  unsigned rrow = 0u;  // level-major row of this anchor (B*A*(5+C) < 2^32 is checked by the backward; rows fit 32 bits)
   if (ba < total) {
     const int b = (int)(ba / d.A), a = (int)(ba - (size_t)b * d.A);
-    const float* r = raw + raw_row(d, b, a) * nch;
-    const bool f = fg[ba] != 0;
-    s_obj = bce_logits(r[4], f ? 1.0f : 0.0f);
+    rrow = (unsigned)raw_row(d, b, a);
+    const float* r = raw + (size_t)rrow * nch;
+    const float obj_logit = r[4];
+    const int c = ws.cnt[ba];
+    int g = -1;
+    if (c != 0) {
+      g = ws.lastg[ba];
+      if (c > 1) {   // several GTs voted for this anchor: it goes to the cheapest one (first minimum)
+        const int G = ws.G[b];
+        float best = INFINITY;
+        g = 0;
+        for (int gg = 0; gg < G; ++gg) {
+          const float cost = ws.costm[((size_t)b * d.M + gg) * d.A + a];
+          if (cost < best) { best = cost; g = gg; }
+        }
+      }
+      io = ws.ioum[((size_t)b * d.M + g) * d.A + a];
+      f = true;
+    }
+    fg[ba] = f ? 1 : 0;
+    mgt[ba] = g;
+    miou[ba] = io;
+    s_obj = bce_logits(obj_logit, f ? 1.0f : 0.0f);
     if (f) {
-      const float* lg = labels + ((size_t)b * d.M + mgt[ba]) * 5;
+      const float* lg = labels + ((size_t)b * d.M + g) * 5;
+      cg = (int)lg[0];
       s_fg = 1.f;
       s_iou = giou_loss(ws.dec + ba * 4, lg + 1, nullptr);
       if (d.use_l1) {   // nn.L1Loss(reduction="none") of the raw box outputs against get_l1_type (yolox_loss.py:157-158)
@@ -508,19 +510,23 @@ __global__ __launch_bounds__(256) void k_loss(const plyolo_yolox_desc d, const f
     // class term of the (rare) foreground anchors: the whole wave walks the 80 logits of each foreground
     // lane together (coalesced row read, 2 steps) instead of one lane looping 80 times while 63 idle
     const int lane = threadIdx.x & 63;
-    const size_t wave_ba0 = ba - lane;
-    unsigned long long m = __ballot(ba < total && fg[ba < total ? ba : 0] != 0);
+    unsigned long long m = __ballot(f);
     while (m) {
-      const int src = __ffsll((long long)m) - 1;
+      const int s0 = __ffsll((long long)m) - 1;
       m &= m - 1;
-      const size_t fba = wave_ba0 + src;
-      const int fb = (int)(fba / d.A);
-      const float* fr = raw + raw_row(d, fb, (int)(fba - (size_t)fb * d.A)) * nch;
-      const float* lg = labels + ((size_t)fb * d.M + mgt[fba]) * 5;
-      const int cg = (int)lg[0];
-      const float io = miou[fba];
+      const bool two = m != 0ull;
+      const int s1 = two ? __ffsll((long long)m) - 1 : s0;
+      if (two) m &= m - 1;
+      const float* fr0 = raw + (size_t)__shfl(rrow, s0) * nch;
+      const float* fr1 = raw + (size_t)__shfl(rrow, s1) * nch;
+      const int cg0 = __shfl(cg, s0), cg1 = __shfl(cg, s1);
+      const float io0 = __shfl(io, s0), io1 = __shfl(io, s1);
       float part = 0.f;
-      for (int c = lane; c < d.C; c += 64) part += bce_logits(fr[5 + c], c == cg ? io : 0.0f);
+      for (int c = lane; c < d.C; c += 64) {
+        const float x0 = fr0[5 + c], x1 = fr1[5 + c];      // both rows requested before either is used
+        part += bce_logits(x0, c == cg0 ? io0 : 0.0f);
+        if (two) part += bce_logits(x1, c == cg1 ? io1 : 0.0f);
+      }
       s_cls += part;   // every lane carries a share; the block reduction below sums them all
     }
   }
@@ -795,15 +801,12 @@ int plyolo_yolox_loss_fwd(const plyolo_yolox_desc* dp, const float* raw, const f
   const int nblk = (int)((BA + 255) / 256);
   plyolo::annotate("yolox_loss_fwd", 0.0, (double)BA * (5 + d.C) * 4.0 * 2.0);
   return submit(stream, [=](hipStream_t s) -> hipError_t {
-    hipError_t e = plyolo::fill_async(ws.cnt, 0, BA * 4, s);
-    if (e != hipSuccess) return e;
     int nchunk = 0;
     for (int l = 0; l < d.nlevels; ++l) nchunk += cdiv(d.lvl_h[l] * d.lvl_w[l], PREP_A);
     const size_t prep_lds = ((size_t)PREP_A * (5 + d.C) + (size_t)d.M * 5 + 2 * PREP_A) * 4;
     if (hipError_t ea = plyolo::ensure_dynamic_lds((const void*)k_prep, prep_lds); ea != hipSuccess) return ea;
     hipLaunchKernelGGL(k_prep, dim3(nchunk, d.B), dim3(PREP_T), prep_lds, s, d, raw, labels, ws);
     hipLaunchKernelGGL(k_topk, dim3(d.M, d.B), dim3(256), 0, s, d, raw, labels, ws);
-    hipLaunchKernelGGL(k_resolve, dim3(cdiv(d.A, 256), d.B), dim3(256), 0, s, d, raw, labels, ws, fg, matched_gt, matched_iou);
     hipLaunchKernelGGL(k_loss, dim3(nblk), dim3(256), 0, s, d, raw, labels, ws, fg, matched_gt, matched_iou);
     hipLaunchKernelGGL(k_final, dim3(1), dim3(256), 0, s, nblk, d.B, ws, losses);
     return hipGetLastError();
