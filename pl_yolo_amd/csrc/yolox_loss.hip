@@ -131,10 +131,17 @@ __global__ __launch_bounds__(PREP_T) void k_prep(const plyolo_yolox_desc d, cons
   const int hw = d.lvl_h[l] * d.lvl_w[l];
   const int f0 = chunk * PREP_A, n = min(PREP_A, hw - f0);
   const float* src = raw + ((size_t)d.lvl_row[l] + (size_t)b * hw + f0) * nch;
+  // the image's label rows (M <= MAXM = 256: at most 5 values per thread) are requested first and ride the same round trip as the tile
+  float lv[(MAXM * 5 + PREP_T - 1) / PREP_T];
+#pragma unroll
+  for (int k = 0; k < (MAXM * 5 + PREP_T - 1) / PREP_T; ++k) {
+    const int i = tid + k * PREP_T;
+    lv[k] = i < d.M * 5 ? labels[(size_t)b * d.M * 5 + i] : 0.f;
+  }
   {
     // batched copy: BATCH loads in flight per thread before the first LDS store (a load -> store loop
     // serialises the round trips), 16-byte vectors when the block of rows is 16-byte aligned
-    constexpr int BATCH = 4;
+    constexpr int BATCH = 12;   // a full 128 x 85 tile is 10.6 vectors per thread: ONE round trip (4 -> three of them per workgroup)
     const int total = n * nch;
     if ((((size_t)src) & 15) == 0) {
       const int nv = total >> 2;
@@ -170,7 +177,11 @@ __global__ __launch_bounds__(PREP_T) void k_prep(const plyolo_yolox_desc d, cons
       }
     }
   }
-  for (int i = tid; i < d.M * 5; i += PREP_T) lab[i] = labels[(size_t)b * d.M * 5 + i];
+#pragma unroll
+  for (int k = 0; k < (MAXM * 5 + PREP_T - 1) / PREP_T; ++k) {
+    const int i = tid + k * PREP_T;
+    if (i < d.M * 5) lab[i] = lv[k];
+  }
   if (tid == 0) sG = 0;
   __syncthreads();
   {
