@@ -565,20 +565,19 @@ __global__ void nchw_to_nhwc_kernel(int N, int H, int W, int C, const float* in,
 // or a flat launch planned by plyolo_pack_plan (entry i owns workgroups [blk0, blk0 + nblk): slices in proportion to its size)
 DEVINL void pack_block(const plyolo_pack_entry* table, int n_flat, int* ent, int* slice, int* nslice) {
   if (n_flat <= 0) { *ent = blockIdx.x; *slice = blockIdx.y; *nslice = gridDim.y; return; }
-  __shared__ int s_e;
-  if (threadIdx.x == 0) {
-    int lo = 0, hi = n_flat - 1;
-    const int b = (int)blockIdx.x;
-    while (lo < hi) {           // last entry with blk0 <= b
-      const int mid = (lo + hi + 1) >> 1;
-      if (table[mid].blk0 <= b) lo = mid; else hi = mid - 1;
-    }
-    s_e = lo;
-  }
+  // last entry with blk0 <= blockIdx.x.  One thread bisecting the table in global memory was ~7 DEPENDENT round trips in front of
+  // every workgroup's work (4400 workgroups in two rounds: a third of the 35 us launch); here the starts are fetched by all
+  // threads at once -- one round trip -- and counted
+  __shared__ int s_cnt;
+  if (threadIdx.x == 0) s_cnt = 0;
   __syncthreads();
-  *ent = s_e;
-  *slice = (int)blockIdx.x - table[s_e].blk0;
-  *nslice = table[s_e].nblk;
+  const int b = (int)blockIdx.x;
+  int below = 0;
+  for (int i = threadIdx.x; i < n_flat; i += blockDim.x) below += table[i].blk0 <= b ? 1 : 0;
+  if (below) atomicAdd(&s_cnt, below);
+  __syncthreads();
+  *ent = s_cnt - 1;            // blk0 is increasing and table[0].blk0 == 0
+  *slice = *nslice = -1;       // flat launch: the caller derives them from the entry it loads anyway (no extra round trip)
 }
 
 template <typename T>
@@ -586,6 +585,7 @@ __global__ void pack_weights_kernel(const plyolo_pack_entry* table, int n_flat) 
   int ent, slice, nslice;
   pack_block(table, n_flat, &ent, &slice, &nslice);
   const plyolo_pack_entry e = table[ent];
+  if (nslice < 0) { slice = (int)blockIdx.x - e.blk0; nslice = e.nblk; }
   const int taps = e.ksize * e.ksize;
   const int nf = taps * e.Cout * e.Cin_p;
   T* wp = (T*)e.wp;
@@ -708,6 +708,7 @@ __global__ void unpack_wgrads_kernel(const plyolo_pack_entry* table, int accumul
   int ent, slice, nslice;
   pack_block(table, n_flat, &ent, &slice, &nslice);
   const plyolo_pack_entry e = table[ent];
+  if (nslice < 0) { slice = (int)blockIdx.x - e.blk0; nslice = e.nblk; }
   if (!e.dw) return;
   const int taps = e.ksize * e.ksize;
   // one thread per (co, ci): the slab reads are coalesced along ci for every tap, and the thread's taps are
