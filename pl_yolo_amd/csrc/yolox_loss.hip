@@ -10,8 +10,8 @@
 //   bboxes_iou / IOUloss(giou)  models/layers/losses/iou_loss.py:391-414 / :7-50
 //
 // Structure (no [G, N_c, C] tensors are ever materialised, no host syncs):
-//   k_prep    one thread per anchor: decode, candidate mask, and for candidates the
-//             class-independent part of the BCE cost  S_a = sum_c -log(1-p_ac)
+//   k_prep    one workgroup per 128 anchors: decode, candidate mask; the candidates' class-independent part of the BCE
+//             cost  S_a = sum_c -log(1-p_ac)  and their pair costs / IoUs against every GT, dealt out over all threads
 //   k_topk    one workgroup per (image, GT): streams the candidates once, keeps the
 //             10 largest IoUs and the 10 cheapest (cost, anchor) pairs per thread,
 //             merges them with wavefront reductions, derives dynamic k and votes
@@ -27,7 +27,6 @@ namespace {
 
 struct LossWs {
   float* dec;      // [B,A,4]
-  float* S;        // [B,A]
   uint8_t* cand;   // [B,A]
   int* cnt;        // [B,A]
   int* lastg;      // [B,A]
@@ -117,8 +116,11 @@ __global__ __launch_bounds__(PREP_T) void k_prep(const plyolo_yolox_desc d, cons
   const int nch = 5 + d.C;
   float* rows = prep_smem;                 // [PREP_A][nch]
   float* lab = prep_smem + PREP_A * nch;   // [M][5]
-  float* spart = lab + d.M * 5;            // [2][PREP_A] partial class sums of the two halves
-  __shared__ int sG;
+  float* spart = lab + d.M * 5;            // [PREP_A][4] partial class sums of the candidates (four class quarters)
+  float* sgeo = spart + 4 * PREP_A;        // [PREP_A][8] candidates: decoded box, anchor centre
+  int* clist = (int*)(sgeo + 8 * PREP_A);  // [PREP_A] candidate anchors of this tile
+  int* smask = clist + PREP_A;             // [PREP_T] per-thread "inside some GT box / centre region" of its half of the GTs
+  __shared__ int sG, s_nc;
   const int b = blockIdx.y, tid = threadIdx.x;
   // level and chunk of this workgroup
   int l = 0, chunk = blockIdx.x;
@@ -197,56 +199,83 @@ __global__ __launch_bounds__(PREP_T) void k_prep(const plyolo_yolox_desc d, cons
   if (blockIdx.x == 0 && tid == 0) ws.G[b] = G;
   const int la = tid & (PREP_A - 1), half = tid / PREP_A;   // anchor of this thread inside the tile, which half of the work
   const bool live = la < n;
-  const int a = d.lvl_off[l] + f0 + la;
-  const size_t ba = (size_t)b * d.A + (live ? a : d.lvl_off[l] + f0);
-  float* r = rows + (live ? la : 0) * nch;
-  float xs, ys, st;
-  anchor_geom(d, live ? a : d.lvl_off[l] + f0, &xs, &ys, &st);
-  float dec[4];
-  dec[0] = (r[0] + xs) * st;
-  dec[1] = (r[1] + ys) * st;
-  dec[2] = expf(r[2]) * st;
-  dec[3] = expf(r[3]) * st;
+  const int fa = f0 + (live ? la : 0), a = d.lvl_off[l] + fa;
+  const size_t ba = (size_t)b * d.A + a;
+  const float* r = rows + (live ? la : 0) * nch;
+  // one level per workgroup: the stride is uniform; grid quirk kept verbatim (yolox_loss.py:198-200), see anchor_geom
+  const float st = (float)d.lvl_stride[l];
+  const float xs = (float)(fa % d.lvl_h[l]), ys = (float)(fa / d.lvl_h[l]);
   const float xc = xs * st + 0.5f * st, yc = ys * st + 0.5f * st;
-  bool any_box = false, any_ctr = false;
-  for (int g = 0; g < G; ++g) {
+  // candidate test: the two threads of an anchor split the GTs
+  bool any = false;
+  for (int g = half; g < G; g += 2) {
     bool ib, ic;
     in_masks(lab + g * 5 + 1, xc, yc, st, &ib, &ic);
-    any_box |= ib;
-    any_ctr |= ic;
+    any |= ib | ic;
   }
-  const bool cand = live && (any_box || any_ctr);
+  smask[tid] = any ? 1 : 0;
+  if (tid == 0) s_nc = 0;
+  __syncthreads();
+  const bool cand = live && (smask[la] | smask[PREP_A + la]) != 0;
   if (live && half == 0) {
-    *(f32x4*)(ws.dec + ba * 4) = f32x4{dec[0], dec[1], dec[2], dec[3]};
+    const float d0 = (r[0] + xs) * st, d1 = (r[1] + ys) * st, d2 = expf(r[2]) * st, d3 = expf(r[3]) * st;
+    *(f32x4*)(ws.dec + ba * 4) = f32x4{d0, d1, d2, d3};
     ws.cand[ba] = cand ? 1 : 0;
     ws.cnt[ba] = 0;      // votes of k_topk (every anchor belongs to exactly one workgroup here: no separate fill launch)
-  }
-  // class-independent BCE term: this half's classes (sequential partial sums; S = first half + second half)
-  const int c_mid = (d.C + 1) / 2, c_lo = half ? c_mid : 0, c_hi = half ? d.C : c_mid;
-  float Sp = 0.f;
-  if (cand) {
-    const float so = sig_fast(r[4]);
-    for (int c = c_lo; c < c_hi; ++c) {
-      const float p = __fsqrt_rn(sig_fast(r[5 + c]) * so);
-      const float t0 = -fmaxf(__logf(1.0f - p), -100.0f);
-      const float t1 = -fmaxf(__logf(p), -100.0f);
-      Sp += t0;
-      r[5 + c] = t1 - t0;   // the raw class logit of this anchor's LDS row is not needed again (each half owns its classes)
+    if (cand) {
+      float* ge = sgeo + la * 8;
+      ge[0] = d0; ge[1] = d1; ge[2] = d2; ge[3] = d3; ge[4] = xc; ge[5] = yc;
+      clist[atomicAdd(&s_nc, 1)] = la;     // the ORDER of the list only decides which thread works on which candidate
     }
   }
-  spart[half * PREP_A + la] = Sp;
   __syncthreads();
-  const float S = spart[la] + spart[PREP_A + la];
-  if (cand) {
-    for (int g = half; g < G; g += 2) {     // this half's GTs
-      float iou;
-      const float cost = pair_cost(r + 5, dec, S, lab + g * 5, xc, yc, st, &iou);
-      const size_t o = ((size_t)b * d.M + g) * d.A + a;
-      ws.costm[o] = cost;
-      ws.ioum[o] = iou;
+  const int nc = s_nc;
+  // Candidates are a third of the anchors and come in clusters: with one (half-)thread per anchor most lanes of a wave sat idle
+  // through 40 classes x 5 transcendentals and 15 pair costs.  The work is dealt out over the whole workgroup instead:
+  //   items (candidate, quarter of the classes): the class-independent BCE term  S_a = sum_c -log(1-p_ac), in four partial sums;
+  //   items (GT, candidate): pair cost and IoU.
+  const int csz = (d.C + 3) / 4;
+  for (int item = tid; item < nc * 4; item += PREP_T) {
+    float* r2 = rows + clist[item >> 2] * nch;
+    const int c_lo = (item & 3) * csz, c_hi = min(d.C, c_lo + csz);
+    // p = sqrt(sig(cls) * sig(obj)) with sig(x) = 1 / (1 + e^-x):  p = rsqrt((1 + e^-cls) * (1 + e^-obj)) and
+    // -log p = (log(1 + e^-cls) + log(1 + e^-obj)) / 2 -- four hardware-rate transcendentals per class (exp, log, rsq, log) and
+    // no division / square-root refinement sequences; the obj factors are per anchor.  Like the previous form this is the
+    // COST only (discrete choices, ~1e-6 relative), never the loss value.
+    const float eo = 1.0f + __expf(-r2[4]);
+    const float lo = __logf(eo);
+    float Sp = 0.f;
+    for (int c = c_lo; c < c_hi; ++c) {
+      const float ec = 1.0f + __expf(-r2[5 + c]);
+      const float p = __builtin_amdgcn_rsqf(ec * eo);
+      const float t0 = -fmaxf(__logf(1.0f - p), -100.0f);
+      const float t1 = fminf(0.5f * (__logf(ec) + lo), 100.0f);
+      Sp += t0;
+      r2[5 + c] = t1 - t0;   // the raw class logit of this LDS row is not needed again (every item owns its classes)
+    }
+    spart[item] = Sp;
+  }
+  __syncthreads();
+  if (nc > 0) {
+    // a thread keeps ONE candidate (box, centre, S, row in registers) and walks every nsplit-th GT
+    const int nsplit = PREP_T / nc, ci = tid % nc, gs = tid / nc;
+    if (gs < nsplit) {
+      const int la2 = clist[ci];
+      const float* ge = sgeo + la2 * 8;
+      const float dec2[4] = {ge[0], ge[1], ge[2], ge[3]};
+      const float xc2 = ge[4], yc2 = ge[5];
+      const float S = ((spart[ci * 4] + spart[ci * 4 + 1]) + spart[ci * 4 + 2]) + spart[ci * 4 + 3];   // fixed order
+      const float* delta = rows + la2 * nch + 5;
+      float* crow = ws.costm + (size_t)b * d.M * d.A + (d.lvl_off[l] + f0 + la2);
+      float* irow = ws.ioum + (size_t)b * d.M * d.A + (d.lvl_off[l] + f0 + la2);
+      for (int g = gs; g < G; g += nsplit) {
+        float iou;
+        const float cost = pair_cost(delta, dec2, S, lab + g * 5, xc2, yc2, st, &iou);
+        crow[(size_t)g * d.A] = cost;
+        irow[(size_t)g * d.A] = iou;
+      }
     }
   }
-  if (live && half == 0) ws.S[ba] = S;
 }
 
 DEVINL unsigned orderable(float c) {
@@ -775,7 +804,6 @@ LossWs carve(const plyolo_yolox_desc* d, void* workspace, size_t* used) {
   size_t off = 0;
   LossWs ws;
   ws.dec = (float*)(p + off); off += align256(BA * 16);
-  ws.S = (float*)(p + off); off += align256(BA * 4);
   ws.cnt = (int*)(p + off); off += align256(BA * 4);
   ws.lastg = (int*)(p + off); off += align256(BA * 4);
   ws.cand = (uint8_t*)(p + off); off += align256(BA);
@@ -814,7 +842,7 @@ int plyolo_yolox_loss_fwd(const plyolo_yolox_desc* dp, const float* raw, const f
   return submit(stream, [=](hipStream_t s) -> hipError_t {
     int nchunk = 0;
     for (int l = 0; l < d.nlevels; ++l) nchunk += cdiv(d.lvl_h[l] * d.lvl_w[l], PREP_A);
-    const size_t prep_lds = ((size_t)PREP_A * (5 + d.C) + (size_t)d.M * 5 + 2 * PREP_A) * 4;
+    const size_t prep_lds = ((size_t)PREP_A * (5 + d.C) + (size_t)d.M * 5 + (4 + 8 + 1) * PREP_A + PREP_T) * 4;
     if (hipError_t ea = plyolo::ensure_dynamic_lds((const void*)k_prep, prep_lds); ea != hipSuccess) return ea;
     hipLaunchKernelGGL(k_prep, dim3(nchunk, d.B), dim3(PREP_T), prep_lds, s, d, raw, labels, ws);
     hipLaunchKernelGGL(k_topk, dim3(d.M, d.B), dim3(256), 0, s, d, raw, labels, ws);
