@@ -597,6 +597,18 @@ __global__ void pack_weights_kernel(const plyolo_pack_entry* table, int n_flat) 
     // one 16-byte fragment chunk (8 consecutive j) per thread.  fwd chunk (co, kb, h, t): ci = kb*16 + h*8 + j
     const int nck = nkb_f * 2;
     const int nfw = e.Cout * nck * taps;
+    const int c8 = (e.Cout + 7) / 8;
+    const int ndg = wpd ? e.Cin_p * c8 * taps : 0;
+    // A workgroup owns ~256 chunks of either pack (plyolo_pack_plan: 2048 weights), i.e. ONE chunk of each per thread: the eight
+    // values of the data-gradient chunk are requested before the forward chunk is converted and stored, so the two chunks cost
+    // one round trip instead of two (the launch is a chain of round trips: table, entry, forward chunk, data-gradient chunk)
+    const int idx_d0 = slice * blockDim.x + threadIdx.x;
+    float fd0[8];
+    {
+      const int t = idx_d0 % taps, ci = (idx_d0 / taps) % e.Cin_p, co0 = (idx_d0 / (taps * e.Cin_p)) * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) fd0[j] = (idx_d0 < ndg && ci < e.Cin && co0 + j < e.Cout) ? e.w[((size_t)(co0 + j) * e.Cin + ci) * taps + t] : 0.f;
+    }
     for (int idx = slice * blockDim.x + threadIdx.x; idx < nfw; idx += nslice * blockDim.x) {
       const int t = idx % taps, ck = (idx / taps) % nck, co = idx / (taps * nck);
       const int kb = ck >> 1, h = ck & 1, ci0 = kb * 16 + h * 8, cot = e.co_off + co;
@@ -611,14 +623,17 @@ __global__ void pack_weights_kernel(const plyolo_pack_entry* table, int n_flat) 
     }
     if (wpd) {
       // dgrad chunk (ci, kbd, h, t): cot = kbd*16 + h*8 + j, restricted to this entry's rows
-      const int c8 = (e.Cout + 7) / 8;
-      const int ndg = e.Cin_p * c8 * taps;
-      for (int idx = slice * blockDim.x + threadIdx.x; idx < ndg; idx += nslice * blockDim.x) {
+      for (int idx = idx_d0; idx < ndg; idx += nslice * blockDim.x) {
         const int t = idx % taps, ci = (idx / taps) % e.Cin_p, g8 = idx / (taps * e.Cin_p);
         const int co0 = g8 * 8, cot0 = e.co_off + co0;
         float f[8];
+        if (idx == idx_d0) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = (ci < e.Cin && co0 + j < e.Cout) ? e.w[((size_t)(co0 + j) * e.Cin + ci) * taps + t] : 0.f;
+          for (int j = 0; j < 8; ++j) f[j] = fd0[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f[j] = (ci < e.Cin && co0 + j < e.Cout) ? e.w[((size_t)(co0 + j) * e.Cin + ci) * taps + t] : 0.f;
+        }
         u32x4 v;
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = pack2bf(f[2 * j], f[2 * j + 1]);
@@ -721,6 +736,18 @@ __global__ void unpack_wgrads_kernel(const plyolo_pack_entry* table, int accumul
     const int ci = idx % e.Cin, co = idx / e.Cin;
     const float* src = e.dwp + (size_t)(e.co_off + co) * e.Cin_p + ci;
     float* dst = e.dw + (size_t)idx * taps;
+    if (e.nslab == 1 && taps == 9) {
+      // the common case (slabs already folded, 3x3): the nine taps -- and the nine old values when accumulating -- are requested
+      // together; the rolled loop below waited for every tap's round trip in turn (9 of them per thread: most of this launch)
+      float g[9], o[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) g[t] = src[(size_t)t * plane];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) o[t] = accumulate ? dst[t] : 0.f;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) dst[t] = o[t] + (0.f + g[t]);
+      continue;
+    }
     for (int t = 0; t < taps; ++t) {
       float g = 0.f;
       for (int sl = 0; sl < e.nslab; ++sl) g += src[(size_t)sl * slab + (size_t)t * plane];  // fixed order: deterministic
