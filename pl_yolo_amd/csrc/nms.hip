@@ -243,6 +243,14 @@ __global__ __launch_bounds__(64) void k_scan(NmsWs w, int max_det, float* det, i
 // rows of its survivors are OR-ed into the removed-set of the later blocks from LDS, lanes across the words.  Same
 // greedy order, same results.  (Computing the mask itself here, on one CU per image, measured 2x SLOWER than the
 // chip-wide k_mask: 1 M IoU evaluations per image are ~160 us of VALU time for a single CU.)
+// value of lane l (wave-uniform l) as a scalar: v_readlane instead of the LDS-crossbar shuffle, which put ~100 cycles into
+// every step of the scan's dependent chain
+DEVINL unsigned long long readlane_u64(unsigned long long v, int l) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
 __global__ __launch_bounds__(1024) void k_nms_lds(NmsWs w, int max_det, float* det, int* count) {
   const int b = blockIdx.x, tid = threadIdx.x;
   const int n = w.ncand[b];
@@ -250,9 +258,22 @@ __global__ __launch_bounds__(1024) void k_nms_lds(NmsWs w, int max_det, float* d
   const int nb = (n + 63) / 64;
   extern __shared__ __align__(16) unsigned char nms_smem[];
   unsigned long long* smask = (unsigned long long*)nms_smem;              // [n][nb]
-  for (int id = tid; id < n * nb; id += 1024) {
-    const int i = id / nb, cb = id - i * nb;
-    smask[id] = cb >= (i >> 6) ? w.mask[((size_t)b * w.cap + i) * w.words + cb] : 0ull;   // words below the diagonal block were never written
+  // the bit matrix -> LDS, four words per thread in flight (a rolled load -> store loop was 16 dependent round trips in front of
+  // the scan for 1000 candidates); words below the diagonal block were never written: read anyway (allocated), replaced by 0
+  constexpr int CPB = 4;
+  const int total = n * nb;
+  for (int id0 = tid; id0 < total; id0 += 1024 * CPB) {
+    unsigned long long v[CPB];
+#pragma unroll
+    for (int k = 0; k < CPB; ++k) {
+      const int id = min(id0 + k * 1024, total - 1);
+      const int i = id / nb, cb = id - i * nb;
+      const unsigned long long word = w.mask[((size_t)b * w.cap + i) * w.words + cb];
+      v[k] = cb >= (i >> 6) ? word : 0ull;
+    }
+#pragma unroll
+    for (int k = 0; k < CPB; ++k)
+      if (id0 + k * 1024 < total) smask[id0 + k * 1024] = v[k];
   }
   __syncthreads();
   if (tid >= 64) return;
@@ -260,7 +281,7 @@ __global__ __launch_bounds__(1024) void k_nms_lds(NmsWs w, int max_det, float* d
   unsigned long long rem = 0ull;                // lane c: removed bits of block c (nb <= 16 words)
   int kept = 0;
   for (int wd = 0; wd < nb && kept < max_det; ++wd) {
-    unsigned long long remw = __shfl(rem, wd);
+    unsigned long long remw = readlane_u64(rem, wd);
     const int row = wd * 64 + lane;
     const unsigned long long diag = row < n ? smask[(size_t)row * nb + wd] : 0ull;
     const int jn = min(64, n - wd * 64);
@@ -269,7 +290,7 @@ __global__ __launch_bounds__(1024) void k_nms_lds(NmsWs w, int max_det, float* d
       if ((remw >> j) & 1ull) continue;
       keep |= 1ull << j;
       ++kept;
-      remw |= __shfl(diag, j);
+      remw |= readlane_u64(diag, j);
     }
     if ((keep >> lane) & 1ull) {                // survivors of this block -> output rows, in order
       const int pos = kept - __popcll(keep) + __popcll(keep & ((1ull << lane) - 1ull));
