@@ -275,40 +275,63 @@ __global__ __launch_bounds__(1024) void k_nms_lds(NmsWs w, int max_det, float* d
     for (int k = 0; k < CPB; ++k)
       if (id0 + k * 1024 < total) smask[id0 + k * 1024] = v[k];
   }
+  __shared__ unsigned long long s_keep[NMS_LDS_N / 64];   // survivors of every 64-candidate block
+  __shared__ int s_base[NMS_LDS_N / 64];                  // survivors in front of the block
+  if (tid < NMS_LDS_N / 64) { s_keep[tid] = 0ull; s_base[tid] = 0; }
   __syncthreads();
-  if (tid >= 64) return;
-  const int lane = tid;
-  unsigned long long rem = 0ull;                // lane c: removed bits of block c (nb <= 16 words)
-  int kept = 0;
-  for (int wd = 0; wd < nb && kept < max_det; ++wd) {
-    unsigned long long remw = readlane_u64(rem, wd);
-    const int row = wd * 64 + lane;
-    const unsigned long long diag = row < n ? smask[(size_t)row * nb + wd] : 0ull;
-    const int jn = min(64, n - wd * 64);
-    unsigned long long keep = 0ull;
-    for (int j = 0; j < jn && kept < max_det; ++j) {
-      if ((remw >> j) & 1ull) continue;
-      keep |= 1ull << j;
-      ++kept;
-      remw |= readlane_u64(diag, j);
+  if (tid < 64) {
+    const int lane = tid;
+    unsigned long long rem = 0ull;                // lane c: removed bits of block c (nb <= 16 words)
+    int kept = 0;
+    for (int wd = 0; wd < nb && kept < max_det; ++wd) {
+      unsigned long long remw = readlane_u64(rem, wd);
+      const int row = wd * 64 + lane;
+      const unsigned long long diag = row < n ? smask[(size_t)row * nb + wd] : 0ull;
+      const int jn = min(64, n - wd * 64);
+      unsigned long long keep = 0ull;
+      const int before = kept;
+      // walk the candidates that are still alive (one step per SURVIVOR, not per candidate): lowest alive bit -> kept, its
+      // diagonal word removes the ones it suppresses
+      unsigned long long alive = ~remw & (jn == 64 ? ~0ull : ((1ull << jn) - 1ull));
+      while (alive && kept < max_det) {
+        const int j = __ffsll((long long)alive) - 1;
+        keep |= 1ull << j;
+        ++kept;
+        alive &= ~(readlane_u64(diag, j) | (1ull << j));
+      }
+      if (lane == 0) { s_keep[wd] = keep; s_base[wd] = before; }
+      if (lane > wd && lane < nb) {               // their rows suppress candidates of the later blocks (four rows in flight)
+        unsigned long long k2 = keep;
+        while (k2) {
+          int jj[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            jj[q] = k2 ? __ffsll((long long)k2) - 1 : -1;
+            k2 &= k2 - 1ull;      // 0 stays 0
+          }
+          unsigned long long r4[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) r4[q] = smask[(size_t)(wd * 64 + (jj[q] < 0 ? jj[0] : jj[q])) * nb + lane];
+          rem |= (r4[0] | r4[1]) | (r4[2] | r4[3]);
+        }
+      }
     }
-    if ((keep >> lane) & 1ull) {                // survivors of this block -> output rows, in order
-      const int pos = kept - __popcll(keep) + __popcll(keep & ((1ull << lane) - 1ull));
-      const float* src = w.sdet + ((size_t)b * w.cap + row) * 6;
+    if (lane == 0) count[b] = kept;
+  }
+  __syncthreads();
+  // survivors -> output rows, in order, by the whole workgroup at once (copied inside the scan every 64-block waited for its own
+  // round trip to the candidate rows: 16 of them in the one wave's dependent chain)
+  if (tid < n) {
+    const unsigned long long keep = s_keep[tid >> 6];
+    const int lane = tid & 63;
+    if ((keep >> lane) & 1ull) {
+      const int pos = s_base[tid >> 6] + __popcll(keep & ((1ull << lane) - 1ull));
+      const float* src = w.sdet + ((size_t)b * w.cap + tid) * 6;
       float* dst = det + ((size_t)b * max_det + pos) * 6;
 #pragma unroll
       for (int k = 0; k < 6; ++k) dst[k] = src[k];
     }
-    if (lane > wd && lane < nb) {               // their rows suppress candidates of the later blocks
-      unsigned long long k2 = keep;
-      while (k2) {
-        const int j = __ffsll((long long)k2) - 1;
-        k2 &= k2 - 1ull;
-        rem |= smask[(size_t)(wd * 64 + j) * nb + lane];
-      }
-    }
   }
-  if (lane == 0) count[b] = kept;
 }
 
 // ---- evaluation formatting (postprocess.py:95-138): per detection  boxes /= scale (IN PLACE, like the reference),
