@@ -175,36 +175,42 @@ __global__ __launch_bounds__(64) void k_mask(NmsWs w, float thr, int class_agnos
   const int n = w.ncand[b];
   const int nb = (n + 63) / 64;
   const bool vanilla = !class_agnostic && (4 * n > numel_threshold);
-  __shared__ float cb_box[64][4];
-  __shared__ float cb_cls[64];
+  __shared__ __align__(16) float cb_box[64][4];
+  __shared__ float cb_cls[64], cb_area[64];
   const int lane = threadIdx.x;
   for (int t = blockIdx.x; t < nb * nb; t += gridDim.x) {
     const int rb = t / nb, cb = t - rb * nb;
     if (cb < rb) continue;
     const int j0 = cb * 64, i = rb * 64 + lane;
     __syncthreads();
-    if (j0 + lane < n) {
-      const f32x4 v = *(const f32x4*)(w.nbox + ((size_t)b * w.cap + j0 + lane) * 4);
-      cb_box[lane][0] = v[0]; cb_box[lane][1] = v[1]; cb_box[lane][2] = v[2]; cb_box[lane][3] = v[3];
-      cb_cls[lane] = w.sdet[((size_t)b * w.cap + j0 + lane) * 6 + 5];
-    }
+    // the column block's boxes AND this lane's own row are requested together (one round trip; the row used to wait behind the barrier)
+    const int jc = j0 + lane < n ? j0 + lane : n - 1, ic = i < n ? i : n - 1;
+    const f32x4 v = *(const f32x4*)(w.nbox + ((size_t)b * w.cap + jc) * 4);
+    const float vcls = w.sdet[((size_t)b * w.cap + jc) * 6 + 5];
+    const f32x4 me = *(const f32x4*)(w.nbox + ((size_t)b * w.cap + ic) * 4);
+    const float my_cls = w.sdet[((size_t)b * w.cap + ic) * 6 + 5];
+    *(f32x4*)cb_box[lane] = v;
+    cb_cls[lane] = vcls;
+    cb_area[lane] = (v[2] - v[0]) * (v[3] - v[1]);
     __syncthreads();
     if (i < n) {
-      const f32x4 me = *(const f32x4*)(w.nbox + ((size_t)b * w.cap + i) * 4);
-      const float my_cls = w.sdet[((size_t)b * w.cap + i) * 6 + 5];
       const float my_area = (me[2] - me[0]) * (me[3] - me[1]);
       unsigned long long bits = 0ull;
       const int jn = min(64, n - j0);
-      for (int j = (rb == cb ? lane + 1 : 0); j < jn; ++j) {
-        const float xx1 = fmaxf(me[0], cb_box[j][0]), yy1 = fmaxf(me[1], cb_box[j][1]);
-        const float xx2 = fminf(me[2], cb_box[j][2]), yy2 = fminf(me[3], cb_box[j][3]);
+      // every lane walks all columns of the block (uniform trip count: the reads of four columns are in flight together);
+      // the diagonal block keeps only j > lane
+#pragma unroll 4
+      for (int j = 0; j < jn; ++j) {
+        const f32x4 o = *(const f32x4*)cb_box[j];
+        const float xx1 = fmaxf(me[0], o[0]), yy1 = fmaxf(me[1], o[1]);
+        const float xx2 = fminf(me[2], o[2]), yy2 = fminf(me[3], o[3]);
         const float iw = fmaxf(0.0f, xx2 - xx1), ih = fmaxf(0.0f, yy2 - yy1);
         const float inter = iw * ih;
-        const float area_j = (cb_box[j][2] - cb_box[j][0]) * (cb_box[j][3] - cb_box[j][1]);
-        const float ovr = inter / (my_area + area_j - inter);
+        const float ovr = inter / (my_area + cb_area[j] - inter);
         const bool same = !vanilla || (cb_cls[j] == my_cls);
         if (same && ovr > thr) bits |= 1ull << j;
       }
+      if (rb == cb) bits &= lane == 63 ? 0ull : ~0ull << (lane + 1);
       w.mask[((size_t)b * w.cap + i) * w.words + cb] = bits;
     }
   }
