@@ -9,11 +9,14 @@
 //
 //   k_v7_cand    one workgroup per image: the (level, offset class, anchor, GT) slots of
 //                find_3_positive are visited IN THE REFERENCE'S ORDER and compacted with a
-//                ballot prefix, so candidate n here is candidate n there; decode + the
-//                class-independent part of the cost per candidate
-//   k_v7_match   one workgroup per image, one wave per GT: IoU/cost rows, dynamic k from the ten
-//                largest IoUs, the k cheapest candidates (ties -> lowest index), conflict
-//                resolution, ordered list of matched (cell, GT) entries, objectness targets
+//                ballot prefix, so candidate n here is candidate n there (the only part that needs the order)
+//   k_v7_cdec    one thread per candidate, whole chip: decode + the class-independent part of the cost
+//   k_v7_rows    one wave per (image, GT), whole chip: IoU/cost rows in LDS, dynamic k from the ten
+//                largest IoUs, votes for the k cheapest candidates (ties -> lowest index)
+//   k_v7_match   one workgroup per image: conflict resolution, ordered list of matched (cell, GT)
+//                entries, objectness targets
+//   (round 3: the candidate and the per-GT stages ran inside the per-image workgroups -- 32 workgroups on 256 CUs, 80 classes of
+//    libm arithmetic per candidate in a serial loop, every selection round re-reading its row from global memory: 395 + 275 us)
 //   k_v7_obj / k_v7_pos / k_v7_final    the three loss terms (deterministic block partials)
 //   k_v7_bwd_obj / k_v7_bwd_pos         d loss / d raw
 // These are latency-bound integer/compare kernels; no MFMA.
@@ -33,6 +36,7 @@ struct V7Ws {
   int* cand;      // [B][cap][5]  level, a, gj, gi, t
   float* cbox;    // [B][cap][4]  decoded x1,y1,x2,y2 (pixels)
   float* cS;      // [B][cap]     sum_c BCE(logit(y_c), 0)
+  long long* coff; // [B][cap]    element offset of the candidate's (cell, anchor) prediction inside raw
   float* rows;    // [B][4][2][cap]  per-wave IoU / cost rows
   int* selcnt;    // [B][cap]
   int* selgt;     // [B][cap]
@@ -145,28 +149,47 @@ __global__ __launch_bounds__(256) void k_v7_cand(const plyolo_yolov7_desc d, con
       const size_t o = (size_t)b * cap + pos;
       int* c = ws.cand + o * 5;
       c[0] = l; c[1] = a; c[2] = gj; c[3] = gi; c[4] = t;
-      const float* p = cell_ptr(d, raw, b, l, a, gj, gi);
-      float cx, cy, bw, bh;
-      {
-#pragma clang fp contract(off)
-        cx = (sig(p[0]) * 2.0f - 0.5f + (float)gi) * st;  // :203
-        cy = (sig(p[1]) * 2.0f - 0.5f + (float)gj) * st;
-        const float ew = sig(p[2]) * 2.0f, eh = sig(p[3]) * 2.0f;
-        bw = ew * ew * aw * st;                            // :204
-        bh = eh * eh * ah * st;
-        float* bx = ws.cbox + o * 4;
-        bx[0] = cx - bw / 2; bx[1] = cy - bh / 2; bx[2] = cx + bw / 2; bx[3] = cy + bh / 2;
-      }
-      float Ssum = 0.f;
-      const float po = p[4];
-      for (int cc = 0; cc < d.C; ++cc) Ssum += bcewl(pair_logit(p[5 + cc], po), 0.f);
-      ws.cS[o] = Ssum;
     }
   }
   if (tid == 0) {
     ws.ngt[b] = nt;
     ws.ncand[b] = base < cap ? base : cap;
   }
+}
+
+// one thread per candidate: decoded box (:203-204), S = sum_c BCE(logit(y_c), 0) in class order (:236-246), the offset of its
+// prediction row, and a cleared vote counter
+__global__ __launch_bounds__(64) void k_v7_cdec(const plyolo_yolov7_desc d, const float* raw, V7Ws ws) {
+  const int b = blockIdx.y, n = blockIdx.x * 64 + threadIdx.x, cap = d.cand_cap;
+  if (n >= ws.ncand[b]) return;
+  const size_t o = (size_t)b * cap + n;
+  const int* c = ws.cand + o * 5;
+  const int l = c[0], a = c[1], gj = c[2], gi = c[3];
+  const float st = (float)d.lvl_stride[l];
+  const float aw = d.anchors[l][a][0] / st, ah = d.anchors[l][a][1] / st;  // :334
+  const float* p = cell_ptr(d, raw, b, l, a, gj, gi);
+  ws.coff[o] = (long long)(p - raw);
+  ws.selcnt[o] = 0;
+  {
+#pragma clang fp contract(off)
+    const float cx = (sig(p[0]) * 2.0f - 0.5f + (float)gi) * st;  // :203
+    const float cy = (sig(p[1]) * 2.0f - 0.5f + (float)gj) * st;
+    const float ew = sig(p[2]) * 2.0f, eh = sig(p[3]) * 2.0f;
+    const float bw = ew * ew * aw * st, bh = eh * eh * ah * st;   // :204
+    float* bx = ws.cbox + o * 4;
+    bx[0] = cx - bw / 2; bx[1] = cy - bh / 2; bx[2] = cx + bw / 2; bx[3] = cy + bh / 2;
+  }
+  float Ssum = 0.f;
+  const float po = p[4];
+  for (int c0 = 0; c0 < d.C; c0 += 8) {       // eight logits requested together, summed in class order
+    float x[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) x[q] = p[5 + min(c0 + q, d.C - 1)];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (c0 + q < d.C) Ssum += bcewl(pair_logit(x[q], po), 0.f);
+  }
+  ws.cS[o] = Ssum;
 }
 
 // wave-wide (value, index) selection: larger (or smaller) value wins, ties -> lower index
@@ -249,8 +272,90 @@ DEVINL void entry_boxes(const plyolo_yolov7_desc& d, const float* p, const float
   tb[3] = L[4] / st;
 }
 
+// one wave per (image, GT): the GT's IoU / cost rows over the image's candidates live in LDS (the selection rounds re-read them
+// 10 + k times), four candidates' operands are requested together, votes go to the candidates' counters
+__global__ __launch_bounds__(64) void k_v7_rows(const plyolo_yolov7_desc d, const float* raw, const float* labels, V7Ws ws) {
+  const int b = blockIdx.y, g = blockIdx.x, lane = threadIdx.x;
+  const int cap = d.cand_cap, N = ws.ncand[b], G = ws.ngt[b];
+  if (g >= G || N == 0) return;
+  extern __shared__ __align__(16) float v7_rows_smem[];
+  float* iou_row = v7_rows_smem;          // [cap]
+  float* cost_row = v7_rows_smem + cap;   // [cap]
+  const float* lab = labels + (size_t)b * d.M * 5;
+  const float* cbox = ws.cbox + (size_t)b * cap * 4;
+  const float* cS = ws.cS + (size_t)b * cap;
+  const long long* coff = ws.coff + (size_t)b * cap;
+  int* selcnt = ws.selcnt + (size_t)b * cap;
+  int* selgt = ws.selgt + (size_t)b * cap;
+  float gt[4];
+  gt_xyxy(lab + g * 5, gt);
+  const int gcls = (int)lab[g * 5];
+  constexpr int UB = 4;
+  for (int n0 = lane; n0 < N; n0 += 64 * UB) {
+    const float* pp[UB];
+    float S[UB], bx[UB][4], xc[UB], xo[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int nc = min(n0 + u * 64, N - 1);
+      pp[u] = raw + coff[nc];
+      S[u] = cS[nc];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bx[u][q] = cbox[nc * 4 + q];
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) { xc[u] = pp[u][5 + gcls]; xo[u] = pp[u][4]; }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int n = n0 + u * 64;
+      if (n < N) {
+        float iou, cost;
+        pair_terms(gt, bx[u], S[u], pair_logit(xc[u], xo[u]), &iou, &cost);
+        iou_row[n] = iou;
+        cost_row[n] = cost;
+      }
+    }
+  }
+  __syncthreads();
+  // dynamic k = clamp(int(sum of the 10 largest IoUs), 1)   (:225-226)
+  const int nk = N < 10 ? N : 10;
+  float sum = 0.f;
+  for (int r = 0; r < nk; ++r) {
+    float bv = -2.f;
+    int bi = INT_MAX;
+#pragma unroll 4
+    for (int n = lane; n < N; n += 64) {
+      const float v = iou_row[n];
+      if (v > bv) { bv = v; bi = n; }
+    }
+    wave_pick<true>(bv, bi);
+    sum += bv;
+    if (bi != INT_MAX && (bi & 63) == lane) iou_row[bi] = -1.f;
+    __syncthreads();
+  }
+  int k = (int)sum;
+  if (k < 1) k = 1;
+  if (k > N) k = N;
+  for (int r = 0; r < k; ++r) {  // the k cheapest candidates (:255-259)
+    float bv = INFINITY;
+    int bi = INT_MAX;
+#pragma unroll 4
+    for (int n = lane; n < N; n += 64) {
+      const float v = cost_row[n];
+      if (v < bv) { bv = v; bi = n; }
+    }
+    wave_pick<false>(bv, bi);
+    if (bi == INT_MAX) break;  // nothing finite left
+    if ((bi & 63) == lane) {
+      cost_row[bi] = INFINITY;
+      atomicAdd(&selcnt[bi], 1);
+      selgt[bi] = g;
+    }
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(256) void k_v7_match(const plyolo_yolov7_desc d, const float* raw, const float* labels, V7Ws ws) {
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x, tid = threadIdx.x;
   const int cap = d.cand_cap, N = ws.ncand[b], G = ws.ngt[b];
   __shared__ int s_cnt[4];
   __shared__ int s_lvl[V7_NL];
@@ -264,56 +369,7 @@ __global__ __launch_bounds__(256) void k_v7_match(const plyolo_yolov7_desc d, co
     if (tid == 0) ws.nmatch[b] = 0;
     return;
   }
-  for (int n = tid; n < N; n += 256) selcnt[n] = 0;
   if (tid < V7_NL) s_lvl[tid] = 0;
-  __syncthreads();
-  float* iou_row = ws.rows + ((size_t)(b * 4 + wave) * 2 + 0) * cap;
-  float* cost_row = ws.rows + ((size_t)(b * 4 + wave) * 2 + 1) * cap;
-  for (int g = wave; g < G; g += 4) {
-    float gt[4];
-    gt_xyxy(lab + g * 5, gt);
-    const int gcls = (int)lab[g * 5];
-    for (int n = lane; n < N; n += 64) {
-      const int* c = cand + n * 5;
-      const float* p = cell_ptr(d, raw, b, c[0], c[1], c[2], c[3]);
-      float iou, cost;
-      pair_terms(gt, cbox + n * 4, cS[n], pair_logit(p[5 + gcls], p[4]), &iou, &cost);
-      iou_row[n] = iou;
-      cost_row[n] = cost;
-    }
-    // dynamic k = clamp(int(sum of the 10 largest IoUs), 1)   (:225-226)
-    const int nk = N < 10 ? N : 10;
-    float sum = 0.f;
-    for (int r = 0; r < nk; ++r) {
-      float bv = -2.f;
-      int bi = INT_MAX;
-      for (int n = lane; n < N; n += 64) {
-        const float v = iou_row[n];
-        if (v > bv) { bv = v; bi = n; }
-      }
-      wave_pick<true>(bv, bi);
-      sum += bv;
-      if (bi != INT_MAX && (bi & 63) == lane) iou_row[bi] = -1.f;
-    }
-    int k = (int)sum;
-    if (k < 1) k = 1;
-    if (k > N) k = N;
-    for (int r = 0; r < k; ++r) {  // the k cheapest candidates (:255-259)
-      float bv = INFINITY;
-      int bi = INT_MAX;
-      for (int n = lane; n < N; n += 64) {
-        const float v = cost_row[n];
-        if (v < bv) { bv = v; bi = n; }
-      }
-      wave_pick<false>(bv, bi);
-      if (bi == INT_MAX) break;  // nothing finite left
-      if ((bi & 63) == lane) {
-        cost_row[bi] = INFINITY;
-        atomicAdd(&selcnt[bi], 1);
-        selgt[bi] = g;
-      }
-    }
-  }
   __syncthreads();
   // conflict resolution (:262-268) + ordered list of matched entries
   int base = 0;
@@ -501,6 +557,7 @@ V7Ws carve(const plyolo_yolov7_desc* d, void* workspace, size_t* used, size_t* z
   ws.cand = (int*)(p + off); off += al256(B * cap * 5 * 4);
   ws.cbox = (float*)(p + off); off += al256(B * cap * 4 * 4);
   ws.cS = (float*)(p + off); off += al256(B * cap * 4);
+  ws.coff = (long long*)(p + off); off += al256(B * cap * 8);
   ws.rows = (float*)(p + off); off += al256(B * 4 * 2 * cap * 4);
   ws.selcnt = (int*)(p + off); off += al256(B * cap * 4);
   ws.selgt = (int*)(p + off); off += al256(B * cap * 4);
@@ -547,7 +604,11 @@ int plyolo_yolov7_loss_fwd(const plyolo_yolov7_desc* dp, const float* raw, const
   return submit(stream, [=](hipStream_t s) -> hipError_t {
     hipError_t e = plyolo::fill_async((unsigned char*)workspace + zo, 0, zb, s);
     if (e != hipSuccess) return e;
+    const size_t rows_lds = (size_t)d.cand_cap * 2 * 4;
+    if (hipError_t el = plyolo::ensure_dynamic_lds((const void*)k_v7_rows, rows_lds); el != hipSuccess) return el;
     hipLaunchKernelGGL(k_v7_cand, dim3(d.B), dim3(256), 0, s, d, raw, labels, ws);
+    hipLaunchKernelGGL(k_v7_cdec, dim3((d.cand_cap + 63) / 64, d.B), dim3(64), 0, s, d, raw, ws);
+    hipLaunchKernelGGL(k_v7_rows, dim3(d.M, d.B), dim3(64), rows_lds, s, d, raw, labels, ws);
     hipLaunchKernelGGL(k_v7_match, dim3(d.B), dim3(256), 0, s, d, raw, labels, ws);
     hipLaunchKernelGGL(k_v7_obj<false>, dim3(nblk), dim3(256), 0, s, d, raw, ws, total, (const float*)nullptr, (float*)nullptr);
     hipLaunchKernelGGL(k_v7_pos, dim3(d.B), dim3(256), 0, s, d, raw, labels, ws, nblk);
