@@ -464,30 +464,76 @@ __global__ __launch_bounds__(256) void k_v7_obj(const plyolo_yolov7_desc d, cons
   }
 }
 
+// backward, dense part in ONE pass over draw: zero everywhere except the objectness channel, which gets d/d obj of the obj term
+// (the zero fill of the 274 MB gradient tensor and the strided objectness writes were two passes).  A wave owns 64 consecutive
+// (row, anchor) pairs = 64 * (5 + C) contiguous floats: every lane computes ONE objectness gradient, then the wave streams the
+// chunk out in 16-byte vectors, picking the gradients up from the owning lanes.
+__global__ __launch_bounds__(256) void k_v7_bwd_dense(const plyolo_yolov7_desc d, const float* raw, V7Ws ws, unsigned npairs,
+                                                      const float* gout4, float* draw) {
+  const unsigned ch = 5u + (unsigned)d.C;
+  const float inv_ch = 1.0f / (float)ch;
+  const float gw = gout4[0] + gout4[2];
+  const unsigned lane = threadIdx.x & 63u, wv = blockIdx.x * 4u + (threadIdx.x >> 6), nwv = gridDim.x * 4u;
+  for (unsigned chunk = wv; chunk * 64u < npairs; chunk += nwv) {
+    const unsigned pair = chunk * 64u + lane;
+    float gobj = 0.f;
+    if (pair < npairs) {
+      const unsigned row = pair / (unsigned)d.na;
+      const int l = level_of_row(d, row);
+      const float scale = V7_BALANCE[l] / ((float)d.B * d.na * d.lvl_h[l] * d.lvl_w[l]);
+      gobj = gw * scale * (sig(raw[(size_t)pair * ch + 4]) - ws.tobj[pair]);
+    }
+    const unsigned npc = min(64u, npairs - chunk * 64u), nfl = npc * ch;
+    float* base = draw + (size_t)chunk * 64u * ch;            // 64 * ch floats: a multiple of 16 bytes
+    for (unsigned e0 = 0u; e0 < nfl; e0 += 256u) {      // wave-uniform trip count: every lane takes part in the shuffles
+      const unsigned e = e0 + lane * 4u;
+      unsigned q = (unsigned)(((float)e + 0.5f) * inv_ch), r = e - q * ch;   // pair (inside the chunk) and channel of element e
+      float o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float gq = __shfl(gobj, (int)(q & 63u));
+        o[i] = r == 4u ? gq : 0.f;
+        if (++r == ch) { r = 0u; ++q; }
+      }
+      if (e + 4u <= nfl) *(f32x4*)(base + e) = f32x4{o[0], o[1], o[2], o[3]};
+      else
+        for (unsigned i = 0; e + i < nfl; ++i) base[e + i] = o[i];     // (no iteration when e >= nfl)
+    }
+  }
+}
+
 // box (:121-122) and class (:131-134) terms over the matched entries of one image
+// V7_NP workgroups per image over (entry, class) items: a thread per entry walked its 80 class terms (libm) one after the other
+// while most of the workgroup idled; item c == 0 of an entry also carries its box term.  Fixed item -> thread mapping, fixed-order
+// partials: deterministic.
+constexpr int V7_NP = 8;
 __global__ __launch_bounds__(256) void k_v7_pos(const plyolo_yolov7_desc d, const float* raw, const float* labels, V7Ws ws, int nblk_obj) {
   __shared__ float s_red[4];
-  const int b = blockIdx.x, cap = d.cand_cap, Mn = ws.nmatch[b];
+  const int b = blockIdx.y, cap = d.cand_cap, Mn = ws.nmatch[b];
   const int* match = ws.match + (size_t)b * cap * 6;
   const float* lab = labels + (size_t)b * d.M * 5;
   float box = 0.f, cls = 0.f;
-  for (int e = threadIdx.x; e < Mn; e += 256) {
+  const int items = Mn * d.C;
+  for (int it = blockIdx.x * 256 + threadIdx.x; it < items; it += V7_NP * 256) {
+    const int e = it / d.C, c = it - e * d.C;
     const int* m = match + e * 6;
-    const float* p = cell_ptr(d, raw, b, m[0], m[1], m[2], m[3]);
-    float bx[4], tb[4], sg[4];
-    entry_boxes(d, p, lab + m[4] * 5, m[0], m[1], m[2], m[3], bx, tb, sg);
-    const float nl = (float)ws.nlvl[m[0]];
-    box += (1.0f - ciou_terms(bx, tb, nullptr)) / nl;
-    const int tc = (int)lab[m[4] * 5];
-    float s = 0.f;
-    for (int c = 0; c < d.C; ++c) s += bcewl(p[5 + c], c == tc ? 1.f : 0.f);
-    cls += s / (nl * d.C);
+    const int l = m[0], a = m[1], gj = m[2], gi = m[3], t = m[4];
+    const float* p = cell_ptr(d, raw, b, l, a, gj, gi);
+    const float x = p[5 + c];
+    const float nl = (float)ws.nlvl[l];
+    const int tc = (int)lab[t * 5];
+    cls += bcewl(x, c == tc ? 1.f : 0.f) / (nl * d.C);
+    if (c == 0) {
+      float bx[4], tb[4], sg[4];
+      entry_boxes(d, p, lab + t * 5, l, a, gj, gi, bx, tb, sg);
+      box += (1.0f - ciou_terms(bx, tb, nullptr)) / nl;
+    }
   }
   box = block_sum(box, s_red);
   cls = block_sum(cls, s_red);
   if (threadIdx.x == 0) {
-    ws.partial[nblk_obj + b * 2 + 0] = box;
-    ws.partial[nblk_obj + b * 2 + 1] = cls;
+    ws.partial[nblk_obj + (b * V7_NP + blockIdx.x) * 2 + 0] = box;
+    ws.partial[nblk_obj + (b * V7_NP + blockIdx.x) * 2 + 1] = cls;
   }
 }
 
@@ -495,7 +541,7 @@ __global__ __launch_bounds__(256) void k_v7_final(const plyolo_yolov7_desc d, V7
   __shared__ float s_red[4];
   float o = 0.f, bx = 0.f, cl = 0.f;
   for (int i = threadIdx.x; i < nblk_obj; i += 256) o += ws.partial[i];
-  for (int i = threadIdx.x; i < d.B; i += 256) { bx += ws.partial[nblk_obj + i * 2]; cl += ws.partial[nblk_obj + i * 2 + 1]; }
+  for (int i = threadIdx.x; i < d.B * V7_NP; i += 256) { bx += ws.partial[nblk_obj + i * 2]; cl += ws.partial[nblk_obj + i * 2 + 1]; }
   o = block_sum(o, s_red);
   bx = block_sum(bx, s_red);
   cl = block_sum(cl, s_red);
@@ -511,11 +557,12 @@ __global__ __launch_bounds__(256) void k_v7_final(const plyolo_yolov7_desc d, V7
 // d loss / d raw for the box and class channels of matched cells (a cell matched twice receives both)
 __global__ __launch_bounds__(256) void k_v7_bwd_pos(const plyolo_yolov7_desc d, const float* raw, const float* labels, V7Ws ws,
                                                     const float* gout4, float* draw) {
-  const int b = blockIdx.x, cap = d.cand_cap, Mn = ws.nmatch[b], ch = 5 + d.C;
+  const int b = blockIdx.y, cap = d.cand_cap, Mn = ws.nmatch[b], ch = 5 + d.C;
   const int* match = ws.match + (size_t)b * cap * 6;
   const float* lab = labels + (size_t)b * d.M * 5;
   const int items = Mn * (ch - 1);
-  for (int it = threadIdx.x; it < items; it += 256) {
+  // gridDim.x workgroups per image (one workgroup walked ~50 items per thread, each behind its own chain of loads)
+  for (int it = blockIdx.x * 256 + threadIdx.x; it < items; it += gridDim.x * 256) {
     const int e = it / (ch - 1);
     int c = it - e * (ch - 1);
     const int* m = match + e * 6;
@@ -563,7 +610,7 @@ V7Ws carve(const plyolo_yolov7_desc* d, void* workspace, size_t* used, size_t* z
   ws.selgt = (int*)(p + off); off += al256(B * cap * 4);
   ws.nmatch = (int*)(p + off); off += al256(B * 4);
   ws.match = (int*)(p + off); off += al256(B * cap * 6 * 4);
-  ws.partial = (float*)(p + off); off += al256((nblk + 2 * B) * 4);
+  ws.partial = (float*)(p + off); off += al256((nblk + 2 * B * 8) * 4);     // obj partials + V7_NP (box, cls) pairs per image
   *zero_off = off;
   ws.nlvl = (int*)(p + off); off += 256;
   ws.tobj = (float*)(p + off); off += al256(rows * d->na * 4);
@@ -611,7 +658,7 @@ int plyolo_yolov7_loss_fwd(const plyolo_yolov7_desc* dp, const float* raw, const
     hipLaunchKernelGGL(k_v7_rows, dim3(d.M, d.B), dim3(64), rows_lds, s, d, raw, labels, ws);
     hipLaunchKernelGGL(k_v7_match, dim3(d.B), dim3(256), 0, s, d, raw, labels, ws);
     hipLaunchKernelGGL(k_v7_obj<false>, dim3(nblk), dim3(256), 0, s, d, raw, ws, total, (const float*)nullptr, (float*)nullptr);
-    hipLaunchKernelGGL(k_v7_pos, dim3(d.B), dim3(256), 0, s, d, raw, labels, ws, nblk);
+    hipLaunchKernelGGL(k_v7_pos, dim3(V7_NP, d.B), dim3(256), 0, s, d, raw, labels, ws, nblk);
     hipLaunchKernelGGL(k_v7_final, dim3(1), dim3(256), 0, s, d, ws, nblk, losses);
     return hipGetLastError();
   });
@@ -629,10 +676,14 @@ int plyolo_yolov7_loss_bwd(const plyolo_yolov7_desc* dp, const float* raw, const
   const size_t dbytes = rows * (size_t)d.na * (5 + d.C) * 4;
   plyolo::annotate("yolov7_loss_bwd", 0.0, (double)dbytes);
   return submit(stream, [=](hipStream_t s) -> hipError_t {
-    hipError_t e = plyolo::fill_async(draw, 0, dbytes, s);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_v7_obj<true>, dim3(nblk), dim3(256), 0, s, d, raw, ws, total, gout, draw);
-    hipLaunchKernelGGL(k_v7_bwd_pos, dim3(d.B), dim3(256), 0, s, d, raw, labels, ws, gout, draw);
+    if (total < (1ull << 31) && ((uintptr_t)draw & 15) == 0) {
+      hipLaunchKernelGGL(k_v7_bwd_dense, dim3(2048), dim3(256), 0, s, d, raw, ws, (unsigned)total, gout, draw);
+    } else {
+      hipError_t e = plyolo::fill_async(draw, 0, dbytes, s);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(k_v7_obj<true>, dim3(nblk), dim3(256), 0, s, d, raw, ws, total, gout, draw);
+    }
+    hipLaunchKernelGGL(k_v7_bwd_pos, dim3(32, d.B), dim3(256), 0, s, d, raw, labels, ws, gout, draw);
     return hipGetLastError();
   });
 }
