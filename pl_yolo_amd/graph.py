@@ -135,14 +135,25 @@ class Graph:
     def queue_reduce(self, pc):
         """Slab folds are tiny launches (69 per YOLOX-s step, ~12 us each, mostly launch floor): they are queued and run as ONE
         two-stage launch per `reduce_batch` layers on the weight-gradient lane (and before anything reads slab 0)."""
-        self.reduce_queue.append(pc)
+        self.reduce_queue.append((pc, self.plan.cur if self.plan is not None else 0))   # + the lane its slabs were written on
         if len(self.reduce_queue) >= self.reduce_batch:
             self.flush_reduce()
 
     def flush_reduce(self):
-        q, self.reduce_queue = self.reduce_queue, []
-        if not q:
+        """One batched fold launch for the queued layers.  With lanes it always sits on the weight-gradient lane, behind an
+        event of every OTHER lane that wrote one of the queued slabs (ImplicitHead levels on a side lane, ops that issue their
+        weight gradient inline): whichever lane happens to be current when the queue fills, the fold is ordered after every
+        writer; the caller's lane is restored."""
+        qq, self.reduce_queue = self.reduce_queue, []
+        if not qq:
             return
+        q = [pc for pc, _ in qq]
+        plan, prev = self.plan, None
+        if self.use_lanes and plan is not None:
+            prev = plan.cur
+            for l in sorted({l for _, l in qq} - {WGRAD_LANE}):
+                plan.wait(WGRAD_LANE, plan.record(l))
+            plan.lane(WGRAD_LANE)
         from ._lib import ReduceJob
         arr = (ReduceJob * len(q))()
         max_cols = max_groups = 1
@@ -157,6 +168,8 @@ class Graph:
         t = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
         self.keep.append(t)
         call("plyolo_reduce_slabs_multi", t.data_ptr(), len(q), max_cols, max_groups, total, None)
+        if prev is not None:
+            plan.lane(prev)
 
     # ------------------------------------------------------------------ lazy activations
     def resolve_lazy(self):
@@ -1325,11 +1338,20 @@ class ImplicitHeadOp:
         call("plyolo_implicit_bwd", g.dtype, dy, u, ptr(self.im), self.du.data_ptr(), self.du_ld, self.partial.data_ptr(), rows, self.Cout, None)
         d = conv_desc(g, self.desc.N, self.desc.H, self.desc.W, self.Cin, self.Cout, 1, 1, self.x.ld, self.du_ld, 0)
         self.keep = d
-        call("plyolo_bias_grad", g.dtype, self.du.data_ptr(), rows, self.Cout, self.du_ld, self.pc.dbp, None)
-        call("plyolo_conv2d_wgrad", C.byref(d), g.aptr(self.x), self.du.data_ptr(), self.pc.dwp, None)
-        self.pc.reduce_slabs()
         acc = g.grad_mode(self.x)
         call("plyolo_conv2d_dgrad", C.byref(d), self.du.data_ptr(), self.pc.wpd, g.gptr(self.x), acc, None)
+
+        # bias sums, weight gradient and its slab fold only feed the optimizer: weight-gradient lane, like every other unit
+        # (du is private to this level and written once per plan, so the deferred readers need no reuse event)
+        def param_grads():
+            call("plyolo_bias_grad", g.dtype, self.du.data_ptr(), rows, self.Cout, self.du_ld, self.pc.dbp, None)
+            call("plyolo_conv2d_wgrad", C.byref(d), g.aptr(self.x), self.du.data_ptr(), self.pc.dwp, None)
+            self.pc.reduce_slabs()
+
+        if g.use_lanes:
+            g.defer_param_grads(self.lane, param_grads)
+        else:
+            param_grads()
 
     def post_unpack(self):
         """After unpack_wgrads wrote dW: d(im), d(ia), d(bias) and the ia term of dW."""
@@ -1643,9 +1665,11 @@ class Plan:
     def __init__(self):
         self.h = _lib.lib().plyolo_plan_create()
         self.graph_ready = False
+        self.cur = 0          # lane of the launches being recorded (mirrors plyolo_plan_lane)
 
     def __enter__(self):
         call("plyolo_plan_begin", self.h)
+        self.cur = 0
         return self
 
     def __exit__(self, *exc):
@@ -1680,6 +1704,7 @@ class Plan:
     # lanes (concurrent launch sequences inside a hipGraph replay), see include/plyolo.h
     def lane(self, l):
         call("plyolo_plan_lane", self.h, l)
+        self.cur = l
 
     def record(self, lane):
         ev = _lib.lib().plyolo_plan_record(self.h, lane)

@@ -372,14 +372,24 @@ def _check_generation(ctx, s):
 def _accumulating(runner, s):
     """`.grad` still being the flat view AND untouched since the last backward means the caller neither dropped nor zeroed the
     gradients (gradient accumulation over micro-batches, Lightning's accumulate_grad_batches): autograd would ADD the new
-    gradient, while the backward plan overwrites the flat buffer.  The published version is kept per RUNNER -- every traced
-    shape of a model shares the one flat gradient buffer (multi-scale training)."""
+    gradient, while the backward plan overwrites the flat buffer.  The published versions are kept per RUNNER -- every traced
+    shape of a model shares the one flat gradient buffer (multi-scale training).  EVERY used parameter is looked at: the flat
+    buffer is set aside and added back as a whole, so a caller that zeroed or dropped only some of the gradients (an optimizer
+    that owns part of the model, a frozen stem, zero_grad on one parameter group) cannot be served and is refused."""
     pv = runner.flat.get("published") if runner.flat else None
-    if not s.used_params or pv is None:
+    if not s.used_params or not pv:
         return False
-    p, gv = s.used_params[0], s.grad_views[0]
-    g = p.grad
-    return g is not None and g.data_ptr() == gv.data_ptr() and pv == (id(p), g._version)
+    kept = 0
+    for p, gv in zip(s.used_params, s.grad_views):
+        g = p.grad
+        if g is not None and g.data_ptr() == gv.data_ptr() and pv.get(id(p)) == g._version:
+            kept += 1
+    if kept not in (0, len(s.used_params)):
+        raise PlyoloError("backward over partially cleared gradients: %d of %d parameters still hold the previous backward's "
+                          "gradient and the others were zeroed or dropped; the HIP plan writes ONE flat gradient buffer, so "
+                          "clear (or keep, to accumulate) the gradients of all parameters of the model together"
+                          % (kept, len(s.used_params)))
+    return kept > 0
 
 
 def _publish_grads(runner, s):
@@ -395,8 +405,12 @@ def _publish_grads(runner, s):
             p.grad = gv
         else:
             g.add_(gv)
-    if s.used_params and s.used_params[0].grad is not None:
-        runner.flat["published"] = (id(s.used_params[0]), s.used_params[0].grad._version)
+    pub = runner.flat.setdefault("published", {})
+    if not isinstance(pub, dict):
+        pub = runner.flat["published"] = {}
+    for p in s.used_params:
+        if p.grad is not None:
+            pub[id(p)] = p.grad._version
 
 
 class _Accumulate:

@@ -150,6 +150,10 @@ def _check_eval_decode_yolox(model, sd0, imgs, A):
 
 
 # ---------------------------------------------------------------------------------------------- cfg1
+CFG1_BF16_LOSS_TOL = 5e-3     # bf16 loss of the random-initialised nano net against the reference's fp32 loss (round 3 allowed 3e-2)
+CFG1_BF16_COS_MIN = 0.98      # all stored gradients as one vector, bf16 against the reference's fp32
+
+
 def test_cfg1_nano416_b4_fp32_vs_reference_fixture():
     """YOLOX-nano 416x416 batch 4 (the reference's CPU-runnable configuration) through the HIP fp32 parity mode:
     same seeded weights and synthetic batch as the reference run that wrote tests/golden/cfg1_nano416.npz."""
@@ -186,9 +190,24 @@ def test_cfg1_nano416_b4_fp32_vs_reference_fixture():
     # the bf16 MFMA path at this configuration: same batch, loss within the bf16 band
     m16, _ = _build(cfg, "bf16")
     m16.train()
-    l16 = float(m16(imgs.to(hu.DEV), labels.to(hu.DEV))["loss"])
-    print("cfg1 bf16 loss %.5f vs reference %.5f" % (l16, float(g["out/loss"])))
-    assert abs(l16 - float(g["out/loss"])) <= 3e-2 * float(g["out/loss"])
+    o16 = m16(imgs.to(hu.DEV), labels.to(hu.DEV))
+    o16["loss"].backward()
+    torch.cuda.synchronize()
+    l16 = float(o16["loss"])
+    # ... and the gradients it back-propagates, against the reference's own (every tensor the fixture stores): one cosine over
+    # all of them (the instrument of test_warm_yolox_s_bf16_end_to_end; this net is RANDOM-initialised, where bf16 storage noise
+    # is amplified layer by layer and flips a few SimOTA assignments -- DESIGN.md section 6 -- so the floor is lower than the
+    # warm fixtures' 0.9995)
+    p16 = dict(m16.named_parameters())
+    dot = n1 = n2 = 0.0
+    for k in [k for k in g if k.startswith("grad/")]:
+        ref, got = torch.from_numpy(g[k]).double(), p16[k[5:]].grad.cpu().double()
+        dot, n1, n2 = dot + float((ref * got).sum()), n1 + float((ref * ref).sum()), n2 + float((got * got).sum())
+    cos = dot / max((n1 * n2) ** 0.5, 1e-30)
+    print("cfg1 bf16 loss %.5f vs reference %.5f (rel %.2e); gradient cosine over the stored tensors %.5f, norm ratio %.4f"
+          % (l16, float(g["out/loss"]), abs(l16 - float(g["out/loss"])) / float(g["out/loss"]), cos, (n2 / max(n1, 1e-30)) ** 0.5))
+    assert abs(l16 - float(g["out/loss"])) <= CFG1_BF16_LOSS_TOL * float(g["out/loss"])
+    assert cos >= CFG1_BF16_COS_MIN
 
 
 # ---------------------------------------------------------------------------------------------- cfg3

@@ -274,3 +274,54 @@ def test_v7_overfit_one_batch(repconv):
     head, tail = sum(losses[:5]) / 5, sum(losses[-5:]) / 5
     print("yolov7 overfit (repconv=%s): loss %.4f -> %.4f" % (repconv, head, tail))
     assert all(np.isfinite(losses)) and tail < 0.8 * head
+
+
+def _v7_bf16_step(env, repconv):
+    """One bf16 training step of the toy YOLOv7 (4 x 3 x 320 x 320: every ImplicitHead / RepConv weight gradient splits into
+    several private slabs) with environment switches applied while its plans are recorded."""
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        with open(os.path.join(ROOT, "configs", "model", "yolov7", "yolov7_test.yaml")) as f:
+            cfg = yaml.safe_load(f)
+        cfg["neck"]["repconv"] = repconv
+        torch.manual_seed(11)
+        model = pl_yolo_amd.build_model(cfg, 3)
+        model.compute_dtype = "bf16"
+        model = model.to(hu.DEV).train()
+        x = (torch.rand(4, 3, 320, 320, generator=torch.Generator().manual_seed(5)) * 255).to(hu.DEV)
+        labels = torch.zeros(4, 6, 5)
+        labels[0, :2] = torch.tensor([[1, 100.0, 120.0, 80.0, 90.0], [0, 220.0, 170.0, 120.0, 110.0]])
+        labels[1, :1] = torch.tensor([[2, 160.0, 160.0, 200.0, 150.0]])
+        labels[3, :1] = torch.tensor([[1, 60.0, 250.0, 50.0, 70.0]])
+        out = model(x, labels.to(hu.DEV))
+        out["loss"].backward()
+        torch.cuda.synchronize()
+        sess = [s for k, s in model.runner().sessions.items() if k[4] == "train"][0]
+        nslab = {type(op).__name__: max(getattr(op, a).nslab for a in ("pc",) if hasattr(op, a)) for op in sess.g.ops if hasattr(op, "pc")}
+        return float(out["loss"]), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}, nslab
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("repconv", [False, True])
+def test_v7_bf16_gradients_do_not_depend_on_lanes_or_fold_batching(repconv):
+    """The batched slab folds are ordered behind every lane that wrote one of their slabs: the default plan (three lanes,
+    four layers per fold launch) gives the gradients of the single-lane plan and of the one-fold-per-layer plan.  A fold that
+    runs ahead of a weight gradient on another lane (ImplicitHead levels, the RepConv blocks of the side lane) sums stale slabs
+    and shows up here as a gradient that is off by tens of per cent."""
+    l0, g0, ns = _v7_bf16_step({"PLYOLO_LANES": "0"}, repconv)
+    assert ns.get("ImplicitHeadOp", 0) > 1, ns      # the case needs split weight gradients
+    for env in ({}, {"PLYOLO_REDUCE_BATCH": "1"}, {"PLYOLO_REDUCE_BATCH": "7"}):
+        for rep in range(2):
+            l1, g1, _ = _v7_bf16_step(env, repconv)
+            assert abs(l1 - l0) <= 1e-6 * max(1.0, abs(l0)), (env, l0, l1)
+            assert set(g1) == set(g0)
+            for n in g0:
+                scale = max(float(g0[n].abs().max()), 1e-6)
+                # bias / implicit sums use fp32 atomics (run-to-run last-bit differences); everything else is bit-identical
+                assert float((g0[n] - g1[n]).abs().max()) <= 2e-5 * scale, (env, rep, n)
