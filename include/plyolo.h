@@ -406,6 +406,19 @@ int plyolo_conv2d_dgrad_bn_fits(const plyolo_conv_desc* d, int act);
 int plyolo_conv2d_dgrad_bn(const plyolo_conv_desc* d, const plyolo_bn_bwd_fuse* f, const void* wpd, void* dx,
                            int accumulate, void* stream);
 
+/* The WHOLE backward of a pointwise BaseConv unit behind plyolo_bn_act_bwd_reduce, in one persistent launch (csrc/conv_pw_bwd.hip):
+ * dz = plyolo_bn_act_bwd_dz(dout, z) is formed tile by tile in LDS and feeds both dx (+)= dz . W (== plyolo_conv2d_dgrad, bit for
+ * bit) and dW = dz^T . x (== plyolo_conv2d_wgrad up to the order of its fp32 sums); dout, z and x are read once, dz never reaches
+ * HBM (f->dz is ignored and may be NULL).  What autograd computes for act(bn(conv1x1(x))), network_blocks.py:18-40, from the
+ * gradient of the activated output: dx, the weight gradient, dgamma, dbeta.  x and dx share d->x_ld.  The weight gradient leaves
+ * as plyolo_conv2d_bwd_pw_slabs(d) private fp32 slabs [slab][Cout][Cin] at dwp (fold them with plyolo_reduce_slabs).
+ * plyolo_conv2d_bwd_pw_fits: 1 if the unit is covered (bf16, 1x1 stride 1, act none/silu/relu/lrelu, Cout and Cin in {32, 64, 128}
+ * and equal or 2:1, output gradient >= PLYOLO_PWBWD_MIN_MB), else 0. */
+int plyolo_conv2d_bwd_pw_fits(const plyolo_conv_desc* d, int act);
+int plyolo_conv2d_bwd_pw_slabs(const plyolo_conv_desc* d);
+int plyolo_conv2d_bwd_pw(const plyolo_conv_desc* d, const plyolo_bn_bwd_fuse* f, const void* x, const void* wpd, void* dx,
+                         int accumulate, float* dwp, void* stream);
+
 /* norm = "ln" of BaseConv (reference models/layers/normalization.py:9-10): nn.LayerNorm(out_channels) on an NCHW tensor
  * normalises the last axis, the image WIDTH, with affine parameters gamma[W], beta[W] (torch requires W == out_channels), eps
  * inside the square root, biased variance; the activation of BaseConv follows.  x / out / dout / dx are [N*H*W, ld] NHWC

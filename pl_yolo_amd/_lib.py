@@ -164,6 +164,9 @@ SIGNATURES = {
     "plyolo_conv2d_wgrad": (_i, [_P(ConvDesc), _vp, _vp, _vp, _vp]),
     "plyolo_conv2d_dgrad_bn_fits": (_i, [_P(ConvDesc), _i]),
     "plyolo_conv2d_dgrad_bn": (_i, [_P(ConvDesc), _P(BnBwdFuse), _vp, _vp, _i, _vp]),
+    "plyolo_conv2d_bwd_pw_fits": (_i, [_P(ConvDesc), _i]),
+    "plyolo_conv2d_bwd_pw_slabs": (_i, [_P(ConvDesc)]),
+    "plyolo_conv2d_bwd_pw": (_i, [_P(ConvDesc), _P(BnBwdFuse), _vp, _vp, _vp, _i, _vp, _vp]),
     "plyolo_conv2d_wgrad_slabs": (_i, [_P(ConvDesc)]),
     "plyolo_bias_grad": (_i, [_i, _vp, _i, _i, _i, _vp, _vp]),
     "plyolo_bias_grad_multi": (_i, [_i, _vp, _i, _vp]),

@@ -62,6 +62,9 @@ int conv_pw_fwd(const plyolo_conv_desc*, const void*, const void*, const float*,
 int conv_pw_dgrad(const plyolo_conv_desc*, const void*, const void*, void*, int, void*);
 int conv_pw_dgrad_bn_fits(const plyolo_conv_desc*, int);
 int conv_pw_dgrad_bn(const plyolo_conv_desc*, const plyolo_bn_bwd_fuse*, const void*, void*, int, void*);
+int conv_pw_bwd_fits(const plyolo_conv_desc*, int);
+int conv_pw_bwd_slabs(const plyolo_conv_desc*);
+int conv_pw_bwd(const plyolo_conv_desc*, const plyolo_bn_bwd_fuse*, const void*, const void*, void*, int, float*, void*);
 int conv_ref_fwd(const plyolo_conv_desc*, const void*, const void*, const float*, void*, double*, void*);
 int conv_ref_dgrad(const plyolo_conv_desc*, const void*, const void*, void*, int, void*);
 int conv_ref_wgrad(const plyolo_conv_desc*, const void*, const void*, float*, void*);
@@ -470,6 +473,24 @@ int plyolo_conv2d_dgrad_bn(const plyolo_conv_desc* d, const plyolo_bn_bwd_fuse* 
   PLY_CHECK_ARG(!f->dout2 || (f->dout_split > 0 && f->dout_split < d->Cout && f->dout_split % 8 == 0 && f->dout2_ld % 8 == 0), "conv2d_dgrad_bn: bad output-gradient split");
   PLY_CHECK_ARG(f->par_split == 0 || (f->par_split > 0 && f->par_split < d->Cout), "conv2d_dgrad_bn: bad parameter split");
   return conv_pw_dgrad_bn(d, f, wpd, dx, accumulate, stream);
+}
+int plyolo_conv2d_bwd_pw_fits(const plyolo_conv_desc* d, int act) {
+  if (check_conv(d, "conv2d_bwd_pw_fits", false)) return -1;
+  return conv_pw_bwd_fits(d, act);
+}
+int plyolo_conv2d_bwd_pw_slabs(const plyolo_conv_desc* d) {
+  if (check_conv(d, "conv2d_bwd_pw_slabs", false)) return -1;
+  return conv_pw_bwd_slabs(d);
+}
+int plyolo_conv2d_bwd_pw(const plyolo_conv_desc* d, const plyolo_bn_bwd_fuse* f, const void* x, const void* wpd, void* dx, int accumulate,
+                         float* dwp, void* stream) {
+  if (check_conv(d, "conv2d_bwd_pw", false)) return -1;
+  PLY_CHECK_ARG(f && f->dout && f->z && f->coef && f->bslots && x && wpd && dx && dwp, "conv2d_bwd_pw: incomplete arguments");
+  PLY_CHECK_ARG(conv_pw_bwd_fits(d, f->act) == 1, "conv2d_bwd_pw: this unit is not covered (ask plyolo_conv2d_bwd_pw_fits; use plyolo_bn_act_bwd_dz + plyolo_conv2d_dgrad + plyolo_conv2d_wgrad)");
+  PLY_CHECK_ARG(f->dout_ld % 8 == 0 && f->z_ld % 8 == 0 && f->z_ld >= d->Cout, "conv2d_bwd_pw: pitches must be multiples of 8 and hold Cout channels");
+  PLY_CHECK_ARG(!f->dout2 || (f->dout_split > 0 && f->dout_split < d->Cout && f->dout_split % 8 == 0 && f->dout2_ld % 8 == 0), "conv2d_bwd_pw: bad output-gradient split");
+  PLY_CHECK_ARG(f->par_split == 0 || (f->par_split > 0 && f->par_split < d->Cout), "conv2d_bwd_pw: bad parameter split");
+  return conv_pw_bwd(d, f, x, wpd, dx, accumulate, dwp, stream);
 }
 int plyolo_conv2d_wgrad_slabs(const plyolo_conv_desc* d) {
   if (check_conv(d, "conv2d_wgrad_slabs", false)) return -1;

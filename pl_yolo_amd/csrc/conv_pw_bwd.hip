@@ -1,0 +1,414 @@
+// Whole backward of a pointwise (1x1, stride 1) BaseConv unit behind its BatchNorm reduction, in ONE persistent launch (gfx950).
+//
+// Replaces, for act(bn(conv1x1(x))) (reference models/layers/network_blocks.py:18-40), what autograd does between the gradient
+// of the activated output and (dx, dW, dgamma, dbeta) once the two per-channel sums of the BatchNorm backward are known:
+//
+//     dz = A*du + B*z + Cc,  du = dout * act'(z*sc + sh)        (bn.hip: bn_act_bwd_dz, bit for bit)
+//     dx[M, Cin]  (+)= dz[M, Cout] . W[Cout, Cin]                (conv_pw.hip: conv_pw_dgrad)
+//     dW[Cout, Cin] = dz^T[Cout, M] . x[M, Cin]                  (conv_wgrad_mfma.hip, 1x1 variants)
+//
+// As separate launches that chain moves 3 E_out (dz pass) + E_out + E_in (data gradient) + E_out + E_in (weight gradient) bytes
+// and writes dz to HBM only to read it twice.  Here every pixel tile of dout, z and x is read ONCE and dz lives in LDS only:
+// 2 E_out + 2 E_in bytes, both GEMMs run out of the same LDS image (the kernel is HBM-bound: two GEMMs of 2*M*Cout*Cin FLOPs
+// each leave the matrix cores ~80 % idle at 64 ... 128 channels).
+//
+//   * persistent workgroups (256 threads, <= 2 per CU) walk the pixel tiles round-robin; the weight gradient accumulates in
+//     registers across ALL tiles of a workgroup (Cout x Cin fp32 = 64 registers per lane at 128 x 128) and leaves as one
+//     private fp32 slab per workgroup (no atomics; plyolo_reduce_slabs folds them in a fixed order -- run-to-run identical);
+//   * the loads of tile t+1 (16-byte vectors of whole rows -> registers) are issued behind tile t's LDS image and stay in
+//     flight during its MFMAs and epilogue;
+//   * ONE LDS image of dz serves both products: rows (ds_read_b128) as the A operand of dx = dz.W, columns
+//     (ds_read_b64_tr_b16) as the A operand of dW = dz^T.x.  Row pitch C*2+16 bytes makes the row reads conflict-free; the
+//     transposed reads are conflict-free with the contraction index permuted inside every 16-pixel k-step (k -> row
+//     4*(k&3) + (k>>2): the four rows of a half-wave's block are 4 apart, 4*pitch = 64 mod 256 bytes) -- a sum over pixels
+//     does not care about its order, and dz and x are read with the same permutation;
+//   * W (data-gradient fragment pack, conv_mfma.hip order) sits in registers for the whole launch; the per-channel
+//     coefficient table (sc, sh, A, B, Cc) is built once per workgroup from the fp64 stat slots.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+struct PbP {
+  const bf16_t* dout;    // gradient of the activated output [M][CO] (channels >= dsplit in dout2 for merged pairs)
+  const bf16_t* dout2;
+  const bf16_t* z;       // raw conv output of the forward [M][CO]
+  const bf16_t* x;       // input of the forward [M][CI]
+  const bf16_t* wpd;     // data-gradient fragment pack [CI/32][CO/16][64 lanes][8]
+  bf16_t* dx;            // [M][CI], pitch dx_ld
+  float* dw;             // slabs [G * WK][CO][CI]
+  const float* coef;     // (scale | shift | mean | invstd) [4][CO]
+  const double* bslots;  // [PLYOLO_STAT_SLOTS][2][CO]
+  const float *gamma, *gamma2;
+  float *dgamma, *dbeta, *dgamma2, *dbeta2;
+  int dout_ld, dout2_ld, dsplit, psplit, z_ld, x_ld, dx_ld;
+  int M, ntiles, act, accumulate;
+};
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4_b;
+DEVINL s16x4 tr_read_b(const unsigned char* p) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_b*)p); }
+
+DEVINL float pb_act_grad(float u, int act) {     // == pw_act_grad (conv_pw.hip) == act_grad<false> for the three cheap activations
+  switch (act) {
+    case PLYOLO_ACT_SILU: {
+      const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-u));
+      return s * (1.0f + u * (1.0f - s));
+    }
+    case PLYOLO_ACT_RELU: return u > 0.f ? 1.f : 0.f;
+    case PLYOLO_ACT_LRELU: return u > 0.f ? 1.f : 0.1f;
+    default: return 1.f;
+  }
+}
+
+DEVINL u32x4 pb_add_bf16x8(u32x4 a, u32x4 b) {
+  u32x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float lo = __uint_as_float(a[i] << 16) + __uint_as_float(b[i] << 16);
+    float hi = __uint_as_float(a[i] & 0xffff0000u) + __uint_as_float(b[i] & 0xffff0000u);
+    r[i] = pack2bf(lo, hi);
+  }
+  return r;
+}
+
+constexpr int pb_min(int a, int b) { return a < b ? a : b; }
+
+template <int CO, int CI, int BM> struct PbGeom {
+  // data gradient: dx tile [BM][CI], wave (wm, wn) owns 32 input channels x MT 32-row fragments
+  static constexpr int WN = CI / 32 >= 4 ? 4 : CI / 32, WM = 4 / WN, MT = BM / (32 * WM);
+  static constexpr int KSD = CO / 16;                  // k-steps of the data gradient (contraction over CO)
+  // weight gradient: dW [CO][CI] in 32x32 tiles over the four waves; fewer than four tiles -> the waves split the k-steps
+  static constexpr int TCO = CO / 32, TCI = CI / 32;
+  static constexpr int WCO = pb_min(TCO, TCI >= 2 ? 2 : 4), WCI = pb_min(TCI, 4 / WCO), WK = 4 / (WCO * WCI);
+  static constexpr int MTC = TCO / WCO, MTI = TCI / WCI;
+  static constexpr int KSW = BM / 16;                  // k-steps of the weight gradient per tile (contraction over pixels)
+  static constexpr int PD = CO * 2 + 16, PX = CI * 2 + 16;   // LDS row pitches (bytes)
+  static constexpr int DV = CO / 8, XV = CI / 8;       // 16-byte vectors per row
+  static constexpr int NDV = BM * DV / 256, NXV = BM * XV / 256;   // vectors per thread and tile
+  static constexpr int DZ_BYTES = BM * PD, X_BYTES = BM * PX, STG_BYTES = BM * PX;
+  static constexpr int TAB_OFF = DZ_BYTES + X_BYTES + STG_BYTES;
+  static constexpr int LDS = TAB_OFF + 5 * CO * 4;
+  static_assert(MT >= 1 && BM % (32 * WM) == 0, "tile rows vs wave layout");
+  static_assert(WCO * WCI * WK == 4 && KSW % WK == 0, "four waves");
+  static_assert(256 % DV == 0 && 256 % XV == 0 && (BM * DV) % 256 == 0 && (BM * XV) % 256 == 0, "whole vectors per thread");
+};
+
+template <int CO, int CI, int BM>
+__global__ __launch_bounds__(256, 2) void conv_pw_bwd_kernel(const PbP p) {
+  using G = PbGeom<CO, CI, BM>;
+  constexpr int WN = G::WN, WM = G::WM, MT = G::MT, KSD = G::KSD;
+  constexpr int WCO = G::WCO, WCI = G::WCI, WK = G::WK, MTC = G::MTC, MTI = G::MTI, KSW = G::KSW;
+  constexpr int PD = G::PD, PX = G::PX, DV = G::DV, XV = G::XV, NDV = G::NDV, NXV = G::NXV;
+  extern __shared__ __align__(16) unsigned char smem[];
+  unsigned char* dz_s = smem;
+  unsigned char* x_s = smem + G::DZ_BYTES;
+  unsigned char* stg = smem + G::DZ_BYTES + G::X_BYTES;
+  float* tab = (float*)(smem + G::TAB_OFF);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int G_ = (int)gridDim.x, wg = (int)blockIdx.x;
+
+  // ---- per-thread staging geometry (tile-invariant): vector v of the dz / x image = row drow + v*DRP, channel vector dcv
+  constexpr int DRP = 256 / DV, XRP = 256 / XV;
+  const int dcv = tid % DV, drow = tid / DV;
+  const int xcv = tid % XV, xrow = tid / XV;
+  const int dch = dcv * 8;
+  const bool second = p.dsplit > 0 && dch >= p.dsplit;
+  const bf16_t* dsrc = second ? p.dout2 + (dch - p.dsplit) : p.dout + dch;
+  const int dld = second ? p.dout2_ld : p.dout_ld;
+
+  u32x4 av[NDV], zv[NDV], xv[NXV];
+  auto request = [&](const int tile) {
+    const int m0 = tile * BM;
+#pragma unroll
+    for (int v = 0; v < NDV; ++v) {
+      const int m = m0 + drow + v * DRP;
+      const bool ok = m < p.M;
+      av[v] = *(const u32x4*)(ok ? dsrc + (size_t)m * dld : p.dout);
+      zv[v] = *(const u32x4*)(p.z + (ok ? (size_t)m * p.z_ld + dch : 0));
+    }
+#pragma unroll
+    for (int v = 0; v < NXV; ++v) {
+      const int m = m0 + xrow + v * XRP;
+      xv[v] = *(const u32x4*)(p.x + (m < p.M ? (size_t)m * p.x_ld + xcv * 8 : 0));
+    }
+  };
+  if (wg < p.ntiles) request(wg);
+
+  // ---- per-channel table (scale, shift, A, B, Cc), built while the first rows are in flight (conv_pw.hip BNB, bit for bit)
+  for (int ch = tid; ch < CO; ch += 256) {
+    double su = 0.0, suz = 0.0;
+#pragma unroll
+    for (int sl = 0; sl < PLYOLO_STAT_SLOTS; ++sl) {
+      su += p.bslots[((size_t)sl * 2 + 0) * CO + ch];
+      suz += p.bslots[((size_t)sl * 2 + 1) * CO + ch];
+    }
+    const float mean = p.coef[2 * CO + ch], invstd = p.coef[3 * CO + ch];
+    const bool sec = p.psplit > 0 && ch >= p.psplit;
+    const int cp = sec ? ch - p.psplit : ch;
+    const float* gam = sec ? p.gamma2 : p.gamma;
+    const double cnt = (double)p.M;
+    const float A = (gam ? gam[cp] : 1.f) * invstd;
+    const float B = (float)(-(double)A * (suz / cnt) * (double)invstd);
+    tab[ch] = p.coef[ch];
+    tab[CO + ch] = p.coef[CO + ch];
+    tab[2 * CO + ch] = A;
+    tab[3 * CO + ch] = B;
+    tab[4 * CO + ch] = (float)(-(double)A * (su / cnt) - (double)B * (double)mean);
+    if (wg == 0) {   // dbeta = sum du, dgamma = sum du*zhat (bn_act_bwd_dz publishes them from its workgroup 0)
+      float* db_ = sec ? p.dbeta2 : p.dbeta;
+      float* dg_ = sec ? p.dgamma2 : p.dgamma;
+      if (db_) db_[cp] = (float)su;
+      if (dg_) dg_[cp] = (float)suz;
+    }
+  }
+
+  // ---- data-gradient weights of this wave: 32 input channels x all CO, resident in registers
+  const int wm = wave / WN, wn = wave % WN;
+  u32x4 wq[KSD];
+  {
+    const char* wbase = (const char*)p.wpd + (size_t)(wn * KSD) * 1024u + (size_t)lane * 16u;
+#pragma unroll
+    for (int kk = 0; kk < KSD; ++kk) wq[kk] = *(const u32x4*)(wbase + (size_t)kk * 1024u);
+  }
+
+  // ---- weight-gradient accumulators of this wave
+  const int wk = wave / (WCO * WCI), wco = (wave / WCI) % WCO, wci = wave % WCI;
+  f32x16 accw[MTC][MTI];
+#pragma unroll
+  for (int a = 0; a < MTC; ++a)
+#pragma unroll
+    for (int b = 0; b < MTI; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) accw[a][b][i] = 0.f;
+
+  // transposed-read addresses: 16-lane group g = lane>>4 reads the block of rows k = 8*(g>>1) + {0..3} (+4 for the second
+  // read), columns 16*(g&1) .. +15 of a 32-channel fragment; lane 4q+pp of the group supplies row q, columns 4pp .. 4pp+3.
+  // Physical row of k inside the 16-pixel k-step: 4*(k&3) + (k>>2)  ->  4q + 2*(g>>1) (+1 for the second read)
+  const int g4 = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
+  const int trow = 4 * q + 2 * (g4 >> 1);
+  const int a_off = trow * PD + (wco * MTC * 32 + 16 * (g4 & 1) + 4 * pp) * 2;
+  const int b_off = trow * PX + (wci * MTI * 32 + 16 * (g4 & 1) + 4 * pp) * 2;
+  int arow[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) arow[mt] = ((wm * MT + mt) * 32 + r) * PD + h * 16;
+
+  __syncthreads();   // table complete
+
+  for (int tile = wg; tile < p.ntiles; tile += G_) {
+    const int m0 = tile * BM;
+    // ---- dz rows and x rows of this tile -> LDS
+    {
+      float sc[8], sh[8], A[8], B[8], Cc[8];
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) {
+        const f32x4 a0 = *(const f32x4*)(tab + dch + 4 * qq), a1 = *(const f32x4*)(tab + CO + dch + 4 * qq);
+        const f32x4 a2 = *(const f32x4*)(tab + 2 * CO + dch + 4 * qq), a3 = *(const f32x4*)(tab + 3 * CO + dch + 4 * qq);
+        const f32x4 a4 = *(const f32x4*)(tab + 4 * CO + dch + 4 * qq);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { sc[4 * qq + i] = a0[i]; sh[4 * qq + i] = a1[i]; A[4 * qq + i] = a2[i]; B[4 * qq + i] = a3[i]; Cc[4 * qq + i] = a4[i]; }
+      }
+      const u32x4 zero = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int v = 0; v < NDV; ++v) {
+        u32x4 t = av[v];
+        const u32x4 zz = zv[v];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float zl = __uint_as_float(zz[i] << 16), zh = __uint_as_float(zz[i] & 0xffff0000u);
+          const float dl = __uint_as_float(t[i] << 16), dh = __uint_as_float(t[i] & 0xffff0000u);
+          const float dul = dl * pb_act_grad(fmaf(zl, sc[2 * i], sh[2 * i]), p.act);
+          const float duh = dh * pb_act_grad(fmaf(zh, sc[2 * i + 1], sh[2 * i + 1]), p.act);
+          t[i] = pack2bf(fmaf(A[2 * i], dul, fmaf(B[2 * i], zl, Cc[2 * i])), fmaf(A[2 * i + 1], duh, fmaf(B[2 * i + 1], zh, Cc[2 * i + 1])));
+        }
+        const int row = drow + v * DRP;
+        *(u32x4*)(dz_s + row * PD + dcv * 16) = (m0 + row < p.M) ? t : zero;
+      }
+#pragma unroll
+      for (int v = 0; v < NXV; ++v) {
+        const int row = xrow + v * XRP;
+        *(u32x4*)(x_s + row * PX + xcv * 16) = (m0 + row < p.M) ? xv[v] : zero;
+      }
+    }
+    __syncthreads();                                   // B1: the tile's LDS image is complete
+    if (tile + G_ < p.ntiles) request(tile + G_);       // next tile's rows in flight during the MFMAs and the epilogue
+    __builtin_amdgcn_sched_barrier(0);                  // ... and issued ABOVE them
+
+    // ---- dx tile = dz . W
+    f32x16 accd[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) accd[mt][i] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < KSD; ++kk) {
+      const bf16x8 b = *(const bf16x8*)&wq[kk];
+      bf16x8 a[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) a[mt] = *(const bf16x8*)(dz_s + arow[mt] + kk * 32);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) accd[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b, accd[mt], 0, 0, 0);
+    }
+    // ---- dW += dz^T . x  (k = the tile's pixels, 16 per step; this wave takes steps wk, wk + WK, ...)
+#pragma unroll
+    for (int js = 0; js < KSW / WK; ++js) {
+      const int j = wk + js * WK;
+      s16x8 af[MTC], bfr[MTI];
+#pragma unroll
+      for (int a = 0; a < MTC; ++a) {
+        const unsigned char* ap = dz_s + j * 16 * PD + a_off + a * 64;
+        const s16x4 lo = tr_read_b(ap), hi = tr_read_b(ap + PD);
+        af[a] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int b = 0; b < MTI; ++b) {
+        const unsigned char* bp = x_s + j * 16 * PX + b_off + b * 64;
+        const s16x4 lo = tr_read_b(bp), hi = tr_read_b(bp + PX);
+        bfr[b] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int a = 0; a < MTC; ++a)
+#pragma unroll
+        for (int b = 0; b < MTI; ++b)
+          accw[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&af[a], *(const bf16x8*)&bfr[b], accw[a][b], 0, 0, 0);
+    }
+
+    // ---- dx tile -> staging (bf16, pixel-major) -> whole 16-byte channel vectors to HBM
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int m = (wm * MT + mt) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        *(bf16_t*)(stg + m * PX + (wn * 32 + r) * 2) = f2bf(accd[mt][i]);
+      }
+    __syncthreads();                                   // B2: staging complete; every wave is done with dz_s / x_s
+#pragma unroll
+    for (int v = 0; v < NXV; ++v) {
+      const int row = xrow + v * XRP;
+      if (m0 + row < p.M) {
+        u32x4 val = *(const u32x4*)(stg + row * PX + xcv * 16);
+        bf16_t* dst = p.dx + (size_t)(m0 + row) * p.dx_ld + xcv * 8;
+        if (p.accumulate) val = pb_add_bf16x8(*(const u32x4*)dst, val);
+        *(u32x4*)dst = val;
+      }
+    }
+    // (the next iteration writes dz_s / x_s, which every wave left before B2, and staging again only behind its B1)
+  }
+
+  // ---- private slab of this (workgroup, k-split wave): D[row = co][col = ci], col = lane & 31, row = (i&3) + 8*(i>>2) + 4*h
+  float* slab = p.dw + ((size_t)wg * WK + wk) * ((size_t)CO * CI);
+#pragma unroll
+  for (int b = 0; b < MTI; ++b) {
+    const int ci = (wci * MTI + b) * 32 + r;
+#pragma unroll
+    for (int a = 0; a < MTC; ++a)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int co = (wco * MTC + a) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        slab[(size_t)co * CI + ci] = accw[a][b][i];
+      }
+  }
+}
+
+// pixel-tile rows per channel count: bigger tiles for the narrow layers (their rows are short, a tile should still be a
+// few tens of KB of loads in flight)
+constexpr int pb_bm(int co, int ci) { return (co >= 128 || ci >= 128) ? 64 : 128; }
+
+template <int CO, int CI>
+hipError_t pb_launch_inst(const PbP& p, int G_, hipStream_t s) {
+  constexpr int BM = pb_bm(CO, CI);
+  using G = PbGeom<CO, CI, BM>;
+  auto kern = conv_pw_bwd_kernel<CO, CI, BM>;
+  if (hipError_t e = plyolo::ensure_dynamic_lds((const void*)kern, G::LDS); e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(G_), dim3(256), G::LDS, s, p);
+  return hipGetLastError();
+}
+
+struct PbPlan { int ok, bm, ntiles, G, WK; };
+
+PbPlan pb_plan(const plyolo_conv_desc* d) {
+  PbPlan w{};
+  const int co = d->Cout, ci = d->Cin;
+  const bool shape = (co == 32 || co == 64 || co == 128) && (ci == 32 || ci == 64 || ci == 128);
+  // instantiated: the square shapes and the 2:1 / 1:2 ones next to them
+  const bool inst = shape && (co == ci || co == 2 * ci || ci == 2 * co);
+  if (!inst) return w;
+  w.ok = 1;
+  w.bm = pb_bm(co, ci);
+  const size_t M = (size_t)d->N * d->H * d->W;
+  w.ntiles = (int)((M + w.bm - 1) / w.bm);
+  const int per_cu = getenv("PLYOLO_PWBWD_PER_CU") ? atoi(getenv("PLYOLO_PWBWD_PER_CU")) : 2;
+  int gmax = 256 * (per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu));
+  // every workgroup leaves a CO x CI fp32 slab: at most ~1/8 of the tensor bytes the launch moves
+  const double moved = (double)M * (2.0 * co + 2.0 * ci) * 2.0, slab = 4.0 * co * ci;
+  const double frac = getenv("PLYOLO_PWBWD_SLAB_FRAC") ? atof(getenv("PLYOLO_PWBWD_SLAB_FRAC")) : 0.125;
+  const int tco = co / 32, tci = ci / 32, nt = tco * tci;
+  w.WK = nt >= 4 ? 1 : 4 / nt;
+  const int g_budget = (int)(moved * frac / (slab * w.WK));
+  if (gmax > g_budget) gmax = g_budget;
+  if (gmax < 1) gmax = 1;
+  if (gmax > w.ntiles) gmax = w.ntiles;
+  const int rounds = (w.ntiles + gmax - 1) / gmax;
+  w.G = (w.ntiles + rounds - 1) / rounds;      // the same number of rounds with an even share per workgroup
+  if (const char* e = getenv("PLYOLO_PWBWD_G")) { const int v = atoi(e); if (v > 0) w.G = v < w.ntiles ? v : w.ntiles; }   // tests: forced grid
+  return w;
+}
+
+}  // namespace
+
+namespace plyolo {
+
+bool conv_pw_enabled();
+
+// 1 when plyolo_conv2d_bwd_pw covers this unit: bf16 pointwise stride-1, a cheap activation, Cout and Cin in {32, 64, 128}
+// (square or 2:1), and an output gradient of at least PLYOLO_PWBWD_MIN_MB (the small maps' launches are latency-bound and
+// their slabs would outweigh the tensors)
+int conv_pw_bwd_fits(const plyolo_conv_desc* d, int act) {
+  if (!conv_pw_enabled() || d->dtype != PLYOLO_BF16 || d->ksize != 1 || d->stride != 1) return 0;
+  if (act < PLYOLO_ACT_NONE || act > PLYOLO_ACT_LRELU) return 0;
+  const double min_mb = getenv("PLYOLO_PWBWD_MIN_MB") ? atof(getenv("PLYOLO_PWBWD_MIN_MB")) : 12.0;
+  if ((double)d->N * d->H * d->W * d->Cout * 2.0 < min_mb * 1.0e6) return 0;
+  return pb_plan(d).ok;
+}
+
+int conv_pw_bwd_slabs(const plyolo_conv_desc* d) {
+  const PbPlan w = pb_plan(d);
+  return w.ok ? w.G * w.WK : 0;
+}
+
+int conv_pw_bwd(const plyolo_conv_desc* d, const plyolo_bn_bwd_fuse* f, const void* x, const void* wpd, void* dx, int accumulate,
+                float* dwp, void* stream) {
+  const PbPlan w = pb_plan(d);
+  PbP p{};
+  p.dout = (const bf16_t*)f->dout; p.dout_ld = f->dout_ld;
+  p.dout2 = (const bf16_t*)f->dout2; p.dout2_ld = f->dout2_ld; p.dsplit = f->dout2 ? f->dout_split : 0;
+  p.z = (const bf16_t*)f->z; p.z_ld = f->z_ld;
+  p.x = (const bf16_t*)x; p.x_ld = d->x_ld;
+  p.wpd = (const bf16_t*)wpd;
+  p.dx = (bf16_t*)dx; p.dx_ld = d->x_ld;       // the gradient matrix of x mirrors x (same pitch)
+  p.dw = dwp;
+  p.coef = f->coef; p.bslots = f->bslots;
+  p.gamma = f->gamma; p.dgamma = f->dgamma; p.dbeta = f->dbeta;
+  p.psplit = f->par_split; p.gamma2 = f->gamma2; p.dgamma2 = f->dgamma2; p.dbeta2 = f->dbeta2;
+  p.M = d->N * d->H * d->W;
+  p.ntiles = w.ntiles;
+  p.act = f->act;
+  p.accumulate = accumulate;
+  const int co = d->Cout, ci = d->Cin, G_ = w.G;
+  {
+    char lab[64];
+    snprintf(lab, sizeof(lab), "conv_pw_bwd<%dx%d>", co, ci);
+    annotate(lab, 4.0 * p.M * (double)co * ci, (double)p.M * (2.0 * co + ci * (accumulate ? 3.0 : 2.0)) * 2.0 + 4.0 * co * ci);
+  }
+  return submit(stream, [=](hipStream_t s) -> hipError_t {
+#define PB_CASE(a, b) if (co == a && ci == b) return pb_launch_inst<a, b>(p, G_, s);
+    PB_CASE(32, 32) PB_CASE(64, 64) PB_CASE(128, 128)
+    PB_CASE(64, 32) PB_CASE(32, 64) PB_CASE(128, 64) PB_CASE(64, 128)
+#undef PB_CASE
+    return hipErrorInvalidValue;
+  });
+}
+
+}  // namespace plyolo

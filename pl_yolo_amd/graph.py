@@ -123,6 +123,10 @@ class Graph:
         # measurable change of the step time (profiles/r03_ab_bn_fusion.txt), 2 % slower on YOLOX-x at 1280x1280 without its size limit
         self.fuse_bnbwd = os.environ.get("PLYOLO_FUSE_BNBWD", "0") == "1"
         self.fwd_res_in_dz = os.environ.get("PLYOLO_RES_IN_DZ", "1") == "1"    # A/B switch: 0 = a copy_add launch per shortcut
+        # PLYOLO_FUSE_PWBWD (default on, round 4): the whole backward of a large-map pointwise unit behind its BatchNorm reduction --
+        # dz, data gradient and weight gradient -- is ONE persistent launch (plyolo_conv2d_bwd_pw): dout, z and x are read once, dz
+        # never reaches HBM, the bn_act_bwd_dz pass and the 1x1 weight-gradient launch of those units disappear
+        self.fuse_pwbwd = os.environ.get("PLYOLO_FUSE_PWBWD", "1") == "1" and dtype == BF16 and training
         self.lazy_acts = os.environ.get("PLYOLO_LAZY", "0") in ("1", "2") and training
         # PLYOLO_LAZY=2: selective -- only where EVERY reader is a pointwise (1x1 stride-1) convolution: those kernels (and their
         # 1x1 weight gradients) are HBM-bound with an idle VALU, and there is no halo to re-pay the activation on
@@ -256,6 +260,16 @@ class Graph:
                 fn()
             plan.lane(l)
             self.pending[l] = []
+
+    def pw_bwd_slabs(self, desc, act, ok=True):
+        """Private weight-gradient slabs of plyolo_conv2d_bwd_pw for this unit, or 0 when the unit keeps the separate
+        dz / data-gradient / weight-gradient launches (not covered, switched off, lazy inputs in play)."""
+        if not (ok and self.fuse_pwbwd and not self.lazy_acts and not self.fuse_bnbwd):
+            return 0
+        lib = _lib.lib()
+        if lib.plyolo_conv2d_bwd_pw_fits(C.byref(desc), act) != 1:
+            return 0
+        return max(lib.plyolo_conv2d_bwd_pw_slabs(C.byref(desc)), 0)
 
     def dz_buffer(self, op, elems):
         """dz scratch of one conv unit's backward.  With lanes every unit owns its buffer (the weight-gradient
@@ -742,6 +756,10 @@ class ConvUnitOp:
         self.Cout = Cout
         self.desc = conv_desc(g, x.N, x.H, x.W, self.Cin_p, Cout, k, stride, self.Cin_p, Cout)
         self.pc.set_slabs(self.desc)
+        # whole backward in one launch (pointwise units of the large maps): its slab count replaces the weight-gradient kernel's
+        self.pw_slabs = g.pw_bwd_slabs(self.desc, self.act, bn is not None and need_dgrad and conv_b is None)
+        if self.pw_slabs:
+            self.pc.nslab = self.pw_slabs
         g.scratch_elems = max(g.scratch_elems, self.z.rows * Cout)
         g.add_op(self)
 
@@ -818,11 +836,12 @@ class ConvUnitOp:
         M, Cout = self.out.M, self.Cout
         dout, zt = g.gptr(self.out), self.z.tensor.data_ptr()
         plan, lanes, me = g.plan, g.use_lanes, self.lane
-        dz, key = g.dz_buffer(self, M * Cout)
+        pw_one = bool(self.pw_slabs)          # dz + data gradient + weight gradient in one launch (plyolo_conv2d_bwd_pw)
+        dz, key = (None, None) if pw_one else g.dz_buffer(self, M * Cout)
         fused = False
         # the shortcut's share of the gradient (network_blocks.py:89-90): forwarded by the bn_act_bwd_dz pass that reads dout anyway;
         # units without that pass (no BatchNorm, fused pointwise path) copy it with a launch of its own
-        res_in_dz = (self.res is not None and bn is not None and g.fwd_res_in_dz
+        res_in_dz = (self.res is not None and bn is not None and g.fwd_res_in_dz and not pw_one
                      and not (g.fuse_bnbwd and self.need_dgrad and _lib.lib().plyolo_conv2d_dgrad_bn_fits(C.byref(self.desc_d), self.act) == 1))
         if self.res is not None:
             acc_res = g.grad_mode(self.res)
@@ -834,6 +853,19 @@ class ConvUnitOp:
         else:
             bslots = g.bstat_arena.data_ptr() + self.slot_off * 8
             call("plyolo_bn_act_bwd_reduce", g.dtype, M, Cout, dout, self.out.ld, zt, Cout, self.coef.data_ptr(), self.act, bslots, None, None)
+            if pw_one:
+                f = BnBwdFuse()
+                f.dout, f.dout_ld, f.z, f.z_ld, f.coef, f.bslots = dout, self.out.ld, zt, Cout, self.coef.data_ptr(), bslots
+                f.gamma, f.dgamma, f.dbeta = ptr(bn.weight), g.grad_ptr_of(bn.weight), g.grad_ptr_of(bn.bias)
+                f.act = self.act
+                self.keep_f = f
+                acc = g.grad_mode(self.x)
+                call("plyolo_conv2d_bwd_pw", C.byref(self.desc_d), C.byref(f), self.xptr, self.pc.wpd, g.gptr(self.x), acc, self.pc.dwp, None)
+                if lanes:     # only the slab fold is left for the weight-gradient lane
+                    g.defer_param_grads(me, self.pc.reduce_slabs)
+                else:
+                    self.pc.reduce_slabs()
+                return
             # pointwise units: dz is formed inside the data gradient's loader (one launch and one pass over dout / z less)
             fused = g.fuse_bnbwd and self.need_dgrad and _lib.lib().plyolo_conv2d_dgrad_bn_fits(C.byref(self.desc_d), self.act) == 1
             if fused:
@@ -903,6 +935,9 @@ class ConvPairOp:
         g.storages.append(self.z)
         self.desc = conv_desc(g, x.N, x.H, x.W, Cin, self.Cout, k, stride, Cin, self.Cout)
         self.pc.set_slabs(self.desc)
+        self.pw_slabs = g.pw_bwd_slabs(self.desc, self.act)
+        if self.pw_slabs:
+            self.pc.nslab = self.pw_slabs
         g.scratch_elems = max(g.scratch_elems, self.z.rows * self.Cout)
         self.need_dgrad, self.bn, self.res = True, bn_a, None
         g.add_op(self)
@@ -961,6 +996,21 @@ class ConvPairOp:
         call("plyolo_bn_act_bwd_reduce", g.dtype, M, Cout, g.gptr(self.out_a), self.out_a.ld, zt, Cout, self.coef.data_ptr(), self.act,
              bslots, C.byref(dsp), None)
         plan, lanes, me = g.plan, g.use_lanes, self.lane
+        if self.pw_slabs:    # pointwise pair (CSP conv1 || conv2) of a large map: dz + data gradient + weight gradient in one launch
+            f = BnBwdFuse()
+            f.dout, f.dout_ld, f.dout2, f.dout2_ld, f.dout_split = g.gptr(self.out_a), self.out_a.ld, dsp.p2, dsp.ld2, self.Ca
+            f.z, f.z_ld, f.coef, f.bslots = zt, Cout, self.coef.data_ptr(), bslots
+            f.gamma, f.dgamma, f.dbeta = ptr(a.weight), g.grad_ptr_of(a.weight), g.grad_ptr_of(a.bias)
+            f.par_split, f.gamma2, f.dgamma2, f.dbeta2 = self.Ca, ptr(b.weight), g.grad_ptr_of(b.weight), g.grad_ptr_of(b.bias)
+            f.act = self.act
+            self.keep_f = f
+            acc = g.grad_mode(self.x)
+            call("plyolo_conv2d_bwd_pw", C.byref(self.desc_d), C.byref(f), self.xptr, self.pc.wpd, g.gptr(self.x), acc, self.pc.dwp, None)
+            if lanes:
+                g.defer_param_grads(me, self.pc.reduce_slabs)
+            else:
+                self.pc.reduce_slabs()
+            return
         dz, key = g.dz_buffer(self, M * Cout)
         fused = g.fuse_bnbwd and _lib.lib().plyolo_conv2d_dgrad_bn_fits(C.byref(self.desc_d), self.act) == 1
         if fused:    # pointwise pair (CSP conv1 || conv2): dz is formed inside the data gradient's loader

@@ -310,3 +310,94 @@ def test_pointwise_dgrad_with_fused_bn_backward(shape, act):
         for u, v in ((dg0, dg1), (db0, db1), (dg0b, dg1b), (db0b, db1b)):
             assert torch.equal(u, v)
         assert float(dz1.float().abs().max()) > 0
+
+
+# (N, H, W, Cin, Cout, split): pointwise units of the shapes plyolo_conv2d_bwd_pw instantiates; 3x20x20 and 1x13x9 end in a ragged pixel tile
+PWBWD_SHAPES = [(2, 40, 40, 128, 128, 0), (3, 20, 20, 64, 64, 0), (2, 40, 40, 64, 64, 32), (1, 13, 9, 32, 32, 8), (2, 24, 24, 64, 128, 0),
+                (2, 24, 24, 128, 64, 64), (1, 40, 40, 32, 64, 0), (1, 40, 40, 64, 32, 0)]
+
+
+@pytest.mark.parametrize("shape", PWBWD_SHAPES, ids=str)
+@pytest.mark.parametrize("act", ["silu", "lrelu", None])
+@pytest.mark.parametrize("grid", [0, 3])
+def test_pointwise_unit_backward_in_one_launch(shape, act, grid, monkeypatch):
+    """plyolo_conv2d_bwd_pw == plyolo_bn_act_bwd_dz + plyolo_conv2d_dgrad + plyolo_conv2d_wgrad: dx, dgamma, dbeta bit for bit (same dz
+    bits, same MFMA order), the weight gradient up to the order of its fp32 sums and against torch's fp32 matmul of the SAME dz;
+    merged pairs (output gradient in two matrices, two BatchNorm parameter sets), accumulation into dx, ragged last tile, a grid of
+    three persistent workgroups (many tiles per workgroup) and the planned one."""
+    from pl_yolo_amd._lib import ACT, BnBwdFuse, Split, BnBwdSplit, STAT_SLOTS
+    monkeypatch.setenv("PLYOLO_PWBWD_MIN_MB", "0")
+    if grid:
+        monkeypatch.setenv("PLYOLO_PWBWD_G", str(grid))
+    N, H, W, Cin, Cout, split = shape
+    dt, M = BF16, N * H * W
+    torch.manual_seed(sum(shape) + 5)
+    dev = hu.DEV
+    w = hu.rnd_bf16(torch.randn(Cout, Cin, 1, 1, device=dev) / Cout ** 0.5)
+    pk = hu.Packed(w, dt)
+    z = (torch.randn(M, Cout, device=dev) * 1.5).to(torch.bfloat16)
+    Ca = split if split else Cout
+    d_ld = Ca + 8
+    dout = torch.randn(M, d_ld, device=dev).to(torch.bfloat16)
+    dout2 = torch.randn(M, Cout - Ca + 16, device=dev).to(torch.bfloat16) if split else None
+    gamma, gamma2 = torch.rand(Cout, device=dev) + 0.5, torch.rand(Cout, device=dev) + 0.5
+    mean, invstd = torch.randn(Cout, device=dev) * 0.1, torch.rand(Cout, device=dev) + 0.5
+    beta = torch.randn(Cout, device=dev) * 0.1
+    g_eff = torch.cat([gamma[:Ca], gamma2[:Cout - Ca]]) if split else gamma
+    scale = g_eff * invstd
+    coef = torch.cat([scale, beta - mean * scale, mean, invstd]).contiguous()
+    bslots = torch.zeros(STAT_SLOTS * 2 * Cout, dtype=torch.float64, device=dev)
+    sp = Split()
+    if split:
+        sp.split, sp.p2, sp.ld2 = Ca, dout2.data_ptr(), dout2.shape[1]
+    a = ACT[act]
+    call("plyolo_bn_act_bwd_reduce", dt, M, Cout, dout.data_ptr(), d_ld, z.data_ptr(), Cout, coef.data_ptr(), a, bslots.data_ptr(),
+         C.byref(sp) if split else None, hu.stream())
+    x_ld = Cin + 8
+    xm = torch.randn(M, x_ld, device=dev).to(torch.bfloat16)
+    d = hu.conv_desc(dt, N, H, W, Cin, Cout, 1, 1, x_ld, Cout)
+    lib = hu._lib.lib()
+    assert lib.plyolo_conv2d_bwd_pw_fits(C.byref(d), a) == 1
+    base = torch.randn(M, x_ld, device=dev).to(torch.bfloat16)
+    for acc in (0, 1):
+        # reference: the three separate launches
+        dz0 = torch.zeros(M, Cout, dtype=torch.bfloat16, device=dev)
+        dg0, db0, dg0b, db0b = (torch.zeros(Cout, device=dev) for _ in range(4))
+        p2 = BnBwdSplit()
+        if split:
+            p2.split, p2.gamma2, p2.dgamma2, p2.dbeta2 = Ca, gamma2.data_ptr(), dg0b.data_ptr(), db0b.data_ptr()
+        call("plyolo_bn_act_bwd_dz", dt, M, Cout, dout.data_ptr(), d_ld, z.data_ptr(), Cout, coef.data_ptr(), bslots.data_ptr(), gamma.data_ptr(),
+             dg0.data_ptr(), db0.data_ptr(), 0, a, dz0.data_ptr(), Cout, C.byref(sp) if split else None, C.byref(p2) if split else None, hu.stream())
+        dx0 = base.clone()
+        call("plyolo_conv2d_dgrad", C.byref(d), dz0.data_ptr(), pk.wpd.data_ptr(), dx0.data_ptr(), acc, hu.stream())
+        pk0 = hu.Packed(w, dt)
+        pk0.set_slabs(d)
+        call("plyolo_conv2d_wgrad", C.byref(d), xm.data_ptr(), dz0.data_ptr(), pk0.dwp.data_ptr(), hu.stream())
+        dw0 = pk0.unpack().clone()
+        # one launch
+        ns = lib.plyolo_conv2d_bwd_pw_slabs(C.byref(d))
+        assert ns >= 1 and (not grid or ns % grid == 0)
+        pk1 = hu.Packed(w, dt, nslab=ns)
+        pk1.entry.nslab = ns
+        pk1.table = torch.frombuffer(bytearray(bytes((type(pk1.entry) * 1)(pk1.entry))), dtype=torch.uint8).to(dev)
+        pk1.dwp.fill_(float("nan"))       # every slab element must be written
+        dg1, db1, dg1b, db1b = (torch.zeros(Cout, device=dev) for _ in range(4))
+        f = BnBwdFuse()
+        f.dout, f.dout_ld, f.z, f.z_ld, f.coef, f.bslots = dout.data_ptr(), d_ld, z.data_ptr(), Cout, coef.data_ptr(), bslots.data_ptr()
+        if split:
+            f.dout2, f.dout2_ld, f.dout_split = dout2.data_ptr(), dout2.shape[1], Ca
+            f.par_split, f.gamma2, f.dgamma2, f.dbeta2 = Ca, gamma2.data_ptr(), dg1b.data_ptr(), db1b.data_ptr()
+        f.gamma, f.dgamma, f.dbeta, f.act = gamma.data_ptr(), dg1.data_ptr(), db1.data_ptr(), a
+        dx1 = base.clone()
+        call("plyolo_conv2d_bwd_pw", C.byref(d), C.byref(f), xm.data_ptr(), pk.wpd.data_ptr(), dx1.data_ptr(), acc, pk1.dwp.data_ptr(), hu.stream())
+        dw1 = pk1.unpack().clone()
+        torch.cuda.synchronize()
+        assert torch.equal(dx0[:, :Cin].view(torch.int16), dx1[:, :Cin].view(torch.int16)), "dx differs"
+        assert torch.equal(dx1[:, Cin:], base[:, Cin:]), "pad columns of dx touched"
+        for u, v in ((dg0, dg1), (db0, db1), (dg0b, dg1b), (db0b, db1b)):
+            assert torch.equal(u, v)
+        ref = (dz0.float().t() @ xm[:, :Cin].float()).view(Cout, Cin, 1, 1)
+        e0, e1 = hu.relerr(dw0, ref), hu.relerr(dw1, ref)
+        print("pw_bwd", shape, act, "acc", acc, "slabs", ns, "dW relerr separate %.3g fused %.3g" % (e0, e1))
+        assert torch.isfinite(dw1).all() and e1 <= 1e-4 and hu.relerr(dw1, dw0) <= 1e-4
+        assert float(dx1.float().abs().max()) > 0

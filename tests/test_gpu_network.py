@@ -569,6 +569,54 @@ def test_warm_yolox_s_bf16_end_to_end():
     assert allc >= 0.9995 and worst_cos >= 0.995 and allr <= 2e-2 and worst_norm <= 3e-2   # measured 0.99998 / 0.99969 / 0.0067 / 0.0104
 
 
+def _warm_s_step(env):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        g, model = _warm_s_model("bf16")
+        x, labels = torch.from_numpy(g["x"]).to(hu.DEV), torch.from_numpy(g["labels"]).to(hu.DEV)
+        out = model(x, labels)
+        out["loss"].backward()
+        torch.cuda.synchronize()
+        sess = [s for k, s in model.runner().sessions.items() if k[4] == "train"][0]
+        n_one = sum(1 for op in sess.g.ops if getattr(op, "pw_slabs", 0))
+        return g, model, {k: float(out[k]) for k in ("loss", "loss_iou", "loss_obj", "loss_cls")}, n_one
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_warm_yolox_s_bf16_pointwise_backward_in_one_launch():
+    """plyolo_conv2d_bwd_pw (dz + data gradient + weight gradient of a pointwise unit in one persistent launch; on the benchmarked
+    640x640 batch the 160x160 / 80x80 units take it) forced onto EVERY covered unit of yolox_s at the fixture's 160x160 input
+    (PLYOLO_PWBWD_MIN_MB=0): against the plan with the separate launches -- same losses, data-gradient chain bit-identical, so every
+    gradient that is not one of the fused units' own weight gradients is unchanged and those agree to the order of their fp32 sums
+    -- and against the REFERENCE's step with the bounds of test_warm_yolox_s_bf16_end_to_end."""
+    g, m0, l0, n0 = _warm_s_step({"PLYOLO_FUSE_PWBWD": "0"})
+    _, m1, l1, n1 = _warm_s_step({"PLYOLO_FUSE_PWBWD": "1", "PLYOLO_PWBWD_MIN_MB": "0"})
+    assert n0 == 0 and n1 >= 15, (n0, n1)
+    assert l0 == l1, (l0, l1)
+    p0, p1 = dict(m0.named_parameters()), dict(m1.named_parameters())
+    nexact = 0
+    for n in p0:
+        if p0[n].grad is None:
+            continue
+        a, b = p0[n].grad, p1[n].grad
+        if torch.equal(a, b):
+            nexact += 1
+            continue
+        assert n.endswith("conv.weight") and a.shape[2] == 1, n      # only pointwise weight gradients may differ at all
+        assert float((a - b).abs().max()) <= 2e-5 * max(float(a.abs().max()), 1e-6), n
+    print("pointwise backward in one launch: %d units, %d gradient tensors bit-identical to the separate launches" % (n1, nexact))
+    for k in ("loss", "loss_iou", "loss_obj", "loss_cls"):
+        assert abs(l1[k] - float(g["out/" + k])) <= 2e-3 * max(1.0, abs(float(g["out/" + k]))), k
+    allc, allr, worst_rms, worst_cos, worst_norm = _fixture_grad_checks("warm yolox_s bf16, pointwise backward in one launch, vs reference fp32", m1, g)
+    assert allc >= 0.9995 and worst_cos >= 0.995 and allr <= 2e-2 and worst_norm <= 3e-2
+
+
 def test_warm_yolox_s_bf16_gradients_vs_emulating_oracle():
     """labels=None path on the warm yolox_s weights, fixed upstream gradients: every HIP bf16 parameter gradient against the
     bf16-emulating oracle (replaces the random-init comparison whose bound was 0.95 / 0.9)."""
