@@ -358,9 +358,10 @@ def main():
             pb = s.bwd.profile(st)
             if rep:  # first pass warms caches
                 prof.append(pf + pb)
+                n_fwd_launches = len(pf)
         agg = {}
         for run in prof:
-            for (label, ms, fl, by) in run:
+            for (label, ms, fl, by, _lane) in run:
                 a = agg.setdefault(label, [0, 0.0, 0.0, 0.0])
                 a[0] += 1; a[1] += ms; a[2] += fl; a[3] += by
         nrep = len(prof)
@@ -405,10 +406,10 @@ def main():
         if args.profile_out:
             os.makedirs(os.path.dirname(os.path.abspath(args.profile_out)), exist_ok=True)
             with open(args.profile_out, "w") as f:
-                nf = s.fwd.size()
-                ops = [[("fwd" if i < nf else "bwd"), l, sum(r[i][1] for r in prof) / nrep, fl, by] for i, (l, _, fl, by) in enumerate(prof[0])]
+                nf = n_fwd_launches
+                ops = [[("fwd" if i < nf else "bwd"), l, sum(r[i][1] for r in prof) / nrep, fl, by, ln] for i, (l, _, fl, by, ln) in enumerate(prof[0])]
                 json.dump({"columns": ["kernel", "launches", "total_ms", "algo_flops", "algo_bytes"], "rows": table,
-                           "sum_ms": total_ms, "ops_columns": ["plan", "kernel", "ms", "algo_flops", "algo_bytes"], "ops": ops}, f, indent=1)
+                           "sum_ms": total_ms, "ops_columns": ["plan", "kernel", "ms", "algo_flops", "algo_bytes", "lane"], "ops": ops}, f, indent=1)
         result = {
             "metric": ("images/sec fwd+bwd YOLOX-s 640x640 bs32" if (args.model, args.size, args.batch) == ("yolox_s", 640, 32)
                        else "images/sec fwd+bwd %s %dx%d bs%d" % (args.model, args.size, args.size, args.batch)),

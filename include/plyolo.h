@@ -93,6 +93,8 @@ int plyolo_plan_graph_launch(plyolo_plan*, void* stream);
  * kernel label and its ALGORITHMIC flops / HBM bytes (what roofline.achieved is priced on). */
 int plyolo_plan_profile(plyolo_plan*, void* stream, float* ms_out, int n);
 int plyolo_plan_op_info(const plyolo_plan*, int i, char* label, int label_cap, double* flops, double* bytes);
+/* launch lane of recorded op i (plyolo_plan_lane at record time), or a negative code */
+int plyolo_plan_op_lane(const plyolo_plan*, int i);
 /* Measurement aid for multi-lane plans: one eager multi-stream replay; ms_out[l] = time from the start of the
  * replay to the end of lane l's last launch (l < lanes), ms_out[lanes] = to the join.  Synchronises the stream. */
 int plyolo_plan_lane_times(plyolo_plan*, void* stream, float* ms_out, int n);

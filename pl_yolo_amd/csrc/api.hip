@@ -389,6 +389,12 @@ int plyolo_plan_op_info(const plyolo_plan* p, int i, char* label, int label_cap,
   return 0;
 }
 
+int plyolo_plan_op_lane(const plyolo_plan* p, int i) {
+  const Plan* q = (const Plan*)p;
+  PLY_CHECK_ARG(q && i >= 0 && i < (int)q->ops.size(), "plan_op_lane: bad index");
+  return q->ops[i].lane;
+}
+
 // ---- RCCL: the gradient exchange of one bucket through the C ABI.  The communicator belongs to the host
 // (ncclCommInitRank over the xGMI ring); the library resolves ncclAllReduce at run time from the RCCL the process already
 // uses (or from the path given to plyolo_rccl_set_library), so libplyolo_hip.so carries no link-time RCCL dependency.

@@ -74,28 +74,33 @@ DEVINL u32x4 pb_add_bf16x8(u32x4 a, u32x4 b) {
 
 constexpr int pb_min(int a, int b) { return a < b ? a : b; }
 
+constexpr int NW = 8, NT = NW * 64;     // eight waves per workgroup, ONE workgroup per CU (two waves per SIMD)
+
 template <int CO, int CI, int BM> struct PbGeom {
   // data gradient: dx tile [BM][CI], wave (wm, wn) owns 32 input channels x MT 32-row fragments
-  static constexpr int WN = CI / 32 >= 4 ? 4 : CI / 32, WM = 4 / WN, MT = BM / (32 * WM);
+  static constexpr int WN = pb_min(CI / 32, 4), WM = NW / WN, MT = BM / (32 * WM);
   static constexpr int KSD = CO / 16;                  // k-steps of the data gradient (contraction over CO)
-  // weight gradient: dW [CO][CI] in 32x32 tiles over the four waves; fewer than four tiles -> the waves split the k-steps
+  // weight gradient: dW [CO][CI] in 32x32 tiles over the eight waves; fewer than eight tiles -> wave groups split the k-steps
   static constexpr int TCO = CO / 32, TCI = CI / 32;
-  static constexpr int WCO = pb_min(TCO, TCI >= 2 ? 2 : 4), WCI = pb_min(TCI, 4 / WCO), WK = 4 / (WCO * WCI);
+  static constexpr int WCI = pb_min(TCI, 4), WCO = pb_min(TCO, NW / WCI), WK = NW / (WCO * WCI);
   static constexpr int MTC = TCO / WCO, MTI = TCI / WCI;
   static constexpr int KSW = BM / 16;                  // k-steps of the weight gradient per tile (contraction over pixels)
   static constexpr int PD = CO * 2 + 16, PX = CI * 2 + 16;   // LDS row pitches (bytes)
   static constexpr int DV = CO / 8, XV = CI / 8;       // 16-byte vectors per row
-  static constexpr int NDV = BM * DV / 256, NXV = BM * XV / 256;   // vectors per thread and tile
+  static constexpr int NDV = BM * DV / NT, NXV = BM * XV / NT;   // vectors per thread and tile
   static constexpr int DZ_BYTES = BM * PD, X_BYTES = BM * PX, STG_BYTES = BM * PX;
   static constexpr int TAB_OFF = DZ_BYTES + X_BYTES + STG_BYTES;
   static constexpr int LDS = TAB_OFF + 5 * CO * 4;
   static_assert(MT >= 1 && BM % (32 * WM) == 0, "tile rows vs wave layout");
-  static_assert(WCO * WCI * WK == 4 && KSW % WK == 0, "four waves");
-  static_assert(256 % DV == 0 && 256 % XV == 0 && (BM * DV) % 256 == 0 && (BM * XV) % 256 == 0, "whole vectors per thread");
+  static_assert(WCO * WCI * WK == NW && KSW % WK == 0 && MTC >= 1 && MTI >= 1, "eight waves");
+  static_assert(NT % DV == 0 && NT % XV == 0 && (BM * DV) % NT == 0 && (BM * XV) % NT == 0, "whole vectors per thread");
+  static_assert((WK - 1) * WCO * WCI * MTC * MTI * 4096 <= DZ_BYTES + X_BYTES + STG_BYTES, "k-split partials fit in LDS");
 };
 
-template <int CO, int CI, int BM>
-__global__ __launch_bounds__(256, 2) void conv_pw_bwd_kernel(const PbP p) {
+// ACT: PLYOLO_ACT_SILU = the compile-time SiLU instance every shipped config runs (straight-line staging code: a switch on a run-time
+// activation inside the unrolled element loops compiles to a branch per element); -1 = the activation is p.act (none / relu / lrelu)
+template <int CO, int CI, int BM, int ACT>
+__global__ __launch_bounds__(NT, 1) void conv_pw_bwd_kernel(const PbP p) {
   using G = PbGeom<CO, CI, BM>;
   constexpr int WN = G::WN, WM = G::WM, MT = G::MT, KSD = G::KSD;
   constexpr int WCO = G::WCO, WCI = G::WCI, WK = G::WK, MTC = G::MTC, MTI = G::MTI, KSW = G::KSW;
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_bwd_kernel(const PbP p) {
   const int G_ = (int)gridDim.x, wg = (int)blockIdx.x;
 
   // ---- per-thread staging geometry (tile-invariant): vector v of the dz / x image = row drow + v*DRP, channel vector dcv
-  constexpr int DRP = 256 / DV, XRP = 256 / XV;
+  constexpr int DRP = NT / DV, XRP = NT / XV;
   const int dcv = tid % DV, drow = tid / DV;
   const int xcv = tid % XV, xrow = tid / XV;
   const int dch = dcv * 8;
@@ -119,26 +124,40 @@ __global__ __launch_bounds__(256, 2) void conv_pw_bwd_kernel(const PbP p) {
   const bf16_t* dsrc = second ? p.dout2 + (dch - p.dsplit) : p.dout + dch;
   const int dld = second ? p.dout2_ld : p.dout_ld;
 
-  u32x4 av[NDV], zv[NDV], xv[NXV];
-  auto request = [&](const int tile) {
+  // two register sets: while tile t is turned into its LDS image and multiplied, the rows of tiles t+G and t+2G are in flight
+  struct Rows { u32x4 av[NDV], zv[NDV], xv[NXV]; };
+  // Requests are UNCONDITIONAL (no branch around them): the compiler's vector-memory wait counts are exact only in straight-line
+  // code -- a load behind a branch makes every later wait for an OLDER load a wait for everything in flight, prefetch included.
+  // A tile index beyond the last tile (and a row beyond M) reads row 0 instead: one L2-resident row, never used.
+  auto request = [&](Rows& R, const int tile) {
     const int m0 = tile * BM;
 #pragma unroll
     for (int v = 0; v < NDV; ++v) {
-      const int m = m0 + drow + v * DRP;
-      const bool ok = m < p.M;
-      av[v] = *(const u32x4*)(ok ? dsrc + (size_t)m * dld : p.dout);
-      zv[v] = *(const u32x4*)(p.z + (ok ? (size_t)m * p.z_ld + dch : 0));
+      const int m = m0 + drow + v * DRP, mc = (tile < p.ntiles && m < p.M) ? m : 0;
+      R.av[v] = *(const u32x4*)(dsrc + (size_t)mc * dld);
+      R.zv[v] = *(const u32x4*)(p.z + (size_t)mc * p.z_ld + dch);
     }
 #pragma unroll
     for (int v = 0; v < NXV; ++v) {
-      const int m = m0 + xrow + v * XRP;
-      xv[v] = *(const u32x4*)(p.x + (m < p.M ? (size_t)m * p.x_ld + xcv * 8 : 0));
+      const int m = m0 + xrow + v * XRP, mc = (tile < p.ntiles && m < p.M) ? m : 0;
+      R.xv[v] = *(const u32x4*)(p.x + (size_t)mc * p.x_ld + xcv * 8);
     }
   };
-  if (wg < p.ntiles) request(wg);
+  Rows RA, RB;
 
-  // ---- per-channel table (scale, shift, A, B, Cc), built while the first rows are in flight (conv_pw.hip BNB, bit for bit)
-  for (int ch = tid; ch < CO; ch += 256) {
+  // ---- data-gradient weights of this wave: 32 input channels x all CO, resident in registers.  Requested first and pinned as
+  // "arrived" behind the table build: the vector-memory counter retires in order, so a wait for them inside the tile loop (where
+  // their first use is) would have to be written as "everything in flight has landed", prefetched rows included
+  const int wm = wave / WN, wn = wave % WN;
+  u32x4 wq[KSD];
+  {
+    const char* wbase = (const char*)p.wpd + (size_t)(wn * KSD) * 1024u + (size_t)lane * 16u;
+#pragma unroll
+    for (int kk = 0; kk < KSD; ++kk) wq[kk] = *(const u32x4*)(wbase + (size_t)kk * 1024u);
+  }
+
+  // ---- per-channel table (scale, shift, A, B, Cc) (conv_pw.hip BNB, bit for bit)
+  for (int ch = tid; ch < CO; ch += NT) {
     double su = 0.0, suz = 0.0;
 #pragma unroll
     for (int sl = 0; sl < PLYOLO_STAT_SLOTS; ++sl) {
@@ -165,14 +184,12 @@ __global__ __launch_bounds__(256, 2) void conv_pw_bwd_kernel(const PbP p) {
     }
   }
 
-  // ---- data-gradient weights of this wave: 32 input channels x all CO, resident in registers
-  const int wm = wave / WN, wn = wave % WN;
-  u32x4 wq[KSD];
-  {
-    const char* wbase = (const char*)p.wpd + (size_t)(wn * KSD) * 1024u + (size_t)lane * 16u;
 #pragma unroll
-    for (int kk = 0; kk < KSD; ++kk) wq[kk] = *(const u32x4*)(wbase + (size_t)kk * 1024u);
-  }
+  for (int kk = 0; kk < KSD; ++kk) asm volatile("" : "+v"(wq[kk]));
+  request(RA, wg);
+  __builtin_amdgcn_sched_barrier(0);   // set A's loads stay in front of set B's: the loop head waits for "all but set B" by count
+  request(RB, wg + G_);
+  __builtin_amdgcn_sched_barrier(0);
 
   // ---- weight-gradient accumulators of this wave
   const int wk = wave / (WCO * WCI), wco = (wave / WCI) % WCO, wci = wave % WCI;
@@ -197,9 +214,9 @@ __global__ __launch_bounds__(256, 2) void conv_pw_bwd_kernel(const PbP p) {
 
   __syncthreads();   // table complete
 
-  for (int tile = wg; tile < p.ntiles; tile += G_) {
+  // one tile: rows in R -> LDS image -> (R re-requested for tile + 2G) -> both products -> dx rows out
+  auto process = [&](Rows& R, const int tile) {
     const int m0 = tile * BM;
-    // ---- dz rows and x rows of this tile -> LDS
     {
       float sc[8], sh[8], A[8], B[8], Cc[8];
 #pragma unroll
@@ -212,29 +229,37 @@ __global__ __launch_bounds__(256, 2) void conv_pw_bwd_kernel(const PbP p) {
       }
       const u32x4 zero = {0u, 0u, 0u, 0u};
 #pragma unroll
+      for (int v = 0; v < NXV; ++v) {
+        const int row = xrow + v * XRP;
+        *(u32x4*)(x_s + row * PX + xcv * 16) = (m0 + row < p.M) ? R.xv[v] : zero;
+      }
+#pragma unroll
       for (int v = 0; v < NDV; ++v) {
-        u32x4 t = av[v];
-        const u32x4 zz = zv[v];
+        u32x4 t = R.av[v];
+        const u32x4 zz = R.zv[v];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float zl = __uint_as_float(zz[i] << 16), zh = __uint_as_float(zz[i] & 0xffff0000u);
           const float dl = __uint_as_float(t[i] << 16), dh = __uint_as_float(t[i] & 0xffff0000u);
-          const float dul = dl * pb_act_grad(fmaf(zl, sc[2 * i], sh[2 * i]), p.act);
-          const float duh = dh * pb_act_grad(fmaf(zh, sc[2 * i + 1], sh[2 * i + 1]), p.act);
+          const float dul = dl * pb_act_grad(fmaf(zl, sc[2 * i], sh[2 * i]), ACT >= 0 ? ACT : p.act);
+          const float duh = dh * pb_act_grad(fmaf(zh, sc[2 * i + 1], sh[2 * i + 1]), ACT >= 0 ? ACT : p.act);
           t[i] = pack2bf(fmaf(A[2 * i], dul, fmaf(B[2 * i], zl, Cc[2 * i])), fmaf(A[2 * i + 1], duh, fmaf(B[2 * i + 1], zh, Cc[2 * i + 1])));
         }
         const int row = drow + v * DRP;
         *(u32x4*)(dz_s + row * PD + dcv * 16) = (m0 + row < p.M) ? t : zero;
       }
-#pragma unroll
-      for (int v = 0; v < NXV; ++v) {
-        const int row = xrow + v * XRP;
-        *(u32x4*)(x_s + row * PX + xcv * 16) = (m0 + row < p.M) ? xv[v] : zero;
-      }
     }
-    __syncthreads();                                   // B1: the tile's LDS image is complete
-    if (tile + G_ < p.ntiles) request(tile + G_);       // next tile's rows in flight during the MFMAs and the epilogue
-    __builtin_amdgcn_sched_barrier(0);                  // ... and issued ABOVE them
+    __syncthreads();                                            // B1: the tile's LDS image is complete
+    // accumulating launches: the old dx rows are requested FIRST, so that the epilogue's wait for them does not cover the prefetch
+    // (unconditional like every request: a plain launch reads row 0 four times per tile and ignores it)
+    u32x4 oldx[NXV];
+#pragma unroll
+    for (int v = 0; v < NXV; ++v) {
+      const int m = m0 + xrow + v * XRP, mc = (p.accumulate && m < p.M) ? m : 0;
+      oldx[v] = *(const u32x4*)(p.dx + (size_t)mc * p.dx_ld + xcv * 8);
+    }
+    request(R, tile + 2 * G_);                                  // this register set is free again: the tile after next
+    __builtin_amdgcn_sched_barrier(0);                           // ... requested ABOVE the MFMAs
 
     // ---- dx tile = dz . W
     f32x16 accd[MT];
@@ -290,39 +315,78 @@ __global__ __launch_bounds__(256, 2) void conv_pw_bwd_kernel(const PbP p) {
       if (m0 + row < p.M) {
         u32x4 val = *(const u32x4*)(stg + row * PX + xcv * 16);
         bf16_t* dst = p.dx + (size_t)(m0 + row) * p.dx_ld + xcv * 8;
-        if (p.accumulate) val = pb_add_bf16x8(*(const u32x4*)dst, val);
+        if (p.accumulate) val = pb_add_bf16x8(oldx[v], val);
         *(u32x4*)dst = val;
       }
     }
-    // (the next iteration writes dz_s / x_s, which every wave left before B2, and staging again only behind its B1)
+    // (the next tile writes dz_s / x_s, which every wave left before B2, and staging again only behind its own B1)
+  };
+
+  // Pairs of tiles in the loop, an odd last tile behind it: every path to the loop head passes BOTH sets' requests, so the wait
+  // for set A at the head is "all but set B's loads" by count (with a conditional second tile inside the loop the compiler has to
+  // assume a back edge that issued nothing behind set A's request, and that wait becomes a wait for everything in flight)
+  int tile = wg;
+  for (; tile + G_ < p.ntiles; tile += 2 * G_) {
+    process(RA, tile);
+    process(RB, tile + G_);
+  }
+  if (tile < p.ntiles) process(RA, tile);
+
+  // ---- k-split wave groups (narrow layers): fold the partial accumulators of groups 1 .. WK-1 into group 0 through LDS
+  if constexpr (WK > 1) {
+    __syncthreads();                                   // the last tile's staging reads are done: LDS is free
+    float* part = (float*)smem;                        // [(wk-1)][wco][wci][MTC][MTI][16 regs][64 lanes]
+    if (wk > 0) {
+#pragma unroll
+      for (int a = 0; a < MTC; ++a)
+#pragma unroll
+        for (int b = 0; b < MTI; ++b)
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            part[((((size_t)(wk - 1) * WCO + wco) * WCI + wci) * MTC * MTI + a * MTI + b) * 1024 + i * 64 + lane] = accw[a][b][i];
+    }
+    __syncthreads();
+    if (wk == 0) {
+#pragma unroll
+      for (int k2 = 1; k2 < WK; ++k2)
+#pragma unroll
+        for (int a = 0; a < MTC; ++a)
+#pragma unroll
+          for (int b = 0; b < MTI; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+              accw[a][b][i] += part[((((size_t)(k2 - 1) * WCO + wco) * WCI + wci) * MTC * MTI + a * MTI + b) * 1024 + i * 64 + lane];
+    }
   }
 
-  // ---- private slab of this (workgroup, k-split wave): D[row = co][col = ci], col = lane & 31, row = (i&3) + 8*(i>>2) + 4*h
-  float* slab = p.dw + ((size_t)wg * WK + wk) * ((size_t)CO * CI);
+  // ---- private slab of this workgroup: D[row = co][col = ci], col = lane & 31, row = (i&3) + 8*(i>>2) + 4*h
+  if (wk == 0) {
+    float* slab = p.dw + (size_t)wg * ((size_t)CO * CI);
 #pragma unroll
-  for (int b = 0; b < MTI; ++b) {
-    const int ci = (wci * MTI + b) * 32 + r;
+    for (int b = 0; b < MTI; ++b) {
+      const int ci = (wci * MTI + b) * 32 + r;
 #pragma unroll
-    for (int a = 0; a < MTC; ++a)
+      for (int a = 0; a < MTC; ++a)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int co = (wco * MTC + a) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        slab[(size_t)co * CI + ci] = accw[a][b][i];
-      }
+        for (int i = 0; i < 16; ++i) {
+          const int co = (wco * MTC + a) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          slab[(size_t)co * CI + ci] = accw[a][b][i];
+        }
+    }
   }
 }
 
-// pixel-tile rows per channel count: bigger tiles for the narrow layers (their rows are short, a tile should still be a
-// few tens of KB of loads in flight)
-constexpr int pb_bm(int co, int ci) { return (co >= 128 || ci >= 128) ? 64 : 128; }
+// pixel-tile rows per channel count: bigger tiles for the narrow layers (their rows are short, a tile should still be several
+// tens of KB of loads in flight)
+constexpr int pb_bm(int co, int ci) { return (co >= 128 && ci >= 128) ? 64 : ((co >= 128 || ci >= 128) ? 128 : 256); }
 
 template <int CO, int CI>
 hipError_t pb_launch_inst(const PbP& p, int G_, hipStream_t s) {
   constexpr int BM = pb_bm(CO, CI);
   using G = PbGeom<CO, CI, BM>;
-  auto kern = conv_pw_bwd_kernel<CO, CI, BM>;
+  auto kern = p.act == PLYOLO_ACT_SILU ? conv_pw_bwd_kernel<CO, CI, BM, PLYOLO_ACT_SILU> : conv_pw_bwd_kernel<CO, CI, BM, -1>;
   if (hipError_t e = plyolo::ensure_dynamic_lds((const void*)kern, G::LDS); e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3(G_), dim3(256), G::LDS, s, p);
+  hipLaunchKernelGGL(kern, dim3(G_), dim3(NT), G::LDS, s, p);
   return hipGetLastError();
 }
 
@@ -339,13 +403,11 @@ PbPlan pb_plan(const plyolo_conv_desc* d) {
   w.bm = pb_bm(co, ci);
   const size_t M = (size_t)d->N * d->H * d->W;
   w.ntiles = (int)((M + w.bm - 1) / w.bm);
-  const int per_cu = getenv("PLYOLO_PWBWD_PER_CU") ? atoi(getenv("PLYOLO_PWBWD_PER_CU")) : 2;
-  int gmax = 256 * (per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu));
+  int gmax = 256;      // one 512-thread workgroup per CU
   // every workgroup leaves a CO x CI fp32 slab: at most ~1/8 of the tensor bytes the launch moves
   const double moved = (double)M * (2.0 * co + 2.0 * ci) * 2.0, slab = 4.0 * co * ci;
   const double frac = getenv("PLYOLO_PWBWD_SLAB_FRAC") ? atof(getenv("PLYOLO_PWBWD_SLAB_FRAC")) : 0.125;
-  const int tco = co / 32, tci = ci / 32, nt = tco * tci;
-  w.WK = nt >= 4 ? 1 : 4 / nt;
+  w.WK = 1;            // k-split wave groups fold their partial sums inside the kernel: one slab per workgroup
   const int g_budget = (int)(moved * frac / (slab * w.WK));
   if (gmax > g_budget) gmax = g_budget;
   if (gmax < 1) gmax = 1;
@@ -363,12 +425,13 @@ namespace plyolo {
 bool conv_pw_enabled();
 
 // 1 when plyolo_conv2d_bwd_pw covers this unit: bf16 pointwise stride-1, a cheap activation, Cout and Cin in {32, 64, 128}
-// (square or 2:1), and an output gradient of at least PLYOLO_PWBWD_MIN_MB (the small maps' launches are latency-bound and
-// their slabs would outweigh the tensors)
+// (square or 2:1), and an output gradient of at least PLYOLO_PWBWD_MIN_MB (default 20: below that the three separate launches are
+// as fast -- 13 MB: 28 us against 21 for dz + data gradient, 26 MB: 34 against 29, 52 MB: 47 against 60, 105 MB: 86 against 101 --
+// and the step, same box, three alternations: off 9.15 ms, >= 12 MB 9.01, >= 20 MB 8.99, >= 40 MB 9.00)
 int conv_pw_bwd_fits(const plyolo_conv_desc* d, int act) {
   if (!conv_pw_enabled() || d->dtype != PLYOLO_BF16 || d->ksize != 1 || d->stride != 1) return 0;
   if (act < PLYOLO_ACT_NONE || act > PLYOLO_ACT_LRELU) return 0;
-  const double min_mb = getenv("PLYOLO_PWBWD_MIN_MB") ? atof(getenv("PLYOLO_PWBWD_MIN_MB")) : 12.0;
+  const double min_mb = getenv("PLYOLO_PWBWD_MIN_MB") ? atof(getenv("PLYOLO_PWBWD_MIN_MB")) : 20.0;
   if ((double)d->N * d->H * d->W * d->Cout * 2.0 < min_mb * 1.0e6) return 0;
   return pb_plan(d).ok;
 }

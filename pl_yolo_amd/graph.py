@@ -1786,7 +1786,7 @@ class Plan:
         for i in range(n):
             call("plyolo_plan_op_info", self.h, i, buf, 96, C.byref(fl), C.byref(by))
             if buf.value not in (b"record", b"wait"):   # ordering markers, not launches
-                out.append((buf.value.decode(), float(ms[i]), fl.value, by.value))
+                out.append((buf.value.decode(), float(ms[i]), fl.value, by.value, _lib.lib().plyolo_plan_op_lane(self.h, i)))
         return out
 
     def lane_times(self, stream):

@@ -314,7 +314,7 @@ def test_pointwise_dgrad_with_fused_bn_backward(shape, act):
 
 # (N, H, W, Cin, Cout, split): pointwise units of the shapes plyolo_conv2d_bwd_pw instantiates; 3x20x20 and 1x13x9 end in a ragged pixel tile
 PWBWD_SHAPES = [(2, 40, 40, 128, 128, 0), (3, 20, 20, 64, 64, 0), (2, 40, 40, 64, 64, 32), (1, 13, 9, 32, 32, 8), (2, 24, 24, 64, 128, 0),
-                (2, 24, 24, 128, 64, 64), (1, 40, 40, 32, 64, 0), (1, 40, 40, 64, 32, 0)]
+                (2, 24, 24, 128, 64, 32), (1, 40, 40, 32, 64, 0), (1, 40, 40, 64, 32, 0)]
 
 
 @pytest.mark.parametrize("shape", PWBWD_SHAPES, ids=str)
@@ -376,7 +376,7 @@ def test_pointwise_unit_backward_in_one_launch(shape, act, grid, monkeypatch):
         dw0 = pk0.unpack().clone()
         # one launch
         ns = lib.plyolo_conv2d_bwd_pw_slabs(C.byref(d))
-        assert ns >= 1 and (not grid or ns % grid == 0)
+        assert 1 <= ns <= (grid or 256)
         pk1 = hu.Packed(w, dt, nslab=ns)
         pk1.entry.nslab = ns
         pk1.table = torch.frombuffer(bytearray(bytes((type(pk1.entry) * 1)(pk1.entry))), dtype=torch.uint8).to(dev)
