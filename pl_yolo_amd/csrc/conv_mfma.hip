@@ -38,6 +38,10 @@ static inline hipError_t conv3ws_launch(const void*, const void*, void*, double*
 #endif
 }
 
+namespace plyolo {
+hipError_t conv_mfma_launch_s2(const void* convp, int BN, hipStream_t s);   // conv_mfma_s2.hip
+}
+
 namespace {
 
 template <bool OUT_F32>
@@ -239,6 +243,20 @@ int conv_mfma_fwd(const plyolo_conv_desc* d, const void* x, const void* wp, cons
     return submit(stream, [=](hipStream_t s) {
       return conv3ws_launch(p.x, p.w, p.y, p.stats, p.N, p.H, p.W, p.Cin, p.Cout, p.x_ld, p.y_ld, p.nkb, p.nnb, 0, p.taps_lo, p.taps_hi, s);
     });
+  }
+  // 3x3 stride 2: the dedicated instances (4-row tiles, double-buffered de-interleaved halo); PLYOLO_S2F=0: the generic path
+  const bool s2f_on = !(getenv("PLYOLO_S2F") && atoi(getenv("PLYOLO_S2F")) == 0);
+  // (Cin >= 64: the 32 -> 64 layer of the 320x320 map is a single chunk of tiny workgroups, 106 us generic against 131 here -- its
+  // weight fragments, re-read from L2 by every workgroup, outweigh its tiles)
+  const int s2_min_cin = getenv("PLYOLO_S2F_MINCIN") ? atoi(getenv("PLYOLO_S2F_MINCIN")) : 64;
+  if (s2f_on && d->ksize == 3 && d->stride == 2 && !f32 && !p.pre && !p.ablate && d->Cin >= s2_min_cin && d->Cin >= 32 && d->Cout >= 64) {
+    const int bn = d->Cout > 64 ? 128 : 64;
+    apply_tiles(p, 3, 3, 4);
+    char lab[64];
+    snprintf(lab, sizeof(lab), "conv_mfma_fwd_s2<BN%d,CK32,TH4>", bn);
+    const double M = (double)p.N * p.OHf * p.OWf;
+    annotate(lab, 2.0 * M * d->Cout * d->Cin * 9.0, M * d->Cout * 2.0 + (double)d->N * d->H * d->W * d->Cin * 2.0);
+    return submit(stream, [=](hipStream_t s) { return conv_mfma_launch_s2(&p, bn, s); });
   }
   {
     char lab[64];

@@ -97,9 +97,15 @@ DEVINL u32x4 pre_apply(u32x4 t, const float* __restrict__ pre, int pre_ld, int a
 // and L2 bytes; MI355X_MICROARCH.md (DVFS item 7) measured this shape holding a higher clock under load.  B fragments come from
 // the SAME weight pack (a 16-channel half x 32-deep fragment = four 256-byte pieces of two 32x16 fragments); the pixel pitch grows
 // to CK*2+32 bytes, which makes the 16-pixel x 4-k-group ds_read_b128 conflict-free.
-template <int BN, int CK, int TH, bool OUT_F32, int ABL, bool DB = false, bool PRE = false, bool MF16 = false>
+// S2 (conv_mfma_s2.hip, 3x3 stride-2 forward): 4 x 16 output positions, the (2*4+1) x 33 halo tile of a chunk double-buffered like
+// the stride-1 tiles (descriptor loader, next chunk in flight during the taps) and stored with its COLUMNS DE-INTERLEAVED -- even
+// halo columns first (17 entries), odd ones behind them (16) -- so that the 16 pixels of a fragment row, two input columns apart,
+// are neighbours in LDS again (pitch CK*2+16: conflict-free ds_read_b128; side by side as they lie in the image they are 2*pitch
+// apart and every read is 2-way conflicted).  Tap (dy, dx) reads region dx & 1 at column offset dx >> 1.
+template <int BN, int CK, int TH, bool OUT_F32, int ABL, bool DB = false, bool PRE = false, bool MF16 = false, bool S2 = false>
 DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
   static_assert(!MF16 || (CK == 32 && !OUT_F32 && !PRE && DB), "MF16 instances: 32-channel double-buffered bf16 tiles");
+  static_assert(!S2 || (DB && !MF16 && !PRE && !OUT_F32), "S2 instances: double-buffered bf16 tiles");
   constexpr int BM = TH * TW;
   constexpr int WN = BN / 32, WM = 4 / WN, MT = BM / (32 * WM);
   constexpr int MT16 = 2 * MT, HALF16 = MT;   // MF16: 16-pixel fragments per wave / per software-pipeline half
@@ -132,7 +138,7 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int m = (wm * MT + mt) * 32 + r;
-    arow[mt] = ((m >> 4) * p.si) * p.rowp + ((m & 15) * p.si) * ROWB + h * 16;
+    arow[mt] = S2 ? ((m >> 4) * 2) * p.rowp + (m & 15) * ROWB + h * 16 : ((m >> 4) * p.si) * p.rowp + ((m & 15) * p.si) * ROWB + h * 16;
   }
 
   f32x16 acc[MF16 ? 1 : MT];
@@ -205,7 +211,7 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
   // vectors is the same for every Cin chunk, so it is computed ONCE per tile: in-kernel stamps showed the halo
   // phases at ~10k cycles each, most of it the per-vector index arithmetic (a runtime division by the tile
   // width, bounds tests, 64-bit addresses) repeated for the loads, again for the LDS stores, and per chunk.
-  constexpr int HVT = ((TH + 2) * 18 * CV + 255) / 256;   // vectors per thread of a 3x3 stride-1 halo tile
+  constexpr int HVT = S2 ? ((2 * TH + 1) * 33 * CV + 255) / 256 : ((TH + 2) * 18 * CV + 255) / 256;   // vectors per thread of a 3x3 halo tile
   const int nvec = p.ITH * p.ITW * CV;
   const bool fastpath = nvec <= HVT * 256;                 // stride-2 forward tiles take the generic loop
   const bf16_t* xn = p.x + (size_t)n * p.H * p.W * p.x_ld;
@@ -221,7 +227,7 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
         const int pix = idx / CV;
         const int iy = pix / p.ITW, ix = pix - iy * p.ITW;
         const int gy = iy0 + iy, gx = ix0 + ix;
-        loff[v] = iy * p.rowp + ix * ROWB + cvt * 16;
+        loff[v] = iy * p.rowp + (S2 ? ((ix & 1) ? 17 + (ix >> 1) : (ix >> 1)) : ix) * ROWB + cvt * 16;
         if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) goff[v] = (gy * p.W + gx) * p.x_ld + cvt * 8;
       }
     }
@@ -294,7 +300,8 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
     // (shorter live range) where the next tap's s_waitcnt vmcnt(0) exposes their full latency
     __builtin_amdgcn_sched_barrier(0);
     const unsigned tc = tap_code(p, t);
-    const int toff = boff + (int)(tc & 3u) * p.rowp + (int)((tc >> 2) & 3u) * ROWB;
+    const int tdx = (int)((tc >> 2) & 3u);
+    const int toff = boff + (int)(tc & 3u) * p.rowp + (S2 ? ((tdx & 1) ? 17 : 0) + (tdx >> 1) : tdx) * ROWB;
     // software pipeline over the k-steps: the A fragments of step kk+1 are requested from LDS before the MFMAs
     // of step kk are issued, so that no MFMA waits on a ds_read issued just before it
     if constexpr (MF16) {
@@ -576,9 +583,9 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
   }
 }
 
-template <int BN, int CK, int TH, bool OUT_F32, int ABL = 0, bool DB = false, bool PRE = false, bool MF16 = false>
+template <int BN, int CK, int TH, bool OUT_F32, int ABL = 0, bool DB = false, bool PRE = false, bool MF16 = false, bool S2 = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvP p) {
-  conv_mfma_body<BN, CK, TH, OUT_F32, ABL, DB, PRE, MF16>(p, (int)blockIdx.x, (int)gridDim.x);
+  conv_mfma_body<BN, CK, TH, OUT_F32, ABL, DB, PRE, MF16, S2>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // MF16 instances (stride-1 tiles of 8 rows, 32-channel double-buffered chunks, bf16 output): launch with the wider pixel pitch

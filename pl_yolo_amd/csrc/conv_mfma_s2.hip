@@ -1,0 +1,38 @@
+// 3x3 stride-2 forward instances of the bf16 MFMA convolution (conv_mfma_body.h, S2): the five stride-2 layers of a CSPDarknet /
+// PAFPN (reference models/backbones/darknet_csp.py: dark2..dark5 BaseConv(…, 3, 2); models/necks/pafpn_csp.py: bu_conv1 / bu_conv2).
+// Through the generic path (si = 2 at run time) those layers ran at 280-440 TFLOP/s against 850-1070 for the stride-1 3x3 layers
+// of the same maps: their 17 x 33 halo tile took the index-arithmetic loader (two exposed memory round trips per 32-channel chunk,
+// no double buffer) and every fragment read hit LDS 2-way conflicted (pixels two columns apart).  Own translation unit: co-compiled
+// template instances perturb each other's code (see conv_mfma_body.h).
+#include "conv_mfma_body.h"
+
+namespace {
+
+template <int BN>
+hipError_t launch_s2_inst(ConvP p, hipStream_t s) {
+  constexpr int CK = 32, TH = 4, BM = TH * TW, WN = BN / 32, WM = 4 / WN;
+  constexpr int ROWB = CK * 2 + 16, SROW = BN * 2 + 16;
+  p.rowp = (33 * ROWB + 255) & ~255;
+  p.bufsz = p.ITH * p.rowp;
+  p.db = 1;
+  const size_t lds_main = 2 * (size_t)p.bufsz, lds_epi = (size_t)BM * SROW + WM * 2 * BN * 4;
+  const size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+  auto kern = conv_mfma_kernel<BN, CK, TH, false, 0, true, false, false, true>;
+  if (hipError_t e = plyolo::ensure_dynamic_lds((const void*)kern, lds); e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(p.nmb, (p.Cout + BN - 1) / BN), dim3(256), lds, s, p);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+namespace plyolo {
+
+// `convp`: a ConvP prepared for 4-row tiles (ITH 9, ITW 33, si 2)
+hipError_t conv_mfma_launch_s2(const void* convp, int BN, hipStream_t s) {
+  const ConvP& p = *(const ConvP*)convp;
+  if (BN == 128) return launch_s2_inst<128>(p, s);
+  if (BN == 64) return launch_s2_inst<64>(p, s);
+  return hipErrorInvalidValue;
+}
+
+}  // namespace plyolo

@@ -39,6 +39,8 @@ SHAPES = [
     (16, 80, 80, 256, 128, 1, 1),   # pointwise, 16x16 tile, 4 chunks
     (6, 72, 88, 48, 80, 3, 1),      # 16x16 tile with ragged edges, Cin tail chunk (48 = 32 + 16), Cout 80
     (2, 160, 160, 64, 64, 3, 2),    # stride 2 dgrad parity classes on 16x16 tiles
+    (3, 26, 38, 64, 128, 3, 2),     # stride-2 forward instances (4-row tiles, de-interleaved halo): ragged 13 x 19 output, two chunks
+    (2, 22, 46, 96, 64, 3, 2),      # ... Cin 96 = three chunks, 11 x 23 output, 64-channel block
 ]
 
 
