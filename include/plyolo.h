@@ -416,10 +416,41 @@ int plyolo_conv2d_dgrad_bn(const plyolo_conv_desc* d, const plyolo_bn_bwd_fuse* 
  * as plyolo_conv2d_bwd_pw_slabs(d) private fp32 slabs [slab][Cout][Cin] at dwp (fold them with plyolo_reduce_slabs).
  * plyolo_conv2d_bwd_pw_fits: 1 if the unit is covered (bf16, 1x1 stride 1, act none/silu/relu/lrelu, Cout and Cin in {32, 64, 128}
  * and equal or 2:1, output gradient >= PLYOLO_PWBWD_MIN_MB), else 0. */
+/* BatchNorm-backward reduction of the UPSTREAM unit(s), folded into the data gradient that writes their output gradient LAST
+ * (plyolo_conv2d_dgrad_red / plyolo_conv2d_bwd_pw_red): while a data-gradient kernel stores the final dx rows -- the gradient of
+ * the activated output a_U of the unit(s) U that produced x -- it also reads U's raw conv output z_U and adds
+ *     sum du,  sum du * zhat      (du = dx * act'(z_U * scale + shift), zhat = (z_U - mean) * invstd)
+ * to U's fp64 backward stat slots: exactly what plyolo_bn_act_bwd_reduce(dx, z_U) would add in a launch of its own, which then
+ * reads dx and z_U again.  Up to PLYOLO_BN_RED_SEGS channel segments [c0, c1) of dx (a concatenated input: one segment per
+ * producing unit; a segment without a BatchNorm unit is simply left out); every pointer is pre-offset to the segment's first
+ * channel; z [M][..] pitch z_ld; coef rows (scale | shift | mean | invstd) coef_ld apart; bslots [PLYOLO_STAT_SLOTS][2][slot_ld]
+ * of the unit (slot_ld = its channel count).  c0 / c1 multiples of 8.  The caller zeroes bslots, and must be the LAST writer of
+ * those dx channels. */
+#define PLYOLO_BN_RED_SEGS 3
+typedef struct plyolo_bn_red_seg {
+  int c0, c1;
+  const void* z; int z_ld;
+  const float* coef; int coef_ld;
+  double* bslots; int slot_ld;
+  int act;
+} plyolo_bn_red_seg;
+typedef struct plyolo_bn_red {
+  int n;
+  plyolo_bn_red_seg seg[PLYOLO_BN_RED_SEGS];
+} plyolo_bn_red;
+/* plyolo_conv2d_dgrad + the reduction above (bf16 only; red == NULL or red->n == 0: plain plyolo_conv2d_dgrad) */
+int plyolo_conv2d_dgrad_red(const plyolo_conv_desc* d, const void* dy, const void* wpd, void* dx, int accumulate,
+                            const plyolo_bn_red* red, void* stream);
+/* 1 when plyolo_conv2d_dgrad_red has a kernel instance for this data gradient (bf16; decided with the launch's own tile selection) */
+int plyolo_conv2d_dgrad_red_fits(const plyolo_conv_desc* d);
+
 int plyolo_conv2d_bwd_pw_fits(const plyolo_conv_desc* d, int act);
 int plyolo_conv2d_bwd_pw_slabs(const plyolo_conv_desc* d);
 int plyolo_conv2d_bwd_pw(const plyolo_conv_desc* d, const plyolo_bn_bwd_fuse* f, const void* x, const void* wpd, void* dx,
                          int accumulate, float* dwp, void* stream);
+/* ... + the BatchNorm-backward reduction of the unit(s) that produced x (plyolo_bn_red above) */
+int plyolo_conv2d_bwd_pw_red(const plyolo_conv_desc* d, const plyolo_bn_bwd_fuse* f, const void* x, const void* wpd, void* dx,
+                             int accumulate, float* dwp, const plyolo_bn_red* red, void* stream);
 
 /* norm = "ln" of BaseConv (reference models/layers/normalization.py:9-10): nn.LayerNorm(out_channels) on an NCHW tensor
  * normalises the last axis, the image WIDTH, with affine parameters gamma[W], beta[W] (torch requires W == out_channels), eps

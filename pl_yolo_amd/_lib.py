@@ -55,6 +55,18 @@ class BnBwdFuse(C.Structure):      # plyolo_bn_bwd_fuse
                 ("dz", C.c_void_p), ("dz_ld", C.c_int)]
 
 
+class BnRedSeg(C.Structure):       # plyolo_bn_red_seg
+    _fields_ = [("c0", C.c_int), ("c1", C.c_int), ("z", C.c_void_p), ("z_ld", C.c_int), ("coef", C.c_void_p), ("coef_ld", C.c_int),
+                ("bslots", C.c_void_p), ("slot_ld", C.c_int), ("act", C.c_int)]
+
+
+BN_RED_SEGS = 3
+
+
+class BnRed(C.Structure):          # plyolo_bn_red
+    _fields_ = [("n", C.c_int), ("seg", BnRedSeg * BN_RED_SEGS)]
+
+
 class BiasJob(C.Structure):        # plyolo_bias_job
     _fields_ = [("dy", C.c_void_p), ("M", C.c_int), ("C", C.c_int), ("ld", C.c_int), ("db", C.c_void_p), ("nblk", C.c_int)]
 
@@ -165,6 +177,9 @@ SIGNATURES = {
     "plyolo_conv2d_wgrad": (_i, [_P(ConvDesc), _vp, _vp, _vp, _vp]),
     "plyolo_conv2d_dgrad_bn_fits": (_i, [_P(ConvDesc), _i]),
     "plyolo_conv2d_dgrad_bn": (_i, [_P(ConvDesc), _P(BnBwdFuse), _vp, _vp, _i, _vp]),
+    "plyolo_conv2d_dgrad_red": (_i, [_P(ConvDesc), _vp, _vp, _vp, _i, _P(BnRed), _vp]),
+    "plyolo_conv2d_dgrad_red_fits": (_i, [_P(ConvDesc)]),
+    "plyolo_conv2d_bwd_pw_red": (_i, [_P(ConvDesc), _P(BnBwdFuse), _vp, _vp, _vp, _i, _vp, _P(BnRed), _vp]),
     "plyolo_conv2d_bwd_pw_fits": (_i, [_P(ConvDesc), _i]),
     "plyolo_conv2d_bwd_pw_slabs": (_i, [_P(ConvDesc)]),
     "plyolo_conv2d_bwd_pw": (_i, [_P(ConvDesc), _P(BnBwdFuse), _vp, _vp, _vp, _i, _vp, _vp]),

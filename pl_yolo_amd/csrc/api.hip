@@ -54,17 +54,18 @@ void take_annotation(PlanOp* op) {
 
 int conv_mfma_fwd(const plyolo_conv_desc*, const void*, const void*, const float*, void*, double*, const float*, int, const void*, int, void*);
 void conv_mfma_pack_elems(int Cout_total, int Cin_p, int ksize, size_t* wp, size_t* wpd);
-int conv_mfma_dgrad(const plyolo_conv_desc*, const void*, const void*, void*, int, void*);
+int conv_mfma_dgrad(const plyolo_conv_desc*, const void*, const void*, void*, int, const plyolo_bn_red*, void*, int*);
+int conv_mfma_dgrad_red_fits(const plyolo_conv_desc*);
 int conv_mfma_wgrad(const plyolo_conv_desc*, const void*, const void*, float*, void*);
 int conv_mfma_wgrad_slabs(const plyolo_conv_desc*);
 bool conv_pw_enabled();
 int conv_pw_fwd(const plyolo_conv_desc*, const void*, const void*, const float*, void*, double*, const float*, int, const void*, int, void*);
-int conv_pw_dgrad(const plyolo_conv_desc*, const void*, const void*, void*, int, void*);
+int conv_pw_dgrad(const plyolo_conv_desc*, const void*, const void*, void*, int, const plyolo_bn_red*, void*, int*);
 int conv_pw_dgrad_bn_fits(const plyolo_conv_desc*, int);
 int conv_pw_dgrad_bn(const plyolo_conv_desc*, const plyolo_bn_bwd_fuse*, const void*, void*, int, void*);
 int conv_pw_bwd_fits(const plyolo_conv_desc*, int);
 int conv_pw_bwd_slabs(const plyolo_conv_desc*);
-int conv_pw_bwd(const plyolo_conv_desc*, const plyolo_bn_bwd_fuse*, const void*, const void*, void*, int, float*, void*);
+int conv_pw_bwd(const plyolo_conv_desc*, const plyolo_bn_bwd_fuse*, const void*, const void*, void*, int, float*, const plyolo_bn_red*, void*);
 int conv_ref_fwd(const plyolo_conv_desc*, const void*, const void*, const float*, void*, double*, void*);
 int conv_ref_dgrad(const plyolo_conv_desc*, const void*, const void*, void*, int, void*);
 int conv_ref_wgrad(const plyolo_conv_desc*, const void*, const void*, float*, void*);
@@ -464,8 +465,36 @@ int plyolo_pack_elems(int dtype, int Cout_total, int Cin_p, int ksize, size_t* w
 int plyolo_conv2d_dgrad(const plyolo_conv_desc* d, const void* dy, const void* wpd, void* dx, int accumulate, void* stream) {
   if (check_conv(d, "conv2d_dgrad", false)) return -1;
   if (d->dtype != PLYOLO_BF16) return conv_ref_dgrad(d, dy, wpd, dx, accumulate, stream);
-  if (is_pointwise(d)) return conv_pw_dgrad(d, dy, wpd, dx, accumulate, stream);
-  return conv_mfma_dgrad(d, dy, wpd, dx, accumulate, stream);
+  if (is_pointwise(d)) return conv_pw_dgrad(d, dy, wpd, dx, accumulate, nullptr, stream, nullptr);
+  return conv_mfma_dgrad(d, dy, wpd, dx, accumulate, nullptr, stream, nullptr);
+}
+static int check_red(const plyolo_bn_red* r, const plyolo_conv_desc* d, const char* who) {
+  PLY_CHECK_ARG(r->n >= 0 && r->n <= PLYOLO_BN_RED_SEGS, "%s: bad segment count", who);
+  for (int k = 0; k < r->n; ++k) {
+    const plyolo_bn_red_seg& g = r->seg[k];
+    PLY_CHECK_ARG(g.c0 >= 0 && g.c1 > g.c0 && g.c1 <= d->Cin && g.c0 % 8 == 0 && g.c1 % 8 == 0, "%s: segment %d: channels [%d, %d) must be multiples of 8 inside [0, Cin)", who, k, g.c0, g.c1);
+    PLY_CHECK_ARG(g.z && g.coef && g.bslots && g.z_ld % 8 == 0 && g.z_ld >= g.c1 - g.c0 && g.coef_ld >= g.c1 - g.c0 && g.slot_ld >= g.c1 - g.c0, "%s: segment %d: incomplete", who, k);
+    PLY_CHECK_ARG(g.act >= PLYOLO_ACT_NONE && g.act <= PLYOLO_ACT_GELU, "%s: segment %d: bad activation", who, k);
+    for (int j = 0; j < k; ++j) PLY_CHECK_ARG(g.c0 >= r->seg[j].c1 || g.c1 <= r->seg[j].c0, "%s: segments %d and %d overlap", who, j, k);
+  }
+  return 0;
+}
+/* 1 when plyolo_conv2d_dgrad_red has an instance for this data gradient (bf16; the tile configuration the launch itself picks) */
+int plyolo_conv2d_dgrad_red_fits(const plyolo_conv_desc* d) {
+  if (check_conv(d, "conv2d_dgrad_red_fits", false)) return -1;
+  if (d->dtype != PLYOLO_BF16) return 0;
+  int fits = 0;
+  if (is_pointwise(d)) conv_pw_dgrad(d, nullptr, nullptr, nullptr, 0, nullptr, nullptr, &fits);
+  else fits = conv_mfma_dgrad_red_fits(d);
+  return fits;
+}
+int plyolo_conv2d_dgrad_red(const plyolo_conv_desc* d, const void* dy, const void* wpd, void* dx, int accumulate, const plyolo_bn_red* red, void* stream) {
+  if (red == nullptr || red->n == 0) return plyolo_conv2d_dgrad(d, dy, wpd, dx, accumulate, stream);
+  if (check_conv(d, "conv2d_dgrad_red", false)) return -1;
+  PLY_CHECK_ARG(d->dtype == PLYOLO_BF16, "conv2d_dgrad_red: bf16 only");
+  if (check_red(red, d, "conv2d_dgrad_red")) return -1;
+  if (is_pointwise(d)) return conv_pw_dgrad(d, dy, wpd, dx, accumulate, red, stream, nullptr);
+  return conv_mfma_dgrad(d, dy, wpd, dx, accumulate, red, stream, nullptr);
 }
 int plyolo_conv2d_dgrad_bn_fits(const plyolo_conv_desc* d, int act) {
   if (check_conv(d, "conv2d_dgrad_bn_fits", false)) return -1;
@@ -490,13 +519,18 @@ int plyolo_conv2d_bwd_pw_slabs(const plyolo_conv_desc* d) {
 }
 int plyolo_conv2d_bwd_pw(const plyolo_conv_desc* d, const plyolo_bn_bwd_fuse* f, const void* x, const void* wpd, void* dx, int accumulate,
                          float* dwp, void* stream) {
+  return plyolo_conv2d_bwd_pw_red(d, f, x, wpd, dx, accumulate, dwp, nullptr, stream);
+}
+int plyolo_conv2d_bwd_pw_red(const plyolo_conv_desc* d, const plyolo_bn_bwd_fuse* f, const void* x, const void* wpd, void* dx, int accumulate,
+                             float* dwp, const plyolo_bn_red* red, void* stream) {
   if (check_conv(d, "conv2d_bwd_pw", false)) return -1;
+  if (red && red->n > 0 && check_red(red, d, "conv2d_bwd_pw_red")) return -1;
   PLY_CHECK_ARG(f && f->dout && f->z && f->coef && f->bslots && x && wpd && dx && dwp, "conv2d_bwd_pw: incomplete arguments");
   PLY_CHECK_ARG(conv_pw_bwd_fits(d, f->act) == 1, "conv2d_bwd_pw: this unit is not covered (ask plyolo_conv2d_bwd_pw_fits; use plyolo_bn_act_bwd_dz + plyolo_conv2d_dgrad + plyolo_conv2d_wgrad)");
   PLY_CHECK_ARG(f->dout_ld % 8 == 0 && f->z_ld % 8 == 0 && f->z_ld >= d->Cout, "conv2d_bwd_pw: pitches must be multiples of 8 and hold Cout channels");
   PLY_CHECK_ARG(!f->dout2 || (f->dout_split > 0 && f->dout_split < d->Cout && f->dout_split % 8 == 0 && f->dout2_ld % 8 == 0), "conv2d_bwd_pw: bad output-gradient split");
   PLY_CHECK_ARG(f->par_split == 0 || (f->par_split > 0 && f->par_split < d->Cout), "conv2d_bwd_pw: bad parameter split");
-  return conv_pw_bwd(d, f, x, wpd, dx, accumulate, dwp, stream);
+  return conv_pw_bwd(d, f, x, wpd, dx, accumulate, dwp, red, stream);
 }
 int plyolo_conv2d_wgrad_slabs(const plyolo_conv_desc* d) {
   if (check_conv(d, "conv2d_wgrad_slabs", false)) return -1;

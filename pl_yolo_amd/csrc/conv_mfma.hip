@@ -40,6 +40,10 @@ static inline hipError_t conv3ws_launch(const void*, const void*, void*, double*
 
 namespace plyolo {
 hipError_t conv_mfma_launch_s2(const void* convp, int BN, hipStream_t s);   // conv_mfma_s2.hip
+// conv_mfma_red.hip: data-gradient instances that fold the upstream BatchNorm-backward reduction into their store loop
+int conv_mfma_red_has(int BN, int CK, int TH, int jobs);
+hipError_t conv_mfma_launch_red(const void* convp, int BN, int CK, int TH, hipStream_t s);
+hipError_t conv_mfma_launch_jobs_red(const void* jobsp, int BN, int CK, int TH, hipStream_t s);
 }
 
 namespace {
@@ -268,8 +272,10 @@ int conv_mfma_fwd(const plyolo_conv_desc* d, const void* x, const void* wp, cons
 }
 
 // dx[N,H,W,Cin] = sum_taps dy[...] * w ; weights in the dgrad fragment pack
+// red (optional): the BatchNorm-backward reduction of the unit(s) behind dx rides this launch's store loop (plyolo_bn_red); the
+// caller has asked conv_mfma_dgrad_red_fits first
 int conv_mfma_dgrad(const plyolo_conv_desc* d, const void* dy, const void* wpd, void* dx, int accumulate,
-                    void* stream) {
+                    const plyolo_bn_red* red, void* stream, int* red_fits) {
   const int pad = (d->ksize - 1) / 2;
   const int OH = (d->H + 2 * pad - d->ksize) / d->stride + 1;
   const int OW = (d->W + 2 * pad - d->ksize) / d->stride + 1;
@@ -306,7 +312,7 @@ int conv_mfma_dgrad(const plyolo_conv_desc* d, const void* dy, const void* wpd, 
         p.tap_w[t] = (signed char)((d->ksize - 1 - dy_) * d->ksize + (d->ksize - 1 - dx_));
       }
     finish(p, d->ksize, d->ksize, false, &BN, &CK, &TH);
-    if (d->ksize == 3 && !p.ablate && conv3ws_accepts(p.N, p.H, p.W, p.Cin, p.Cout, p.x_ld, p.y_ld, dx)) {
+    if (!red_fits && !(red && red->n > 0) && d->ksize == 3 && !p.ablate && conv3ws_accepts(p.N, p.H, p.W, p.Cin, p.Cout, p.x_ld, p.y_ld, dx)) {
       char lab[64];
       snprintf(lab, sizeof(lab), "conv3ws_dgrad<Cin%d,Cout%d>", p.Cin, p.Cout);
       const double Mo = (double)d->N * OH * OW, Mi = (double)d->N * d->H * d->W;
@@ -315,12 +321,17 @@ int conv_mfma_dgrad(const plyolo_conv_desc* d, const void* dy, const void* wpd, 
         return conv3ws_launch(p.x, p.w, p.y, nullptr, p.N, p.H, p.W, p.Cin, p.Cout, p.x_ld, p.y_ld, p.nkb, p.nnb, p.accumulate, p.taps_lo, p.taps_hi, s);
       });
     }
+    if (red_fits) { *red_fits = (d->ksize == 3 && !p.ablate) ? conv_mfma_red_has(BN, CK, TH, 0) : 0; return 0; }
+    const bool use_red = red && red->n > 0 && !p.ablate && conv_mfma_red_has(BN, CK, TH, 0);
+    if (red && red->n > 0 && !use_red) { set_error("conv_mfma_dgrad: no RED instance for this tile configuration (ask plyolo_conv2d_dgrad_red_fits)"); return -1; }
+    if (use_red) p.red = *red;
     {
       char lab[64];
-      snprintf(lab, sizeof(lab), "conv_mfma_dgrad<BN%d,CK%d,TH%d>", BN, CK, TH);
+      snprintf(lab, sizeof(lab), "conv_mfma_dgrad<BN%d,CK%d,TH%d>%s", BN, CK, TH, use_red ? "+bnred" : "");
       const double Mo = (double)d->N * OH * OW, Mi = (double)d->N * d->H * d->W;
-      annotate(lab, 2.0 * Mo * d->Cout * d->Cin * d->ksize * d->ksize, (Mo * Kc + Mi * d->Cin * (accumulate ? 2.0 : 1.0)) * 2.0);
+      annotate(lab, 2.0 * Mo * d->Cout * d->Cin * d->ksize * d->ksize, (Mo * Kc + Mi * d->Cin * (accumulate ? 2.0 : 1.0) + (use_red ? Mi * d->Cin : 0.0)) * 2.0);
     }
+    if (use_red) return submit(stream, [=](hipStream_t s) { return conv_mfma_launch_red(&p, BN, CK, TH, s); });
     return submit(stream, [=](hipStream_t s) { return launch_bn<false>(p, BN, CK, TH, s); });
   }
   // stride 2 (ksize 3 pad 1, or ksize 1): one job per output parity class (1/2/2/4 taps), all four in ONE launch
@@ -365,13 +376,31 @@ int conv_mfma_dgrad(const plyolo_conv_desc* d, const void* dy, const void* wpd, 
     }
   if (jobs.n == 0) return 0;
   for (int j = 0; j < jobs.n; ++j) apply_tiles(jobs.c[j], ext[j][0], ext[j][1], jTH);
+  if (red_fits) { *red_fits = (d->ksize == 3 && jobs.n == 4) ? conv_mfma_red_has(jBN, jCK, jTH, 1) : 0; return 0; }
+  const bool use_red = red && red->n > 0 && conv_mfma_red_has(jBN, jCK, jTH, 1);
+  if (red && red->n > 0 && !use_red) { set_error("conv_mfma_dgrad: no RED instance for this stride-2 tile configuration"); return -1; }
+  if (use_red) {
+    for (int j = 0; j < jobs.n; ++j) jobs.c[j].red = *red;
+    by += (double)d->N * d->H * d->W * d->Cin * 2.0;
+  }
   {
     char lab[64];
-    snprintf(lab, sizeof(lab), "conv_mfma_dgrad_s2<BN%d,CK%d,TH%d>x%d", jBN, jCK, jTH, jobs.n);
+    snprintf(lab, sizeof(lab), "conv_mfma_dgrad_s2<BN%d,CK%d,TH%d>x%d%s", jBN, jCK, jTH, jobs.n, use_red ? "+bnred" : "");
     annotate(lab, fl, by);
   }
   const int bn = jBN, ck = jCK, th = jTH;
+  if (use_red) return submit(stream, [=](hipStream_t s) { return conv_mfma_launch_jobs_red(&jobs, bn, ck, th, s); });
   return submit(stream, [=](hipStream_t s) { return launch_jobs(jobs, bn, ck, th, s); });
+}
+
+
+// 1 when conv_mfma_dgrad(d, ..., red) has a RED instance for the tiles this data gradient runs on (asked with the launch's own
+// tile selection, nothing is submitted)
+int conv_mfma_dgrad_red_fits(const plyolo_conv_desc* d) {
+  if (d->dtype != PLYOLO_BF16) return 0;
+  int fits = 0;
+  conv_mfma_dgrad(d, nullptr, nullptr, nullptr, 0, nullptr, nullptr, &fits);
+  return fits;
 }
 
 }  // namespace plyolo

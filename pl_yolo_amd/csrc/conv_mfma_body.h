@@ -7,6 +7,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "bnred.h"
 
 namespace {
 
@@ -44,6 +45,7 @@ struct ConvP {
   unsigned long long taps_lo;
   unsigned int taps_hi;
   int ablate;  // diagnostics (PLYOLO_ABLATE): 1 skip epilogue, 4 reload no halo after chunk 0, 8 skip MFMA, 16 skip weight loads, 32 skip LDS fragment reads
+  plyolo_bn_red red;  // RED instances (data gradients): BatchNorm-backward reduction of the unit(s) whose output gradient this launch completes
 };
 
 DEVINL unsigned tap_code(const ConvP& p, int t) {
@@ -102,8 +104,10 @@ DEVINL u32x4 pre_apply(u32x4 t, const float* __restrict__ pre, int pre_ld, int a
 // halo columns first (17 entries), odd ones behind them (16) -- so that the 16 pixels of a fragment row, two input columns apart,
 // are neighbours in LDS again (pitch CK*2+16: conflict-free ds_read_b128; side by side as they lie in the image they are 2*pitch
 // apart and every read is 2-way conflicted).  Tap (dy, dx) reads region dx & 1 at column offset dx >> 1.
-template <int BN, int CK, int TH, bool OUT_F32, int ABL, bool DB = false, bool PRE = false, bool MF16 = false, bool S2 = false>
+// RED (conv_mfma_red.hip, data gradients): the store loop also folds the BatchNorm-backward reduction of the upstream unit(s) (bnred.h)
+template <int BN, int CK, int TH, bool OUT_F32, int ABL, bool DB = false, bool PRE = false, bool MF16 = false, bool S2 = false, bool RED = false>
 DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
+  static_assert(!RED || !OUT_F32, "RED instances store bf16 gradients");
   static_assert(!MF16 || (CK == 32 && !OUT_F32 && !PRE && DB), "MF16 instances: 32-channel double-buffered bf16 tiles");
   static_assert(!S2 || (DB && !MF16 && !PRE && !OUT_F32), "S2 instances: double-buffered bf16 tiles");
   constexpr int BM = TH * TW;
@@ -567,6 +571,40 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
   } else {
     bf16_t* y = (bf16_t*)p.y;
     constexpr int VPR = BN / 8;
+    if constexpr (RED) {
+      // same rows, same stores; every thread owns ONE channel vector (256 % VPR == 0) and NIT rows.  The upstream unit's z vectors
+      // (and the old dx rows of an accumulating launch) are requested up front -- one memory round trip for the whole loop
+      constexpr int NIT = BM * VPR / 256;
+      static_assert(256 % VPR == 0 && (BM * VPR) % 256 == 0, "RED: whole rows per thread");
+      const int v = tid % VPR, co = cout0 + v * 8;
+      BnRedThread rt;
+      bnred_init(rt, p.red, co);
+      u32x4 zq[NIT], old[NIT];
+      size_t pixs[NIT];
+      bool ok[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int m = (tid + it * 256) / VPR;
+        const int a = oy0 + (m >> 4), b = ox0 + (m & 15);
+        ok[it] = a < p.OHt && b < p.OWt && co < p.Cout;
+        const int oy = a * p.so + p.oy_off, ox = b * p.so + p.ox_off;
+        pixs[it] = ok[it] ? (size_t)(n * p.OHf + oy) * p.OWf + ox : 0;
+        zq[it] = rt.z ? bnred_load(rt, pixs[it]) : u32x4{0u, 0u, 0u, 0u};
+        old[it] = p.accumulate ? *(const u32x4*)(y + pixs[it] * p.y_ld + (co < p.Cout ? co : 0)) : u32x4{0u, 0u, 0u, 0u};
+      }
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int m = (tid + it * 256) / VPR;
+        if (ok[it]) {
+          u32x4 val = *(const u32x4*)(smem + m * SROW + v * 16);
+          if (p.accumulate) val = add_bf16x8(old[it], val);
+          *(u32x4*)(y + pixs[it] * p.y_ld + co) = val;
+          if (rt.z) bnred_add<-1>(rt, val, zq[it]);
+        }
+      }
+      __syncthreads();   // every thread is done with the staging rows: the fold reuses them
+      bnred_flush<256, VPR>(rt, p.red, cout0, (float*)smem, tid, tile % PLYOLO_STAT_SLOTS);
+    } else {
     for (int idx = tid; idx < BM * VPR; idx += 256) {
       const int m = idx / VPR, v = idx - m * VPR;
       const int a = oy0 + (m >> 4), b = ox0 + (m & 15), co = cout0 + v * 8;
@@ -580,12 +618,13 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
         *(u32x4*)dst = val;
       }
     }
+    }
   }
 }
 
-template <int BN, int CK, int TH, bool OUT_F32, int ABL = 0, bool DB = false, bool PRE = false, bool MF16 = false, bool S2 = false>
+template <int BN, int CK, int TH, bool OUT_F32, int ABL = 0, bool DB = false, bool PRE = false, bool MF16 = false, bool S2 = false, bool RED = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvP p) {
-  conv_mfma_body<BN, CK, TH, OUT_F32, ABL, DB, PRE, MF16, S2>(p, (int)blockIdx.x, (int)gridDim.x);
+  conv_mfma_body<BN, CK, TH, OUT_F32, ABL, DB, PRE, MF16, S2, RED>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // MF16 instances (stride-1 tiles of 8 rows, 32-channel double-buffered chunks, bf16 output): launch with the wider pixel pitch
@@ -603,12 +642,12 @@ hipError_t launch_inst_mf16(ConvP p, hipStream_t s) {
   return hipGetLastError();
 }
 
-template <int BN, int CK, int TH, bool DB = false>
+template <int BN, int CK, int TH, bool DB = false, bool RED = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_jobs_kernel(const ConvJobs jobs) {
   int j = 0;
   for (int k = 1; k < 4; ++k)
     if (k < jobs.n && (int)blockIdx.x >= jobs.start[k]) j = k;
-  conv_mfma_body<BN, CK, TH, false, 0, DB>(jobs.c[j], (int)blockIdx.x - jobs.start[j], jobs.start[j + 1] - jobs.start[j]);
+  conv_mfma_body<BN, CK, TH, false, 0, DB, false, false, false, RED>(jobs.c[j], (int)blockIdx.x - jobs.start[j], jobs.start[j + 1] - jobs.start[j]);
 }
 
 template <int BN, int CK, int TH, bool OUT_F32, bool PRE = false>

@@ -23,6 +23,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "bnred.h"
 
 namespace {
 
@@ -58,6 +59,7 @@ struct PwP {
   int bpsplit, bact;
   bf16_t* bdz;
   int bdz_ld;
+  plyolo_bn_red red;     // RED instances (data gradients): BatchNorm-backward reduction of the unit(s) whose output gradient this launch completes
 };
 
 // derivative of the three cheap activations (the BNB loader; hswish / gelu units keep the separate bn_act_bwd_dz launch)
@@ -90,8 +92,10 @@ constexpr int PW_BM = 128;
 // thread pay for the loader's second operand and its coefficient registers (207 -> 3 waves per SIMD without spilling)
 template <int BN, bool BNB> constexpr int pw_bm() { return (BNB && BN >= 64) ? 64 : PW_BM; }
 
-template <int BN, int KC, bool OUT_F32, bool PRE, bool PIPE, bool BNB = false>
+// RED: the bf16 store loop also folds the BatchNorm-backward reduction of the upstream unit(s) (bnred.h)
+template <int BN, int KC, bool OUT_F32, bool PRE, bool PIPE, bool BNB = false, bool RED = false>
 __global__ __launch_bounds__(256, BNB ? 3 : 2) void conv_pw_kernel(const PwP p) {
+  static_assert(!RED || (!OUT_F32 && !PRE && !BNB), "RED instances: plain bf16 data gradients");
   constexpr int BM = pw_bm<BN, BNB>();
   constexpr int WN = BN / 32, WM = 4 / WN, MT = BM / (32 * WM);
   constexpr int ROWB = KC * 2 + 16;   // LDS row pitch (bytes)
@@ -436,6 +440,36 @@ __global__ __launch_bounds__(256, BNB ? 3 : 2) void conv_pw_kernel(const PwP p) 
   } else {
     bf16_t* y = (bf16_t*)p.y;
     constexpr int VPR = BN / 8;
+    if constexpr (RED) {
+      // every thread owns ONE channel vector (256 % VPR == 0) and NIT rows; the upstream unit's z vectors and the old dx rows of an
+      // accumulating launch are requested up front -- one memory round trip for the whole loop
+      constexpr int NIT = BM * VPR / 256;
+      static_assert(256 % VPR == 0 && (BM * VPR) % 256 == 0, "RED: whole rows per thread");
+      const int v = tid % VPR, co = cout0 + v * 8;
+      BnRedThread rt;
+      bnred_init(rt, p.red, co);
+      u32x4 zq[NIT], old[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int m = (tid + it * 256) / VPR;
+        const bool ok = m0 + m < p.M && co < p.N;
+        const size_t pix = ok ? (size_t)(m0 + m) : 0;
+        zq[it] = rt.z ? bnred_load(rt, pix) : u32x4{0u, 0u, 0u, 0u};
+        old[it] = p.accumulate ? *(const u32x4*)(y + pix * p.y_ld + (co < p.N ? co : 0)) : u32x4{0u, 0u, 0u, 0u};
+      }
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int m = (tid + it * 256) / VPR;
+        if (m0 + m < p.M && co < p.N) {
+          u32x4 val = *(const u32x4*)(smem + m * SROW + v * 16);
+          if (p.accumulate) val = pw_add_bf16x8(old[it], val);
+          *(u32x4*)(y + (size_t)(m0 + m) * p.y_ld + co) = val;
+          if (rt.z) bnred_add<-1>(rt, val, zq[it]);
+        }
+      }
+      __syncthreads();   // every thread is done with the staging rows: the fold reuses them
+      bnred_flush<256, VPR>(rt, p.red, cout0, (float*)smem, tid, mt_i % PLYOLO_STAT_SLOTS);
+    } else {
     for (int idx = tid; idx < BM * VPR; idx += 256) {
       const int m = idx / VPR, v = idx - m * VPR;
       const int co = cout0 + v * 8;
@@ -447,6 +481,7 @@ __global__ __launch_bounds__(256, BNB ? 3 : 2) void conv_pw_kernel(const PwP p) 
         if (p.accumulate) val = pw_add_bf16x8(*(const u32x4*)dst, val);
         *(u32x4*)dst = val;
       }
+    }
     }
   }
 }
@@ -463,6 +498,28 @@ hipError_t pw_launch_inst(const PwP& p, hipStream_t s) {
   if (hipError_t e = plyolo::ensure_dynamic_lds((const void*)kern, lds); e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(p.nmt * p.nnblk), dim3(256), lds, s, p);
   return hipGetLastError();
+}
+
+// RED instances: plain chunk loop, 32- / 64-channel chunks (what pw_tiles picks for a data gradient unless PLYOLO_PW_KCMAX widens them)
+template <int BN, int KC>
+hipError_t pw_launch_red_inst(const PwP& p, hipStream_t s) {
+  constexpr int WN = BN / 32, WM = 4 / WN;
+  constexpr int ROWB = KC * 2 + 16, SROW = BN * 2 + 16;
+  const size_t lds_main = (size_t)PW_BM * ROWB, lds_epi = (size_t)PW_BM * SROW + WM * 2 * BN * 4;
+  size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+  lds = lds > 16384 ? lds : 16384;     // bnred_flush scratch (aliases the staging rows)
+  auto kern = conv_pw_kernel<BN, KC, false, false, false, false, true>;
+  if (hipError_t e = plyolo::ensure_dynamic_lds((const void*)kern, lds); e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(p.nmt * p.nnblk), dim3(256), lds, s, p);
+  return hipGetLastError();
+}
+bool pw_red_has(int BN, int KC) { return (BN == 32 || BN == 64 || BN == 128) && (KC == 32 || KC == 64); }
+hipError_t pw_launch_red(const PwP& p, int BN, int KC, hipStream_t s) {
+#define PW_RCASE(bn, kc) \
+  if (BN == bn && KC == kc) return pw_launch_red_inst<bn, kc>(p, s);
+  PW_RCASE(32, 32) PW_RCASE(32, 64) PW_RCASE(64, 32) PW_RCASE(64, 64) PW_RCASE(128, 32) PW_RCASE(128, 64)
+#undef PW_RCASE
+  return hipErrorInvalidValue;
 }
 
 // BNB instances: bf16 output, plain chunk loop, 32- / 64-channel chunks
@@ -562,7 +619,9 @@ int conv_pw_fwd(const plyolo_conv_desc* d, const void* x, const void* wp, const 
 }
 
 // dx[M, Cin] (+)= dy[M, Cout_p8] . Wd   (weights in the dgrad fragment pack: n-blocks over Cin, k-blocks over Cout)
-int conv_pw_dgrad(const plyolo_conv_desc* d, const void* dy, const void* wpd, void* dx, int accumulate, void* stream) {
+// red (optional): plyolo_bn_red folded into the store loop; red_fits != NULL: only report whether a RED instance serves this launch
+int conv_pw_dgrad(const plyolo_conv_desc* d, const void* dy, const void* wpd, void* dx, int accumulate, const plyolo_bn_red* red, void* stream,
+                  int* red_fits) {
   PwP p{};
   p.x = (const bf16_t*)dy;
   p.w = (const bf16_t*)wpd;
@@ -575,11 +634,16 @@ int conv_pw_dgrad(const plyolo_conv_desc* d, const void* dy, const void* wpd, vo
   p.accumulate = accumulate;
   int BN, KC;
   pw_tiles(p, false, &BN, &KC);
+  if (red_fits) { *red_fits = (!p.pipe && pw_red_has(BN, KC)) ? 1 : 0; return 0; }
+  const bool use_red = red && red->n > 0;
+  if (use_red && (p.pipe || !pw_red_has(BN, KC))) { set_error("conv_pw_dgrad: no RED instance for these tiles (ask plyolo_conv2d_dgrad_red_fits)"); return -1; }
+  if (use_red) p.red = *red;
   {
     char lab[64];
-    snprintf(lab, sizeof(lab), "conv_pw_dgrad<BN%d,KC%d>", BN, KC);
-    annotate(lab, 2.0 * p.M * (double)d->Cout * d->Cin, (double)p.M * (p.K + d->Cin * (accumulate ? 2.0 : 1.0)) * 2.0);
+    snprintf(lab, sizeof(lab), "conv_pw_dgrad<BN%d,KC%d>%s", BN, KC, use_red ? "+bnred" : "");
+    annotate(lab, 2.0 * p.M * (double)d->Cout * d->Cin, (double)p.M * (p.K + d->Cin * ((accumulate ? 2.0 : 1.0) + (use_red ? 1.0 : 0.0))) * 2.0);
   }
+  if (use_red) return submit(stream, [=](hipStream_t s) { return pw_launch_red(p, BN, KC, s); });
   return submit(stream, [=](hipStream_t s) { return pw_launch<false, false>(p, BN, KC, s); });
 }
 

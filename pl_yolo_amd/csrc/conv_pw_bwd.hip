@@ -27,6 +27,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "bnred.h"
 
 namespace {
 
@@ -44,6 +45,7 @@ struct PbP {
   float *dgamma, *dbeta, *dgamma2, *dbeta2;
   int dout_ld, dout2_ld, dsplit, psplit, z_ld, x_ld, dx_ld;
   int M, ntiles, act, accumulate;
+  plyolo_bn_red red;     // RED instances: BatchNorm-backward reduction of the unit(s) that produced x (their output gradient is dx)
 };
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4_b;
@@ -90,7 +92,8 @@ template <int CO, int CI, int BM> struct PbGeom {
   static constexpr int NDV = BM * DV / NT, NXV = BM * XV / NT;   // vectors per thread and tile
   static constexpr int DZ_BYTES = BM * PD, X_BYTES = BM * PX, STG_BYTES = BM * PX;
   static constexpr int TAB_OFF = DZ_BYTES + X_BYTES + STG_BYTES;
-  static constexpr int LDS = TAB_OFF + 5 * CO * 4;
+  static constexpr int RTAB_OFF = TAB_OFF + 5 * CO * 4;          // RED: (scale | shift | mean | invstd) of the upstream unit(s), [4][CI]
+  static constexpr int LDS = RTAB_OFF + 4 * CI * 4;
   static_assert(MT >= 1 && BM % (32 * WM) == 0, "tile rows vs wave layout");
   static_assert(WCO * WCI * WK == NW && KSW % WK == 0 && MTC >= 1 && MTI >= 1, "eight waves");
   static_assert(NT % DV == 0 && NT % XV == 0 && (BM * DV) % NT == 0 && (BM * XV) % NT == 0, "whole vectors per thread");
@@ -99,7 +102,10 @@ template <int CO, int CI, int BM> struct PbGeom {
 
 // ACT: PLYOLO_ACT_SILU = the compile-time SiLU instance every shipped config runs (straight-line staging code: a switch on a run-time
 // activation inside the unrolled element loops compiles to a branch per element); -1 = the activation is p.act (none / relu / lrelu)
-template <int CO, int CI, int BM, int ACT>
+// RED: the dx rows this launch completes are also the output gradient of the unit(s) that produced x: their BatchNorm-backward
+// reduction (plyolo_bn_red, bnred.h) rides the dx store -- partial sums in registers across ALL tiles of a workgroup, one fold and one
+// set of fp64 slot adds per workgroup at the end
+template <int CO, int CI, int BM, int ACT, bool RED = false>
 __global__ __launch_bounds__(NT, 1) void conv_pw_bwd_kernel(const PbP p) {
   using G = PbGeom<CO, CI, BM>;
   constexpr int WN = G::WN, WM = G::WM, MT = G::MT, KSD = G::KSD;
@@ -212,6 +218,21 @@ __global__ __launch_bounds__(NT, 1) void conv_pw_bwd_kernel(const PbP p) {
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) arow[mt] = ((wm * MT + mt) * 32 + r) * PD + h * 16;
 
+  // RED: this thread's 8 dx channels (xcv) belong to one segment; its coefficients go to an LDS table (read back per tile: the
+  // 128 x 128 instance has no registers left to keep 32 of them resident), the 2 x 8 partial sums stay in registers
+  [[maybe_unused]] BnRedThread rt;
+  [[maybe_unused]] float* rtab = (float*)(smem + G::RTAB_OFF);
+  if constexpr (RED) {
+    bnred_init(rt, p.red, xcv * 8);
+    if (xrow == 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        rtab[0 * CI + xcv * 8 + i] = rt.sc[i]; rtab[1 * CI + xcv * 8 + i] = rt.sh[i];
+        rtab[2 * CI + xcv * 8 + i] = rt.mu[i]; rtab[3 * CI + xcv * 8 + i] = rt.is[i];
+      }
+    }
+  }
+
   __syncthreads();   // table complete
 
   // one tile: rows in R -> LDS image -> (R re-requested for tile + 2G) -> both products -> dx rows out
@@ -257,6 +278,14 @@ __global__ __launch_bounds__(NT, 1) void conv_pw_bwd_kernel(const PbP p) {
     for (int v = 0; v < NXV; ++v) {
       const int m = m0 + xrow + v * XRP, mc = (p.accumulate && m < p.M) ? m : 0;
       oldx[v] = *(const u32x4*)(p.dx + (size_t)mc * p.dx_ld + xcv * 8);
+    }
+    [[maybe_unused]] u32x4 zup[NXV];
+    if constexpr (RED) {
+#pragma unroll
+      for (int v = 0; v < NXV; ++v) {
+        const int m = m0 + xrow + v * XRP, mc = m < p.M ? m : 0;
+        zup[v] = rt.z ? bnred_load(rt, (size_t)mc) : u32x4{0u, 0u, 0u, 0u};
+      }
     }
     request(R, tile + 2 * G_);                                  // this register set is free again: the tile after next
     __builtin_amdgcn_sched_barrier(0);                           // ... requested ABOVE the MFMAs
@@ -317,6 +346,18 @@ __global__ __launch_bounds__(NT, 1) void conv_pw_bwd_kernel(const PbP p) {
         bf16_t* dst = p.dx + (size_t)(m0 + row) * p.dx_ld + xcv * 8;
         if (p.accumulate) val = pb_add_bf16x8(oldx[v], val);
         *(u32x4*)dst = val;
+        if constexpr (RED) {
+          if (rt.z) {
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+              const f32x4 c0 = *(const f32x4*)(rtab + 0 * CI + xcv * 8 + 4 * qq), c1 = *(const f32x4*)(rtab + 1 * CI + xcv * 8 + 4 * qq);
+              const f32x4 c2 = *(const f32x4*)(rtab + 2 * CI + xcv * 8 + 4 * qq), c3 = *(const f32x4*)(rtab + 3 * CI + xcv * 8 + 4 * qq);
+#pragma unroll
+              for (int i = 0; i < 4; ++i) { rt.sc[4 * qq + i] = c0[i]; rt.sh[4 * qq + i] = c1[i]; rt.mu[4 * qq + i] = c2[i]; rt.is[4 * qq + i] = c3[i]; }
+            }
+            bnred_add<-1>(rt, val, zup[v]);
+          }
+        }
       }
     }
     // (the next tile writes dz_s / x_s, which every wave left before B2, and staging again only behind its own B1)
@@ -331,6 +372,11 @@ __global__ __launch_bounds__(NT, 1) void conv_pw_bwd_kernel(const PbP p) {
     process(RB, tile + G_);
   }
   if (tile < p.ntiles) process(RA, tile);
+
+  if constexpr (RED) {
+    __syncthreads();                                   // the last tile's staging reads are done: LDS is free
+    bnred_flush<NT, XV>(rt, p.red, 0, (float*)smem, tid, wg % PLYOLO_STAT_SLOTS);
+  }
 
   // ---- k-split wave groups (narrow layers): fold the partial accumulators of groups 1 .. WK-1 into group 0 through LDS
   if constexpr (WK > 1) {
@@ -378,13 +424,14 @@ __global__ __launch_bounds__(NT, 1) void conv_pw_bwd_kernel(const PbP p) {
 
 // pixel-tile rows per channel count: bigger tiles for the narrow layers (their rows are short, a tile should still be several
 // tens of KB of loads in flight)
-constexpr int pb_bm(int co, int ci) { return (co >= 128 && ci >= 128) ? 64 : ((co >= 128 || ci >= 128) ? 128 : 256); }
+constexpr int pb_bm(int co, int ci) { return (co >= 128 && ci >= 128) ? 64 : ((co >= 128 || ci >= 128 || (co == 64 && ci == 64)) ? 128 : 256); }
 
 template <int CO, int CI>
 hipError_t pb_launch_inst(const PbP& p, int G_, hipStream_t s) {
   constexpr int BM = pb_bm(CO, CI);
   using G = PbGeom<CO, CI, BM>;
   auto kern = p.act == PLYOLO_ACT_SILU ? conv_pw_bwd_kernel<CO, CI, BM, PLYOLO_ACT_SILU> : conv_pw_bwd_kernel<CO, CI, BM, -1>;
+  if (p.red.n > 0) kern = p.act == PLYOLO_ACT_SILU ? conv_pw_bwd_kernel<CO, CI, BM, PLYOLO_ACT_SILU, true> : conv_pw_bwd_kernel<CO, CI, BM, -1, true>;
   if (hipError_t e = plyolo::ensure_dynamic_lds((const void*)kern, G::LDS); e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(G_), dim3(NT), G::LDS, s, p);
   return hipGetLastError();
@@ -442,7 +489,7 @@ int conv_pw_bwd_slabs(const plyolo_conv_desc* d) {
 }
 
 int conv_pw_bwd(const plyolo_conv_desc* d, const plyolo_bn_bwd_fuse* f, const void* x, const void* wpd, void* dx, int accumulate,
-                float* dwp, void* stream) {
+                float* dwp, const plyolo_bn_red* red, void* stream) {
   const PbPlan w = pb_plan(d);
   PbP p{};
   p.dout = (const bf16_t*)f->dout; p.dout_ld = f->dout_ld;
@@ -459,11 +506,13 @@ int conv_pw_bwd(const plyolo_conv_desc* d, const plyolo_bn_bwd_fuse* f, const vo
   p.ntiles = w.ntiles;
   p.act = f->act;
   p.accumulate = accumulate;
+  const bool use_red = red && red->n > 0;
+  if (use_red) p.red = *red;
   const int co = d->Cout, ci = d->Cin, G_ = w.G;
   {
     char lab[64];
-    snprintf(lab, sizeof(lab), "conv_pw_bwd<%dx%d>", co, ci);
-    annotate(lab, 4.0 * p.M * (double)co * ci, (double)p.M * (2.0 * co + ci * (accumulate ? 3.0 : 2.0)) * 2.0 + 4.0 * co * ci);
+    snprintf(lab, sizeof(lab), "conv_pw_bwd<%dx%d>%s", co, ci, use_red ? "+bnred" : "");
+    annotate(lab, 4.0 * p.M * (double)co * ci, (double)p.M * (2.0 * co + ci * ((accumulate ? 3.0 : 2.0) + (use_red ? 1.0 : 0.0))) * 2.0 + 4.0 * co * ci);
   }
   return submit(stream, [=](hipStream_t s) -> hipError_t {
 #define PB_CASE(a, b) if (co == a && ci == b) return pb_launch_inst<a, b>(p, G_, s);

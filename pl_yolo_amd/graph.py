@@ -127,6 +127,7 @@ class Graph:
         # dz, data gradient and weight gradient -- is ONE persistent launch (plyolo_conv2d_bwd_pw): dout, z and x are read once, dz
         # never reaches HBM, the bn_act_bwd_dz pass and the 1x1 weight-gradient launch of those units disappear
         self.fuse_pwbwd = os.environ.get("PLYOLO_FUSE_PWBWD", "1") == "1" and dtype == BF16 and training
+        self.diag_skip_r = os.environ.get("PLYOLO_DIAG_SKIP_R", "0") == "1"   # diagnostics only (results are wrong): no bn_act_bwd_reduce launches
         self.lazy_acts = os.environ.get("PLYOLO_LAZY", "0") in ("1", "2") and training
         # PLYOLO_LAZY=2: selective -- only where EVERY reader is a pointwise (1x1 stride-1) convolution: those kernels (and their
         # 1x1 weight gradients) are HBM-bound with an idle VALU, and there is no halo to re-pay the activation on
@@ -852,7 +853,8 @@ class ConvUnitOp:
             call("plyolo_act_bwd", g.dtype, M, Cout, dout, self.out.ld, zt, Cout, self.act, dz, Cout, 0, None)
         else:
             bslots = g.bstat_arena.data_ptr() + self.slot_off * 8
-            call("plyolo_bn_act_bwd_reduce", g.dtype, M, Cout, dout, self.out.ld, zt, Cout, self.coef.data_ptr(), self.act, bslots, None, None)
+            if not g.diag_skip_r:
+                call("plyolo_bn_act_bwd_reduce", g.dtype, M, Cout, dout, self.out.ld, zt, Cout, self.coef.data_ptr(), self.act, bslots, None, None)
             if pw_one:
                 f = BnBwdFuse()
                 f.dout, f.dout_ld, f.z, f.z_ld, f.coef, f.bslots = dout, self.out.ld, zt, Cout, self.coef.data_ptr(), bslots
@@ -993,8 +995,9 @@ class ConvPairOp:
         zt = self.z.tensor.data_ptr()
         dsp = self._split(g.gptr, self.out_b)
         bslots = g.bstat_arena.data_ptr() + self.slot_off * 8
-        call("plyolo_bn_act_bwd_reduce", g.dtype, M, Cout, g.gptr(self.out_a), self.out_a.ld, zt, Cout, self.coef.data_ptr(), self.act,
-             bslots, C.byref(dsp), None)
+        if not g.diag_skip_r:
+            call("plyolo_bn_act_bwd_reduce", g.dtype, M, Cout, g.gptr(self.out_a), self.out_a.ld, zt, Cout, self.coef.data_ptr(), self.act,
+                 bslots, C.byref(dsp), None)
         plan, lanes, me = g.plan, g.use_lanes, self.lane
         if self.pw_slabs:    # pointwise pair (CSP conv1 || conv2) of a large map: dz + data gradient + weight gradient in one launch
             f = BnBwdFuse()

@@ -403,3 +403,90 @@ def test_pointwise_unit_backward_in_one_launch(shape, act, grid, monkeypatch):
         print("pw_bwd", shape, act, "acc", acc, "slabs", ns, "dW relerr separate %.3g fused %.3g" % (e0, e1))
         assert torch.isfinite(dw1).all() and e1 <= 1e-4 and hu.relerr(dw1, dw0) <= 1e-4
         assert float(dx1.float().abs().max()) > 0
+        # ... and with the BatchNorm-backward reduction of the unit that produced x folded into the same launch
+        from pl_yolo_amd._lib import BnRed
+        zu = (torch.randn(M, Cin, device=dev) * 1.5).to(torch.bfloat16)
+        cu = torch.cat([torch.rand(Cin, device=dev) + 0.5, torch.randn(Cin, device=dev) * 0.2, torch.randn(Cin, device=dev) * 0.1, torch.rand(Cin, device=dev) + 0.5]).contiguous()
+        su = torch.zeros(STAT_SLOTS * 2 * Cin, dtype=torch.float64, device=dev)
+        red = BnRed()
+        red.n = 1
+        sg = red.seg[0]
+        sg.c0, sg.c1, sg.z, sg.z_ld, sg.coef, sg.coef_ld, sg.bslots, sg.slot_ld, sg.act = 0, Cin, zu.data_ptr(), Cin, cu.data_ptr(), Cin, su.data_ptr(), Cin, ACT["silu"]
+        dx2 = base.clone()
+        pk1.dwp.fill_(float("nan"))
+        call("plyolo_conv2d_bwd_pw_red", C.byref(d), C.byref(f), xm.data_ptr(), pk.wpd.data_ptr(), dx2.data_ptr(), acc, pk1.dwp.data_ptr(), C.byref(red), hu.stream())
+        dw2 = pk1.unpack().clone()
+        ref = torch.zeros(STAT_SLOTS * 2 * Cin, dtype=torch.float64, device=dev)
+        dxs = dx2[:, :Cin].contiguous()
+        call("plyolo_bn_act_bwd_reduce", dt, M, Cin, dxs.data_ptr(), Cin, zu.data_ptr(), Cin, cu.data_ptr(), ACT["silu"], ref.data_ptr(), None, hu.stream())
+        torch.cuda.synchronize()
+        assert torch.equal(dx2.view(torch.int16), dx1.view(torch.int16)) and torch.equal(dw2, dw1)
+        got, want = su.view(STAT_SLOTS, 2, Cin).sum(0), ref.view(STAT_SLOTS, 2, Cin).sum(0)
+        assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
+
+
+# (N, H, W, Cin, Cout, k, s, segments of dx channels): data gradients whose store loop folds the BatchNorm-backward reduction of the
+# upstream unit(s); two segments = a concatenated input (one BatchNorm unit per part), a gap = a part without a BatchNorm unit
+RED_SHAPES = [(2, 20, 20, 128, 128, 3, 1, [(0, 128)]), (3, 24, 18, 64, 64, 3, 1, [(0, 32), (32, 64)]), (1, 36, 40, 32, 32, 3, 1, [(0, 32)]),
+              (2, 32, 32, 64, 128, 3, 2, [(0, 64)]), (1, 64, 64, 32, 64, 3, 2, [(0, 32)]), (2, 26, 38, 128, 256, 3, 2, [(0, 64), (64, 128)]),
+              (2, 20, 20, 128, 128, 1, 1, [(0, 128)]), (3, 13, 9, 64, 96, 1, 1, [(8, 40)]), (2, 40, 40, 256, 80, 1, 1, [(0, 128), (128, 256)]),
+              (4, 20, 20, 128, 16, 1, 1, [(0, 128)])]
+
+
+@pytest.mark.parametrize("shape", RED_SHAPES, ids=str)
+@pytest.mark.parametrize("acc", [0, 1])
+def test_dgrad_folds_upstream_bn_reduction(shape, acc):
+    """plyolo_conv2d_dgrad_red == plyolo_conv2d_dgrad (dx bit for bit) + plyolo_bn_act_bwd_reduce of the FINAL dx against the upstream
+    unit's z, per segment: the sums land in the segment's own slots (other channels of the unit untouched), 3x3 stride 1 / 2 and
+    pointwise kernels, ragged maps, accumulation into dx."""
+    from pl_yolo_amd._lib import ACT, BnRed, STAT_SLOTS
+    N, H, W, Cin, Cout, k, st, segs = shape
+    dt = BF16
+    torch.manual_seed(sum(shape[:7]) + 11)
+    dev = hu.DEV
+    pad = (k - 1) // 2
+    OH, OW = (H + 2 * pad - k) // st + 1, (W + 2 * pad - k) // st + 1
+    Mi, Mo = N * H * W, N * OH * OW
+    w = hu.rnd_bf16(torch.randn(Cout, Cin, k, k, device=dev) / (Cout * k * k) ** 0.5)
+    pk = hu.Packed(w, dt)
+    y_ld, x_ld = (Cout + 7) // 8 * 8 + 8, Cin + 8
+    dy = torch.zeros(Mo, y_ld, device=dev)
+    dy[:, :Cout] = torch.randn(Mo, Cout, device=dev)
+    dy = dy.to(torch.bfloat16)
+    d = hu.conv_desc(dt, N, H, W, Cin, Cout, k, st, x_ld, y_ld)
+    lib = hu._lib.lib()
+    assert lib.plyolo_conv2d_dgrad_red_fits(C.byref(d)) == 1
+    base = torch.randn(Mi, x_ld, device=dev).to(torch.bfloat16)
+    dx0 = base.clone()
+    call("plyolo_conv2d_dgrad", C.byref(d), dy.data_ptr(), pk.wpd.data_ptr(), dx0.data_ptr(), acc, hu.stream())
+    red = BnRed()
+    red.n = len(segs)
+    keep = []
+    for i, (c0, c1) in enumerate(segs):
+        Cu, off = (c1 - c0) + 16, 8                # the unit has more channels than this segment: [off, off + c1 - c0) of them
+        z = (torch.randn(Mi, Cu, device=dev) * 1.5).to(torch.bfloat16)
+        coef = torch.cat([torch.rand(Cu, device=dev) + 0.5, torch.randn(Cu, device=dev) * 0.2, torch.randn(Cu, device=dev) * 0.1, torch.rand(Cu, device=dev) + 0.5]).contiguous()
+        slots = torch.zeros(STAT_SLOTS * 2 * Cu, dtype=torch.float64, device=dev)
+        act = ACT["silu" if i == 0 else "lrelu"]
+        sg = red.seg[i]
+        sg.c0, sg.c1, sg.z, sg.z_ld = c0, c1, z.data_ptr() + off * 2, Cu
+        sg.coef, sg.coef_ld, sg.bslots, sg.slot_ld, sg.act = coef.data_ptr() + off * 4, Cu, slots.data_ptr() + off * 8, Cu, act
+        keep.append((z, coef, slots, act, Cu, off, c0, c1))
+    dx1 = base.clone()
+    call("plyolo_conv2d_dgrad_red", C.byref(d), dy.data_ptr(), pk.wpd.data_ptr(), dx1.data_ptr(), acc, C.byref(red), hu.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(dx0.view(torch.int16), dx1.view(torch.int16)), "dx differs"
+    for (z, coef, slots, act, Cu, off, c0, c1) in keep:
+        n = c1 - c0
+        ref = torch.zeros(STAT_SLOTS * 2 * n, dtype=torch.float64, device=dev)
+        dxs = dx1[:, c0:c1].contiguous()
+        zs = z[:, off:off + n].contiguous()
+        cf = coef.view(4, Cu)[:, off:off + n].contiguous()
+        call("plyolo_bn_act_bwd_reduce", dt, Mi, n, dxs.data_ptr(), n, zs.data_ptr(), n, cf.data_ptr(), act, ref.data_ptr(), None, hu.stream())
+        torch.cuda.synchronize()
+        got = slots.view(STAT_SLOTS, 2, Cu).sum(0)
+        want = ref.view(STAT_SLOTS, 2, n).sum(0)
+        assert float(got[:, :off].abs().max()) == 0.0 and float(got[:, off + n:].abs().max()) == 0.0, "slots outside the segment touched"
+        err = float((got[:, off:off + n] - want).abs().max()) / max(float(want.abs().max()), 1e-9)
+        print("dgrad_red", shape[:7], (c0, c1), "acc", acc, "slot sums rel err %.2e" % err)
+        assert err <= 2e-5 and float(want.abs().max()) > 0
