@@ -55,6 +55,13 @@ DEVINL void bnred_add(BnRedThread& t, const u32x4 dx, const u32x4 zz) {
   }
 }
 
+// run-time activation, dispatched once per VECTOR: SiLU (every shipped config) takes the straight-line instance -- a switch on the
+// activation inside the unrolled element loop compiles to a branch per element
+DEVINL void bnred_add_any(BnRedThread& t, const u32x4 dx, const u32x4 zz) {
+  if (t.act == PLYOLO_ACT_SILU) bnred_add<PLYOLO_ACT_SILU>(t, dx, zz);
+  else bnred_add<-1>(t, dx, zz);
+}
+
 // Workgroup fold + slot adds.  `lds` = NT / VPR x 2 x (VPR * 8) floats of scratch (may alias the store loop's staging: the caller
 // has synchronised behind it); thread layout of the partials: channel vector tid % VPR, row group tid / VPR.  The 2 * VPR * 8 column
 // sums are dealt over the threads (one fixed-order sum of NT / VPR partials and one atomic each); cbase = first dx channel of the

@@ -599,7 +599,7 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
           u32x4 val = *(const u32x4*)(smem + m * SROW + v * 16);
           if (p.accumulate) val = add_bf16x8(old[it], val);
           *(u32x4*)(y + pixs[it] * p.y_ld + co) = val;
-          if (rt.z) bnred_add<-1>(rt, val, zq[it]);
+          if (rt.z) bnred_add_any(rt, val, zq[it]);
         }
       }
       __syncthreads();   // every thread is done with the staging rows: the fold reuses them

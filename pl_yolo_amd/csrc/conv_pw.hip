@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256, BNB ? 3 : 2) void conv_pw_kernel(const PwP p) 
           u32x4 val = *(const u32x4*)(smem + m * SROW + v * 16);
           if (p.accumulate) val = pw_add_bf16x8(old[it], val);
           *(u32x4*)(y + (size_t)(m0 + m) * p.y_ld + co) = val;
-          if (rt.z) bnred_add<-1>(rt, val, zq[it]);
+          if (rt.z) bnred_add_any(rt, val, zq[it]);
         }
       }
       __syncthreads();   // every thread is done with the staging rows: the fold reuses them

@@ -355,7 +355,7 @@ __global__ __launch_bounds__(NT, 1) void conv_pw_bwd_kernel(const PbP p) {
 #pragma unroll
               for (int i = 0; i < 4; ++i) { rt.sc[4 * qq + i] = c0[i]; rt.sh[4 * qq + i] = c1[i]; rt.mu[4 * qq + i] = c2[i]; rt.is[4 * qq + i] = c3[i]; }
             }
-            bnred_add<-1>(rt, val, zup[v]);
+            bnred_add_any(rt, val, zup[v]);
           }
         }
       }

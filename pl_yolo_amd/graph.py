@@ -21,7 +21,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import BF16, F32, ACT, STAT_SLOTS, BnStats, Split, BnBwdSplit, BnBwdFuse, ConvDesc, PackEntry, YoloxDesc, yolov7_desc, call, ptr
+from ._lib import BF16, F32, ACT, STAT_SLOTS, BnStats, Split, BnBwdSplit, BnBwdFuse, BnRed, BN_RED_SEGS, ConvDesc, PackEntry, YoloxDesc, yolov7_desc, call, ptr
 
 BN_EPS_DEFAULT = 1e-3
 
@@ -128,6 +128,12 @@ class Graph:
         # never reaches HBM, the bn_act_bwd_dz pass and the 1x1 weight-gradient launch of those units disappear
         self.fuse_pwbwd = os.environ.get("PLYOLO_FUSE_PWBWD", "1") == "1" and dtype == BF16 and training
         self.diag_skip_r = os.environ.get("PLYOLO_DIAG_SKIP_R", "0") == "1"   # diagnostics only (results are wrong): no bn_act_bwd_reduce launches
+        # PLYOLO_FUSE_BNRED (default on, round 4): bn_act_bwd_reduce of a unit rides the store loop of the data gradient that writes the
+        # unit's output gradient LAST (plan_bn_red): dx is not read back, one launch less per unit on the data-gradient chain
+        self.fuse_bnred = os.environ.get("PLYOLO_FUSE_BNRED", "1") == "1" and dtype == BF16 and training
+        self.red_plan = {}      # (id(producer op), id(input Act)) -> [(c0, c1, unit op, channel offset inside the unit)]
+        self.gm_log = []        # (op, Act) of every gradient write of the backward recording (plan_bn_red is verified against it)
+        self.cur_op = None
         self.lazy_acts = os.environ.get("PLYOLO_LAZY", "0") in ("1", "2") and training
         # PLYOLO_LAZY=2: selective -- only where EVERY reader is a pointwise (1x1 stride-1) convolution: those kernels (and their
         # 1x1 weight gradients) are HBM-bound with an idle VALU, and there is no halo to re-pay the activation on
@@ -261,6 +267,116 @@ class Graph:
                 fn()
             plan.lane(l)
             self.pending[l] = []
+
+    # ------------------------------------------------------------------ BatchNorm-backward reduction inside data gradients
+    def plan_bn_red(self):
+        """Before the backward plan is recorded: which data gradient writes the output gradient of every BatchNorm unit LAST?  When
+        that writer is a convolution data gradient with a RED kernel instance and its dx covers the unit's output view (one of up to
+        three channel segments of a concatenated input), the unit's bn_act_bwd_reduce launch is dropped and the writer folds the two
+        per-channel sums while it stores dx (plyolo_conv2d_dgrad_red / plyolo_conv2d_bwd_pw_red).  A unit is only taken when ALL its
+        output views are covered (both halves of a merged pair).  Gradient accumulations into one buffer run in list order
+        (record_ops), so "last in reversed(ops)" is the last writer whatever lanes the ops sit on; record_ops logs every actual
+        gradient write and check_bn_red() compares."""
+        self.red_plan, self.gm_log = {}, []
+        for op in self.ops:
+            if hasattr(op, "red_done"):
+                op.red_done = False
+        if not self.fuse_bnred:
+            return
+        lib = _lib.lib()
+        views = []     # (unit, Act view, channel offset inside the unit)
+        for op in self.ops:
+            if isinstance(op, ConvUnitOp) and op.bn is not None and op.conv_b is None and hasattr(op, "coef"):
+                views.append((op, op.out, 0))
+            elif isinstance(op, ConvPairOp) and hasattr(op, "coef"):
+                views.append((op, op.out_a, 0))
+                views.append((op, op.out_b, op.Ca))
+        # gradient writes in backward order: (op, input Act, is a convolution data gradient with a RED instance)
+        writes = []
+        for op in reversed(self.ops):
+            if isinstance(op, ConvUnitOp):
+                if op.res is not None:
+                    writes.append((op, op.res, False))
+                if op.need_dgrad:
+                    ok = op.bn is not None and hasattr(op, "desc_d") and (bool(op.pw_slabs) or lib.plyolo_conv2d_dgrad_red_fits(C.byref(op.desc_d)) == 1)
+                    writes.append((op, op.x, ok and not (self.fuse_bnbwd and op.k == 1)))
+            elif isinstance(op, ConvPairOp):
+                ok = hasattr(op, "desc_d") and (bool(op.pw_slabs) or lib.plyolo_conv2d_dgrad_red_fits(C.byref(op.desc_d)) == 1)
+                writes.append((op, op.x, ok and not self.fuse_bnbwd))
+            elif isinstance(op, HeadPredOp):
+                writes.append((op, op.reg_feat, lib.plyolo_conv2d_dgrad_red_fits(C.byref(op.dgrad_descs()[0])) == 1))
+                writes.append((op, op.cls_feat, lib.plyolo_conv2d_dgrad_red_fits(C.byref(op.dgrad_descs()[1])) == 1))
+            else:
+                try:
+                    ins, _ = op_io(op)
+                except TypeError:
+                    ins = []
+                for a in ins:
+                    if isinstance(a, Act):
+                        writes.append((op, a, False))
+        plan, covered = {}, {}
+        for (u, v, choff) in views:
+            rv = _res(v)
+            last = None
+            for (wop, a, ok) in writes:
+                if _overlap(_res(a), rv):
+                    last = (wop, a, ok)
+            if last is None:
+                continue
+            wop, a, ok = last
+            ra = _res(a)
+            if not ok or ra[0] != rv[0] or ra[1] > rv[1] or ra[2] < rv[2]:
+                continue
+            plan.setdefault((id(wop), id(a)), []).append((rv[1] - ra[1], rv[2] - ra[1], u, choff))
+            covered.setdefault(id(u), []).append((u, v))
+        # a producer takes at most BN_RED_SEGS segments; a unit needs all its views taken
+        for key in [k for k, segs in plan.items() if len(segs) > BN_RED_SEGS]:
+            for (_, _, u, _) in plan.pop(key):
+                covered[id(u)] = [(uu, vv) for (uu, vv) in covered.get(id(u), []) if False]
+        nviews = {}
+        for (u, v, choff) in views:
+            nviews[id(u)] = nviews.get(id(u), 0) + 1
+        full = {uid for uid, lst in covered.items() if len(lst) == nviews.get(uid, 0) and lst}
+        for key, segs in plan.items():
+            keep = [sg for sg in segs if id(sg[2]) in full]
+            if keep:
+                self.red_plan[key] = keep
+        for (u, v, choff) in views:
+            if id(u) in full and any(any(sg[2] is u for sg in segs) for segs in self.red_plan.values()):
+                u.red_done = True
+
+    def red_for(self, op, a):
+        """plyolo_bn_red of producer `op` for its input view `a` (None: nothing planned).  The returned struct must stay alive."""
+        segs = self.red_plan.get((id(op), id(a)))
+        if not segs:
+            return None
+        r = BnRed()
+        r.n = len(segs)
+        for i, (c0, c1, u, choff) in enumerate(segs):
+            sg = r.seg[i]
+            ct = u.Cout
+            sg.c0, sg.c1 = c0, c1
+            sg.z, sg.z_ld = u.z.tensor.data_ptr() + choff * self.esize, ct
+            sg.coef, sg.coef_ld = u.coef.data_ptr() + choff * 4, ct
+            sg.bslots, sg.slot_ld = self.bstat_arena.data_ptr() + (u.slot_off + choff) * 8, ct
+            sg.act = u.act
+        self.keep.append(r)
+        return r
+
+    def check_bn_red(self):
+        """After the backward recording: every planned producer really was the last gradient writer of its segments."""
+        for (opid, aid), segs in self.red_plan.items():
+            for (c0, c1, u, choff) in segs:
+                views = [u.out] if isinstance(u, ConvUnitOp) else [u.out_a, u.out_b]
+                v = views[0] if choff == 0 else views[1]
+                rv = _res(v)
+                last = None
+                for (wop, a) in self.gm_log:
+                    if _overlap(_res(a), rv):
+                        last = (wop, a)
+                if last is None or id(last[0]) != opid or id(last[1]) != aid:
+                    raise _lib.PlyoloError("plan_bn_red: the planned last writer of a unit's output gradient is not the recorded one "
+                                           "(%s planned, %s recorded)" % (opid, type(last[0]).__name__ if last else None))
 
     def pw_bwd_slabs(self, desc, act, ok=True):
         """Private weight-gradient slabs of plyolo_conv2d_bwd_pw for this unit, or 0 when the unit keeps the separate
@@ -457,6 +573,8 @@ class Graph:
         flag (0 = first writer).  A partially initialised view gets its missing channels
         zero-filled first so that a single accumulate launch is correct."""
         st = a.storage
+        if self.cur_op is not None:
+            self.gm_log.append((self.cur_op, a))
         flags = st.ginit[a.c_off:a.c_off + a.C]
         if not any(flags):
             acc = 0
@@ -580,7 +698,9 @@ def record_ops(g, plan, ops, method, lanes=True, after=None):
     if not g.side_lanes:
         for op in ops:
             plan.lane(0)
+            g.cur_op = op
             getattr(op, method)()
+            g.cur_op = None
             mark(op)
         plan.lane(0)
         g.flush_reduce_on_lane()
@@ -645,7 +765,9 @@ def record_ops(g, plan, ops, method, lanes=True, after=None):
                 plan.wait(l, ev0)
             for j in deps[i]:
                 plan.wait(l, ev[j])
+            g.cur_op = ops[i]
             getattr(ops[i], method)()
+            g.cur_op = None
             plan.lane(l)
             if need_ev[i]:
                 ev[i] = plan.record(l)
@@ -749,6 +871,7 @@ class ConvUnitOp:
         self.out = g.new_act(x.N, self.OH, self.OW, Cout, "a")
         self.out.producer = self
         self.lazy_out = False          # set by Graph.resolve_lazy(): the activated output is never written
+        self.red_done = False          # set by Graph.plan_bn_red(): the data gradient(s) behind `out` fold this unit's bn_act_bwd_reduce
         x.lazy_users.append(self)      # this unit can apply its producer's BatchNorm + activation while staging x
         if residual is not None:
             residual.needs_tensor = True
@@ -853,7 +976,7 @@ class ConvUnitOp:
             call("plyolo_act_bwd", g.dtype, M, Cout, dout, self.out.ld, zt, Cout, self.act, dz, Cout, 0, None)
         else:
             bslots = g.bstat_arena.data_ptr() + self.slot_off * 8
-            if not g.diag_skip_r:
+            if not (g.diag_skip_r or self.red_done):
                 call("plyolo_bn_act_bwd_reduce", g.dtype, M, Cout, dout, self.out.ld, zt, Cout, self.coef.data_ptr(), self.act, bslots, None, None)
             if pw_one:
                 f = BnBwdFuse()
@@ -862,7 +985,9 @@ class ConvUnitOp:
                 f.act = self.act
                 self.keep_f = f
                 acc = g.grad_mode(self.x)
-                call("plyolo_conv2d_bwd_pw", C.byref(self.desc_d), C.byref(f), self.xptr, self.pc.wpd, g.gptr(self.x), acc, self.pc.dwp, None)
+                red = g.red_for(self, self.x)
+                call("plyolo_conv2d_bwd_pw_red", C.byref(self.desc_d), C.byref(f), self.xptr, self.pc.wpd, g.gptr(self.x), acc, self.pc.dwp,
+                     C.byref(red) if red is not None else None, None)
                 if lanes:     # only the slab fold is left for the weight-gradient lane
                     g.defer_param_grads(me, self.pc.reduce_slabs)
                 else:
@@ -889,7 +1014,9 @@ class ConvUnitOp:
                 if fused:
                     call("plyolo_conv2d_dgrad_bn", C.byref(self.desc_d), C.byref(f), self.pc.wpd, g.gptr(self.x), acc, None)
                 else:
-                    call("plyolo_conv2d_dgrad", C.byref(self.desc_d), dz, self.pc.wpd, g.gptr(self.x), acc, None)
+                    red = g.red_for(self, self.x)
+                    call("plyolo_conv2d_dgrad_red", C.byref(self.desc_d), dz, self.pc.wpd, g.gptr(self.x), acc,
+                         C.byref(red) if red is not None else None, None)
 
         def wgrad():
             call("plyolo_conv2d_wgrad", C.byref(self.desc), self.xptr, dz, self.pc.dwp, None)
@@ -931,6 +1058,7 @@ class ConvPairOp:
         self.out_b = g.new_act(x.N, self.OH, self.OW, Cb, "a")
         self.out_a.producer = self.out_b.producer = self
         self.lazy_out = False
+        self.red_done = False
         x.lazy_users.append(self)
         self.out = self.out_a
         self.z = Storage(x.N, self.OH, self.OW, self.Cout, "z")
@@ -995,7 +1123,7 @@ class ConvPairOp:
         zt = self.z.tensor.data_ptr()
         dsp = self._split(g.gptr, self.out_b)
         bslots = g.bstat_arena.data_ptr() + self.slot_off * 8
-        if not g.diag_skip_r:
+        if not (g.diag_skip_r or self.red_done):
             call("plyolo_bn_act_bwd_reduce", g.dtype, M, Cout, g.gptr(self.out_a), self.out_a.ld, zt, Cout, self.coef.data_ptr(), self.act,
                  bslots, C.byref(dsp), None)
         plan, lanes, me = g.plan, g.use_lanes, self.lane
@@ -1008,7 +1136,9 @@ class ConvPairOp:
             f.act = self.act
             self.keep_f = f
             acc = g.grad_mode(self.x)
-            call("plyolo_conv2d_bwd_pw", C.byref(self.desc_d), C.byref(f), self.xptr, self.pc.wpd, g.gptr(self.x), acc, self.pc.dwp, None)
+            red = g.red_for(self, self.x)
+            call("plyolo_conv2d_bwd_pw_red", C.byref(self.desc_d), C.byref(f), self.xptr, self.pc.wpd, g.gptr(self.x), acc, self.pc.dwp,
+                 C.byref(red) if red is not None else None, None)
             if lanes:
                 g.defer_param_grads(me, self.pc.reduce_slabs)
             else:
@@ -1039,7 +1169,9 @@ class ConvPairOp:
             if fused:
                 call("plyolo_conv2d_dgrad_bn", C.byref(self.desc_d), C.byref(f), self.pc.wpd, g.gptr(self.x), acc, None)
             else:
-                call("plyolo_conv2d_dgrad", C.byref(self.desc_d), dz, self.pc.wpd, g.gptr(self.x), acc, None)
+                red = g.red_for(self, self.x)
+                call("plyolo_conv2d_dgrad_red", C.byref(self.desc_d), dz, self.pc.wpd, g.gptr(self.x), acc,
+                     C.byref(red) if red is not None else None, None)
 
         if lanes:
             dgrad()
@@ -1530,6 +1662,17 @@ class HeadPredOp:
         base = hd.draw.data_ptr() + row0 * hd.nch * 4
         return [(base, M, 5, hd.nch, self.pc_ro.dbp), (base + 5 * 4, M, self.nc, hd.nch, self.pc_cls.dbp)]
 
+    def dgrad_descs(self):
+        """(reg+obj, cls) descriptors of the two data gradients (x_ld = pitch of the features' gradient matrices)."""
+        g, hd = self.g, self.head
+        if g.dtype == BF16:
+            return (conv_desc(g, self.d_ro.N, self.d_ro.H, self.d_ro.W, self.d_ro.Cin, 5, 1, 1, self.reg_feat.ld, 16, 0),
+                    conv_desc(g, self.d_cls.N, self.d_cls.H, self.d_cls.W, self.d_cls.Cin, self.nc, 1, 1, self.cls_feat.ld, hd.cls_ld, 0))
+        d_ro, d_cl = _copy_desc(self.d_ro), _copy_desc(self.d_cls)
+        d_ro.x_ld, d_cl.x_ld = self.reg_feat.ld, self.cls_feat.ld
+        d_ro.x_coef = d_cl.x_coef = None
+        return d_ro, d_cl
+
     def fwd(self):
         g, hd = self.g, self.head
         base = hd.raw.data_ptr() + hd.lvl_row[self.level] * hd.nch * 4
@@ -1544,18 +1687,14 @@ class HeadPredOp:
         g, hd = self.g, self.head
         row0 = hd.lvl_row[self.level]
         M = self.cls_feat.M
+        d_ro, d_cl = self.dgrad_descs()
         if g.dtype == BF16:
             dro = hd.d_regobj.data_ptr() + row0 * 16 * 2
             dcl = hd.d_cls.data_ptr() + row0 * hd.cls_ld * 2
-            d_ro = conv_desc(g, self.d_ro.N, self.d_ro.H, self.d_ro.W, self.d_ro.Cin, 5, 1, 1, self.reg_feat.ld, 16, 0)
-            d_cl = conv_desc(g, self.d_cls.N, self.d_cls.H, self.d_cls.W, self.d_cls.Cin, self.nc, 1, 1, self.cls_feat.ld, hd.cls_ld, 0)
             ld_ro, ld_cl = 16, hd.cls_ld
         else:
             base = hd.draw.data_ptr() + row0 * hd.nch * 4
             dro, dcl = base, base + 5 * 4
-            d_ro, d_cl = _copy_desc(self.d_ro), _copy_desc(self.d_cls)
-            d_ro.x_ld, d_cl.x_ld = self.reg_feat.ld, self.cls_feat.ld
-            d_ro.x_coef = d_cl.x_coef = None
             ld_ro = ld_cl = hd.nch
         # d_ro / d_cl: data gradients (x_ld = pitch of the features' gradient matrices); w_ro / w_cl: weight gradients
         # (x = the features as the forward read them: stored, or the producer's z + coefficients)
@@ -1569,9 +1708,11 @@ class HeadPredOp:
         # forward features -- are not written again in this plan)
         lanes, me = g.use_lanes, self.lane
         acc = g.grad_mode(self.reg_feat)
-        call("plyolo_conv2d_dgrad", C.byref(d_ro), dro, self.pc_ro.wpd, g.gptr(self.reg_feat), acc, None)
+        red = g.red_for(self, self.reg_feat)
+        call("plyolo_conv2d_dgrad_red", C.byref(d_ro), dro, self.pc_ro.wpd, g.gptr(self.reg_feat), acc, C.byref(red) if red is not None else None, None)
         acc = g.grad_mode(self.cls_feat)
-        call("plyolo_conv2d_dgrad", C.byref(d_cl), dcl, self.pc_cls.wpd, g.gptr(self.cls_feat), acc, None)
+        red = g.red_for(self, self.cls_feat)
+        call("plyolo_conv2d_dgrad_red", C.byref(d_cl), dcl, self.pc_cls.wpd, g.gptr(self.cls_feat), acc, C.byref(red) if red is not None else None, None)
 
         def param_grads():
             if not getattr(hd, "bias_fused", False):     # else: one launch for every level, behind the loss backward (YoloxLossOp.bwd)

@@ -207,11 +207,15 @@ class DetectorRunner:
                     # layers that fill them are done (pl_yolo_amd/ddp.py: BucketSchedule)
                     from . import ddp as D
                     s.sched = D.BucketSchedule(self, s, g)
+                    g.plan_bn_red()
                     G.record_ops(g, s.bwd, list(reversed(g.ops)), "bwd", after=s.sched.after)
+                    g.check_bn_red()
                     s.sched.finish()
                     g.join_lanes()
                 else:
+                    g.plan_bn_red()
                     G.record_ops(g, s.bwd, list(reversed(g.ops)), "bwd")
+                    g.check_bn_red()
                     g.join_lanes()
                     g.unpack_wgrads()
                     for op in g.post_unpack:
