@@ -93,7 +93,9 @@ constexpr int PW_BM = 128;
 template <int BN, bool BNB> constexpr int pw_bm() { return (BNB && BN >= 64) ? 64 : PW_BM; }
 
 // RED: the bf16 store loop also folds the BatchNorm-backward reduction of the upstream unit(s) (bnred.h)
-template <int BN, int KC, bool OUT_F32, bool PRE, bool PIPE, bool BNB = false, bool RED = false>
+// BACT (BNB instances): PLYOLO_ACT_SILU = the activation of the unit is SiLU at compile time (a switch on a run-time activation
+// inside the unrolled element loop of the loader compiles to a branch per element), -1 = p.bact
+template <int BN, int KC, bool OUT_F32, bool PRE, bool PIPE, bool BNB = false, bool RED = false, int BACT = -1>
 __global__ __launch_bounds__(256, BNB ? 3 : 2) void conv_pw_kernel(const PwP p) {
   static_assert(!RED || (!OUT_F32 && !PRE && !BNB), "RED instances: plain bf16 data gradients");
   constexpr int BM = pw_bm<BN, BNB>();
@@ -224,8 +226,8 @@ __global__ __launch_bounds__(256, BNB ? 3 : 2) void conv_pw_kernel(const PwP p) 
         for (int i = 0; i < 4; ++i) {
           const float zl = __uint_as_float(zz[i] << 16), zh = __uint_as_float(zz[i] & 0xffff0000u);
           const float dl = __uint_as_float(t[i] << 16), dh = __uint_as_float(t[i] & 0xffff0000u);
-          const float dul = dl * pw_act_grad(fmaf(zl, sc[2 * i], sh[2 * i]), p.bact);
-          const float duh = dh * pw_act_grad(fmaf(zh, sc[2 * i + 1], sh[2 * i + 1]), p.bact);
+          const float dul = dl * pw_act_grad(fmaf(zl, sc[2 * i], sh[2 * i]), BACT >= 0 ? BACT : p.bact);
+          const float duh = dh * pw_act_grad(fmaf(zh, sc[2 * i + 1], sh[2 * i + 1]), BACT >= 0 ? BACT : p.bact);
           t[i] = pack2bf(fmaf(A[2 * i], dul, fmaf(B[2 * i], zl, Cc[2 * i])), fmaf(A[2 * i + 1], duh, fmaf(B[2 * i + 1], zh, Cc[2 * i + 1])));
         }
         av[v] = t;
@@ -531,7 +533,7 @@ hipError_t pw_launch_bnb_inst(const PwP& p, hipStream_t s) {
   const size_t lds_main = (size_t)BM * ROWB + (size_t)5 * p.K * 4;   // row tile + the per-channel table
   const size_t lds_epi = (size_t)BM * SROW + WM * 2 * BN * 4;
   const size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
-  auto kern = conv_pw_kernel<BN, KC, false, false, false, true>;
+  auto kern = p.bact == PLYOLO_ACT_SILU ? conv_pw_kernel<BN, KC, false, false, false, true, false, PLYOLO_ACT_SILU> : conv_pw_kernel<BN, KC, false, false, false, true>;
   if (hipError_t e = plyolo::ensure_dynamic_lds((const void*)kern, lds); e != hipSuccess) return e;
   const int nmt = (p.M + BM - 1) / BM;
   PwP q = p;
