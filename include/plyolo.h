@@ -407,6 +407,10 @@ typedef struct plyolo_bn_bwd_fuse {
 int plyolo_conv2d_dgrad_bn_fits(const plyolo_conv_desc* d, int act);
 int plyolo_conv2d_dgrad_bn(const plyolo_conv_desc* d, const plyolo_bn_bwd_fuse* f, const void* wpd, void* dx,
                            int accumulate, void* stream);
+/* ... + the BatchNorm-backward reduction of the unit(s) that produced x (struct plyolo_bn_red, below) */
+struct plyolo_bn_red;
+int plyolo_conv2d_dgrad_bn_red(const plyolo_conv_desc* d, const plyolo_bn_bwd_fuse* f, const void* wpd, void* dx,
+                               int accumulate, const struct plyolo_bn_red* red, void* stream);
 
 /* The WHOLE backward of a pointwise BaseConv unit behind plyolo_bn_act_bwd_reduce, in one persistent launch (csrc/conv_pw_bwd.hip):
  * dz = plyolo_bn_act_bwd_dz(dout, z) is formed tile by tile in LDS and feeds both dx (+)= dz . W (== plyolo_conv2d_dgrad, bit for

@@ -177,6 +177,7 @@ SIGNATURES = {
     "plyolo_conv2d_wgrad": (_i, [_P(ConvDesc), _vp, _vp, _vp, _vp]),
     "plyolo_conv2d_dgrad_bn_fits": (_i, [_P(ConvDesc), _i]),
     "plyolo_conv2d_dgrad_bn": (_i, [_P(ConvDesc), _P(BnBwdFuse), _vp, _vp, _i, _vp]),
+    "plyolo_conv2d_dgrad_bn_red": (_i, [_P(ConvDesc), _P(BnBwdFuse), _vp, _vp, _i, _P(BnRed), _vp]),
     "plyolo_conv2d_dgrad_red": (_i, [_P(ConvDesc), _vp, _vp, _vp, _i, _P(BnRed), _vp]),
     "plyolo_conv2d_dgrad_red_fits": (_i, [_P(ConvDesc)]),
     "plyolo_conv2d_bwd_pw_red": (_i, [_P(ConvDesc), _P(BnBwdFuse), _vp, _vp, _vp, _i, _vp, _P(BnRed), _vp]),

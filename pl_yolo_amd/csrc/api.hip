@@ -62,7 +62,7 @@ bool conv_pw_enabled();
 int conv_pw_fwd(const plyolo_conv_desc*, const void*, const void*, const float*, void*, double*, const float*, int, const void*, int, void*);
 int conv_pw_dgrad(const plyolo_conv_desc*, const void*, const void*, void*, int, const plyolo_bn_red*, void*, int*);
 int conv_pw_dgrad_bn_fits(const plyolo_conv_desc*, int);
-int conv_pw_dgrad_bn(const plyolo_conv_desc*, const plyolo_bn_bwd_fuse*, const void*, void*, int, void*);
+int conv_pw_dgrad_bn(const plyolo_conv_desc*, const plyolo_bn_bwd_fuse*, const void*, void*, int, const plyolo_bn_red*, void*);
 int conv_pw_bwd_fits(const plyolo_conv_desc*, int);
 int conv_pw_bwd_slabs(const plyolo_conv_desc*);
 int conv_pw_bwd(const plyolo_conv_desc*, const plyolo_bn_bwd_fuse*, const void*, const void*, void*, int, float*, const plyolo_bn_red*, void*);
@@ -501,13 +501,18 @@ int plyolo_conv2d_dgrad_bn_fits(const plyolo_conv_desc* d, int act) {
   return conv_pw_dgrad_bn_fits(d, act);
 }
 int plyolo_conv2d_dgrad_bn(const plyolo_conv_desc* d, const plyolo_bn_bwd_fuse* f, const void* wpd, void* dx, int accumulate, void* stream) {
+  return plyolo_conv2d_dgrad_bn_red(d, f, wpd, dx, accumulate, nullptr, stream);
+}
+int plyolo_conv2d_dgrad_bn_red(const plyolo_conv_desc* d, const plyolo_bn_bwd_fuse* f, const void* wpd, void* dx, int accumulate,
+                               const plyolo_bn_red* red, void* stream) {
   if (check_conv(d, "conv2d_dgrad_bn", false)) return -1;
+  if (red && red->n > 0 && check_red(red, d, "conv2d_dgrad_bn_red")) return -1;
   PLY_CHECK_ARG(f && f->dout && f->z && f->coef && f->bslots && f->dz, "conv2d_dgrad_bn: incomplete plyolo_bn_bwd_fuse");
   PLY_CHECK_ARG(conv_pw_dgrad_bn_fits(d, f->act) == 1, "conv2d_dgrad_bn: this unit is not covered (ask plyolo_conv2d_dgrad_bn_fits; use plyolo_bn_act_bwd_dz + plyolo_conv2d_dgrad)");
   PLY_CHECK_ARG(f->dout_ld % 8 == 0 && f->z_ld % 8 == 0 && f->dz_ld % 8 == 0 && f->dz_ld >= d->Cout && f->z_ld >= d->Cout, "conv2d_dgrad_bn: pitches must be multiples of 8 and hold Cout channels");
   PLY_CHECK_ARG(!f->dout2 || (f->dout_split > 0 && f->dout_split < d->Cout && f->dout_split % 8 == 0 && f->dout2_ld % 8 == 0), "conv2d_dgrad_bn: bad output-gradient split");
   PLY_CHECK_ARG(f->par_split == 0 || (f->par_split > 0 && f->par_split < d->Cout), "conv2d_dgrad_bn: bad parameter split");
-  return conv_pw_dgrad_bn(d, f, wpd, dx, accumulate, stream);
+  return conv_pw_dgrad_bn(d, f, wpd, dx, accumulate, red, stream);
 }
 int plyolo_conv2d_bwd_pw_fits(const plyolo_conv_desc* d, int act) {
   if (check_conv(d, "conv2d_bwd_pw_fits", false)) return -1;

@@ -50,6 +50,27 @@ DEVINL float act_fwd_core(float u, int act) {
     default: return u;
   }
 }
+// act(x * sc + sh) on the 8 bf16 channels of one staged 16-byte vector (lazy-input loaders).  The activation is dispatched ONCE
+// per vector: a switch on a run-time activation inside the unrolled element loop compiles to a branch per element, which serialises
+// the exp / rcp chains of the elements (round 4: that, not the arithmetic itself, was most of what the lazy loaders cost)
+DEVINL u32x4 bn_act_vec8(u32x4 t, const float* sc, const float* sh, const int act) {
+  if (act == PLYOLO_ACT_SILU) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float lo = act_fwd_core(fmaf(__uint_as_float(t[i] << 16), sc[2 * i], sh[2 * i]), PLYOLO_ACT_SILU);
+      const float hi = act_fwd_core(fmaf(__uint_as_float(t[i] & 0xffff0000u), sc[2 * i + 1], sh[2 * i + 1]), PLYOLO_ACT_SILU);
+      t[i] = pack2bf(lo, hi);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float lo = act_fwd_core(fmaf(__uint_as_float(t[i] << 16), sc[2 * i], sh[2 * i]), act);
+      const float hi = act_fwd_core(fmaf(__uint_as_float(t[i] & 0xffff0000u), sc[2 * i + 1], sh[2 * i + 1]), act);
+      t[i] = pack2bf(lo, hi);
+    }
+  }
+  return t;
+}
 DEVINL float act_fwd(float u, int act) {
   switch (act) {
     case PLYOLO_ACT_SILU: return u * __builtin_amdgcn_rcpf(1.0f + __expf(-u));  // hardware exp2 / rcp (1 ulp): bf16 storage path

@@ -85,13 +85,7 @@ DEVINL u32x4 pre_apply(u32x4 t, const float* __restrict__ pre, int pre_ld, int a
   const f32x4 h0 = *(const f32x4*)(pre + pre_ld + c), h1 = *(const f32x4*)(pre + pre_ld + c + 4);
   const float sc[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
   const float sh[8] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float lo = act_fwd_core(fmaf(__uint_as_float(t[i] << 16), sc[2 * i], sh[2 * i]), act);
-    const float hi = act_fwd_core(fmaf(__uint_as_float(t[i] & 0xffff0000u), sc[2 * i + 1], sh[2 * i + 1]), act);
-    t[i] = pack2bf(lo, hi);
-  }
-  return t;
+  return bn_act_vec8(t, sc, sh, act);
 }
 
 // MF16 (PLYOLO_MFMA16=1, A/B instances): the same tile on v_mfma_f32_16x16x32_bf16 -- per wave 2*MT pixel fragments of 16 (one image

@@ -97,7 +97,7 @@ template <int BN, bool BNB> constexpr int pw_bm() { return (BNB && BN >= 64) ? 6
 // inside the unrolled element loop of the loader compiles to a branch per element), -1 = p.bact
 template <int BN, int KC, bool OUT_F32, bool PRE, bool PIPE, bool BNB = false, bool RED = false, int BACT = -1>
 __global__ __launch_bounds__(256, BNB ? 3 : 2) void conv_pw_kernel(const PwP p) {
-  static_assert(!RED || (!OUT_F32 && !PRE && !BNB), "RED instances: plain bf16 data gradients");
+  static_assert(!RED || (!OUT_F32 && !PRE), "RED instances: bf16 data gradients");
   constexpr int BM = pw_bm<BN, BNB>();
   constexpr int WN = BN / 32, WM = 4 / WN, MT = BM / (32 * WM);
   constexpr int ROWB = KC * 2 + 16;   // LDS row pitch (bytes)
@@ -244,14 +244,7 @@ __global__ __launch_bounds__(256, BNB ? 3 : 2) void conv_pw_kernel(const PwP p) 
       }
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
-        u32x4 t = av[v];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float lo = act_fwd_core(fmaf(__uint_as_float(t[i] << 16), sc[2 * i], sh[2 * i]), p.pre_act);
-          const float hi = act_fwd_core(fmaf(__uint_as_float(t[i] & 0xffff0000u), sc[2 * i + 1], sh[2 * i + 1]), p.pre_act);
-          t[i] = pack2bf(lo, hi);
-        }
-        av[v] = t;
+        av[v] = bn_act_vec8(av[v], sc, sh, p.pre_act);
       }
     }
     {
@@ -308,14 +301,7 @@ __global__ __launch_bounds__(256, BNB ? 3 : 2) void conv_pw_kernel(const PwP p) 
       }
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
-        u32x4 t = av[v];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float lo = act_fwd_core(fmaf(__uint_as_float(t[i] << 16), sc[2 * i], sh[2 * i]), p.pre_act);
-          const float hi = act_fwd_core(fmaf(__uint_as_float(t[i] & 0xffff0000u), sc[2 * i + 1], sh[2 * i + 1]), p.pre_act);
-          t[i] = pack2bf(lo, hi);
-        }
-        av[v] = t;
+        av[v] = bn_act_vec8(av[v], sc, sh, p.pre_act);
       }
     }
     {
@@ -534,11 +520,16 @@ hipError_t pw_launch_bnb_inst(const PwP& p, hipStream_t s) {
   const size_t lds_epi = (size_t)BM * SROW + WM * 2 * BN * 4;
   const size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
   auto kern = p.bact == PLYOLO_ACT_SILU ? conv_pw_kernel<BN, KC, false, false, false, true, false, PLYOLO_ACT_SILU> : conv_pw_kernel<BN, KC, false, false, false, true>;
-  if (hipError_t e = plyolo::ensure_dynamic_lds((const void*)kern, lds); e != hipSuccess) return e;
+  size_t lds_ = lds;
+  if (p.red.n > 0) {   // + the upstream unit's BatchNorm-backward reduction in the store loop
+    kern = p.bact == PLYOLO_ACT_SILU ? conv_pw_kernel<BN, KC, false, false, false, true, true, PLYOLO_ACT_SILU> : conv_pw_kernel<BN, KC, false, false, false, true, true>;
+    lds_ = lds > 16384 ? lds : 16384;
+  }
+  if (hipError_t e = plyolo::ensure_dynamic_lds((const void*)kern, lds_); e != hipSuccess) return e;
   const int nmt = (p.M + BM - 1) / BM;
   PwP q = p;
   q.nmt = nmt;
-  hipLaunchKernelGGL(kern, dim3(nmt * p.nnblk), dim3(256), lds, s, q);
+  hipLaunchKernelGGL(kern, dim3(nmt * p.nnblk), dim3(256), lds_, s, q);
   return hipGetLastError();
 }
 
@@ -667,8 +658,10 @@ int conv_pw_dgrad_bn_fits(const plyolo_conv_desc* d, int act) {
   return (d->Cin + bn - 1) / bn <= maxblk ? 1 : 0;
 }
 
-int conv_pw_dgrad_bn(const plyolo_conv_desc* d, const plyolo_bn_bwd_fuse* f, const void* wpd, void* dx, int accumulate, void* stream) {
+int conv_pw_dgrad_bn(const plyolo_conv_desc* d, const plyolo_bn_bwd_fuse* f, const void* wpd, void* dx, int accumulate, const plyolo_bn_red* red,
+                     void* stream) {
   PwP p{};
+  if (red && red->n > 0) p.red = *red;
   p.x = (const bf16_t*)f->dout;
   p.w = (const bf16_t*)wpd;
   p.y = dx;
@@ -693,8 +686,8 @@ int conv_pw_dgrad_bn(const plyolo_conv_desc* d, const plyolo_bn_bwd_fuse* f, con
   p.pipe = 0;
   {
     char lab[64];
-    snprintf(lab, sizeof(lab), "conv_pw_dgrad_bn<BN%d,KC%d>", BN, KC);
-    annotate(lab, 2.0 * p.M * (double)d->Cout * d->Cin, (double)p.M * (3.0 * p.K + d->Cin * (accumulate ? 2.0 : 1.0)) * 2.0);
+    snprintf(lab, sizeof(lab), "conv_pw_dgrad_bn<BN%d,KC%d>%s", BN, KC, p.red.n > 0 ? "+bnred" : "");
+    annotate(lab, 2.0 * p.M * (double)d->Cout * d->Cin, (double)p.M * (3.0 * p.K + d->Cin * ((accumulate ? 2.0 : 1.0) + (p.red.n > 0 ? 1.0 : 0.0))) * 2.0);
   }
   return submit(stream, [=](hipStream_t s) { return pw_launch_bnb(p, BN, KC, s); });
 }

@@ -176,12 +176,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
         u32x4 t = hv[v];
         if constexpr (PRE) {
           if (hmask & (1u << v)) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const float lo = act_fwd_core(fmaf(__uint_as_float(t[i] << 16), psc[2 * i], psh[2 * i]), p.pre_act);
-              const float hi = act_fwd_core(fmaf(__uint_as_float(t[i] & 0xffff0000u), psc[2 * i + 1], psh[2 * i + 1]), p.pre_act);
-              t[i] = pack2bf(lo, hi);
-            }
+            t = bn_act_vec8(t, psc, psh, p.pre_act);
           }
         }
         *(u32x4*)(x_s + pix * XB + vv * 16) = t;
@@ -412,11 +407,10 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WgP p) {
     if constexpr (PRE) {
       if (v >= DV) {
         const bool real = (hmask >> (v - DV)) & 1u;
+        {
+          const u32x4 a_ = bn_act_vec8(t, psc, psh, p.pre_act);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float lo = act_fwd_core(fmaf(__uint_as_float(t[i] << 16), psc[2 * i], psh[2 * i]), p.pre_act);
-          const float hi = act_fwd_core(fmaf(__uint_as_float(t[i] & 0xffff0000u), psc[2 * i + 1], psh[2 * i + 1]), p.pre_act);
-          t[i] = real ? pack2bf(lo, hi) : 0u;
+          for (int i = 0; i < 4; ++i) t[i] = real ? a_[i] : 0u;
         }
       }
     }

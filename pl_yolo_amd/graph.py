@@ -299,10 +299,12 @@ class Graph:
                     writes.append((op, op.res, False))
                 if op.need_dgrad:
                     ok = op.bn is not None and hasattr(op, "desc_d") and (bool(op.pw_slabs) or lib.plyolo_conv2d_dgrad_red_fits(C.byref(op.desc_d)) == 1)
-                    writes.append((op, op.x, ok and not (self.fuse_bnbwd and op.k == 1)))
+                    bnb = self.fuse_bnbwd and not op.pw_slabs and op.bn is not None and lib.plyolo_conv2d_dgrad_bn_fits(C.byref(op.desc_d), op.act) == 1
+                    writes.append((op, op.x, ok or bnb))
             elif isinstance(op, ConvPairOp):
                 ok = hasattr(op, "desc_d") and (bool(op.pw_slabs) or lib.plyolo_conv2d_dgrad_red_fits(C.byref(op.desc_d)) == 1)
-                writes.append((op, op.x, ok and not self.fuse_bnbwd))
+                bnb = self.fuse_bnbwd and not op.pw_slabs and lib.plyolo_conv2d_dgrad_bn_fits(C.byref(op.desc_d), op.act) == 1
+                writes.append((op, op.x, ok or bnb))
             elif isinstance(op, HeadPredOp):
                 writes.append((op, op.reg_feat, lib.plyolo_conv2d_dgrad_red_fits(C.byref(op.dgrad_descs()[0])) == 1))
                 writes.append((op, op.cls_feat, lib.plyolo_conv2d_dgrad_red_fits(C.byref(op.dgrad_descs()[1])) == 1))
@@ -381,7 +383,7 @@ class Graph:
     def pw_bwd_slabs(self, desc, act, ok=True):
         """Private weight-gradient slabs of plyolo_conv2d_bwd_pw for this unit, or 0 when the unit keeps the separate
         dz / data-gradient / weight-gradient launches (not covered, switched off, lazy inputs in play)."""
-        if not (ok and self.fuse_pwbwd and not self.lazy_acts and not self.fuse_bnbwd):
+        if not (ok and self.fuse_pwbwd and not self.lazy_acts):
             return 0
         lib = _lib.lib()
         if lib.plyolo_conv2d_bwd_pw_fits(C.byref(desc), act) != 1:
@@ -1011,10 +1013,11 @@ class ConvUnitOp:
         def dgrad():
             if self.need_dgrad:
                 acc = g.grad_mode(self.x)
+                red = g.red_for(self, self.x)
                 if fused:
-                    call("plyolo_conv2d_dgrad_bn", C.byref(self.desc_d), C.byref(f), self.pc.wpd, g.gptr(self.x), acc, None)
+                    call("plyolo_conv2d_dgrad_bn_red", C.byref(self.desc_d), C.byref(f), self.pc.wpd, g.gptr(self.x), acc,
+                         C.byref(red) if red is not None else None, None)
                 else:
-                    red = g.red_for(self, self.x)
                     call("plyolo_conv2d_dgrad_red", C.byref(self.desc_d), dz, self.pc.wpd, g.gptr(self.x), acc,
                          C.byref(red) if red is not None else None, None)
 
@@ -1166,10 +1169,11 @@ class ConvPairOp:
             self.pc.reduce_slabs()
 
         def dgrad():
+            red = g.red_for(self, self.x)
             if fused:
-                call("plyolo_conv2d_dgrad_bn", C.byref(self.desc_d), C.byref(f), self.pc.wpd, g.gptr(self.x), acc, None)
+                call("plyolo_conv2d_dgrad_bn_red", C.byref(self.desc_d), C.byref(f), self.pc.wpd, g.gptr(self.x), acc,
+                     C.byref(red) if red is not None else None, None)
             else:
-                red = g.red_for(self, self.x)
                 call("plyolo_conv2d_dgrad_red", C.byref(self.desc_d), dz, self.pc.wpd, g.gptr(self.x), acc,
                      C.byref(red) if red is not None else None, None)
 
