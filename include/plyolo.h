@@ -93,6 +93,9 @@ int plyolo_plan_graph_launch(plyolo_plan*, void* stream);
  * kernel label and its ALGORITHMIC flops / HBM bytes (what roofline.achieved is priced on). */
 int plyolo_plan_profile(plyolo_plan*, void* stream, float* ms_out, int n);
 int plyolo_plan_op_info(const plyolo_plan*, int i, char* label, int label_cap, double* flops, double* bytes);
+/* diagnostics: one eager multi-lane replay with a timing event behind every `every`-th launch of `lane`; ms_out[k] = ms from the
+ * start of the replay to stamp k, op_out[k] = index of the recorded op it follows; returns the stamp count (<= cap).  Synchronises. */
+int plyolo_plan_stamp_times(plyolo_plan*, void* stream, int lane, int every, float* ms_out, int* op_out, int cap);
 /* launch lane of recorded op i (plyolo_plan_lane at record time), or a negative code */
 int plyolo_plan_op_lane(const plyolo_plan*, int i);
 /* Measurement aid for multi-lane plans: one eager multi-stream replay; ms_out[l] = time from the start of the

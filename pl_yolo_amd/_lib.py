@@ -171,6 +171,7 @@ SIGNATURES = {
     "plyolo_plan_lane_times": (_i, [_vp, _vp, _vp, _i]),
     "plyolo_plan_op_info": (_i, [_vp, _i, C.c_char_p, _i, _P(_d), _P(_d)]),
     "plyolo_plan_op_lane": (_i, [_vp, _i]),
+    "plyolo_plan_stamp_times": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i]),
     "plyolo_conv2d_fwd": (_i, [_P(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
     "plyolo_conv2d_fwd_bn_act": (_i, [_P(ConvDesc), _vp, _vp, _vp, _i, _vp, _i, _vp, _vp]),
     "plyolo_conv2d_dgrad": (_i, [_P(ConvDesc), _vp, _vp, _vp, _i, _vp]),

@@ -219,7 +219,9 @@ int plyolo_plan_lanes(const plyolo_plan* p) { return p ? ((const Plan*)p)->nlane
 int plyolo_plan_size(const plyolo_plan* p) { return p ? (int)((const Plan*)p)->ops.size() : 0; }
 // Issue every recorded launch: lane l on its own stream (forked from / joined into `s`), events as
 // recorded.  Used both under stream capture (hipGraph) and for eager multi-stream replay.
-static hipError_t issue_lanes(Plan* q, hipStream_t s, bool lanes, size_t* failed, hipEvent_t* tev = nullptr) {
+// diagnostics (plyolo_plan_stamp_times): a timing event behind every `every`-th launch of `lane`
+struct StampCfg { int lane = -1, every = 0; std::vector<hipEvent_t>* evs = nullptr; std::vector<int>* at = nullptr; };
+static hipError_t issue_lanes(Plan* q, hipStream_t s, bool lanes, size_t* failed, hipEvent_t* tev = nullptr, StampCfg* stamp = nullptr) {
   if (!lanes || q->nlanes <= 1) {  // single stream, recorded order (a valid serialisation of the lanes)
     hipError_t le = hipSuccess;
     for (size_t i = 0; i < q->ops.size() && le == hipSuccess; ++i) {
@@ -275,9 +277,18 @@ static hipError_t issue_lanes(Plan* q, hipStream_t s, bool lanes, size_t* failed
     le = hipEventRecord(fork_ev[0], s);
     for (int l = 1; l < q->nlanes && le == hipSuccess; ++l) le = hipStreamWaitEvent(lane_stream(l), fork_ev[0], 0);
   }
+  int stamp_n = 0;
   for (size_t i = 0; i < q->ops.size() && le == hipSuccess; ++i) {
     const PlanOp& op = q->ops[i];
-    if (op.kind == 0) le = op.fn(lane_stream(op.lane));
+    if (op.kind == 0) {
+      le = op.fn(lane_stream(op.lane));
+      if (stamp && op.lane == stamp->lane && le == hipSuccess && ++stamp_n % stamp->every == 0) {
+        hipEvent_t e;
+        le = hipEventCreate(&e);
+        if (le == hipSuccess) le = hipEventRecord(e, lane_stream(op.lane));
+        if (le == hipSuccess) { stamp->evs->push_back(e); stamp->at->push_back((int)i); }
+      }
+    }
     else if (op.kind == 1) le = hipEventRecord(q->events[(size_t)op.ev], lane_stream(op.lane));
     else if (op.kind == 2) le = hipStreamWaitEvent(lane_stream(op.lane), q->events[(size_t)op.ev], 0);
     else if (q->hook && q->hook(op.ev, (void*)lane_stream(op.lane), q->hook_user) != 0) le = hipErrorUnknown;
@@ -380,6 +391,35 @@ int plyolo_plan_lane_times(plyolo_plan* p, void* stream, float* ms_out, int n) {
   for (auto& e : ev) (void)hipEventDestroy(e);
   if (err != hipSuccess) { set_error("plan_lane_times: %s", hipGetErrorString(err)); return -2; }
   return 0;
+}
+// Diagnostic multi-lane replay with a timing event behind every `every`-th launch of `lane`: ms_out[k] = time from the start of
+// the replay to stamp k, op_out[k] = index of the recorded op the stamp follows.  Returns the number of stamps (<= cap) or a
+// negative code.  Synchronises the stream.
+int plyolo_plan_stamp_times(plyolo_plan* p, void* stream, int lane, int every, float* ms_out, int* op_out, int cap) {
+  PLY_CHECK_ARG(p != nullptr && ms_out != nullptr && op_out != nullptr && every > 0 && cap > 0, "plan_stamp_times: bad arguments");
+  PLY_CHECK_ARG(g_rec == nullptr, "plan_stamp_times: cannot replay while recording");
+  Plan* q = (Plan*)p;
+  PLY_CHECK_ARG(q->nlanes > 1 && lane >= 0 && lane < q->nlanes, "plan_stamp_times: needs a multi-lane plan and one of its lanes");
+  hipStream_t s = (hipStream_t)stream;
+  std::vector<hipEvent_t> tev((size_t)q->nlanes + 2), evs;
+  std::vector<int> at;
+  for (auto& e : tev)
+    if (hipEventCreate(&e) != hipSuccess) { set_error("plan_stamp_times: hipEventCreate failed"); return -2; }
+  StampCfg cfg;
+  cfg.lane = lane; cfg.every = every; cfg.evs = &evs; cfg.at = &at;
+  size_t failed = 0;
+  hipError_t err = issue_lanes(q, s, true, &failed, tev.data(), &cfg);
+  if (err == hipSuccess) err = hipStreamSynchronize(s);
+  int n = 0;
+  if (err == hipSuccess)
+    for (size_t k = 0; k < evs.size() && n < cap; ++k, ++n) {
+      (void)hipEventElapsedTime(&ms_out[n], tev[0], evs[k]);
+      op_out[n] = at[k];
+    }
+  for (auto& e : tev) (void)hipEventDestroy(e);
+  for (auto& e : evs) (void)hipEventDestroy(e);
+  if (err != hipSuccess) { set_error("plan_stamp_times: %s", hipGetErrorString(err)); return -2; }
+  return n;
 }
 int plyolo_plan_op_info(const plyolo_plan* p, int i, char* label, int label_cap, double* flops, double* bytes) {
   const Plan* q = (const Plan*)p;
