@@ -316,8 +316,14 @@ class Graph:
                 for a in ins:
                     if isinstance(a, Act):
                         writes.append((op, a, False))
+        # ... only where it pays: a big reduce launch streams at ~5 TB/s, the same bytes in a conv epilogue cost more than they save
+        # (YOLOX-s stem, 210 MB of z: reduce 85 us alone, +106 us in the stride-2 data gradient that would take it; same box, means
+        # of three alternations: no limit 8.81 ms, 120 MB 8.63, 64 MB 8.64, 30 MB 8.76)
+        max_mb = float(os.environ.get("PLYOLO_BNRED_MAX_MB", "64"))
         plan, covered = {}, {}
         for (u, v, choff) in views:
+            if v.M * v.C * self.esize > max_mb * 1.0e6:
+                continue
             rv = _res(v)
             last = None
             for (wop, a, ok) in writes:
