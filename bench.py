@@ -169,7 +169,8 @@ def nms_bench(device, B=16, n=1000, reps=20, cpu=True):
 # plan-profile label -> the __global__ function that launch runs (csrc/*.hip); forward, data-gradient and the
 # stride-2 parity-class jobs are all instances of conv_mfma_kernel / conv_mfma_jobs_kernel
 _KERNEL_OF = {"conv_mfma_fwd": "conv_mfma_kernel", "conv_mfma_dgrad": "conv_mfma_kernel", "conv_mfma_dgrad_s2": "conv_mfma_jobs_kernel",
-              "conv_wgrad": "conv_wgrad_kernel", "conv3ws_fwd": "conv3ws_kernel", "conv3ws_dgrad": "conv3ws_kernel", "conv_pw_fwd": "conv_pw_kernel", "conv_pw_dgrad": "conv_pw_kernel"}
+              "conv_wgrad": "conv_wgrad_kernel", "conv3ws_fwd": "conv3ws_kernel", "conv3ws_dgrad": "conv3ws_kernel", "conv_pw_fwd": "conv_pw_kernel", "conv_pw_dgrad": "conv_pw_kernel",
+              "conv_mfma_fwd_s2": "conv_mfma_kernel", "conv_pw_dgrad_bn": "conv_pw_kernel", "conv_pw_bwd": "conv_pw_bwd_kernel"}
 
 
 def lib_md5():
@@ -195,7 +196,7 @@ def load_pmc_traffic(args):
     and the entry says which build it belongs to."""
     if (args.model, args.size, args.batch) != ("yolox_s", 640, 32):
         return None
-    for tag in ("r03", "r02", "r01"):
+    for tag in ("r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", "%s_pmc_hbm_traffic.json" % tag)
         try:
             with open(path) as f:
