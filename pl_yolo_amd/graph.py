@@ -118,10 +118,13 @@ class Graph:
         # kernels (10.5 -> 12.2 ms/step): SiLU is 2 transcendental + ~6 plain VALU instructions per element, the whole
         # chip sustains ~3.8 T SiLU/s -- the same order as the HBM stream itself -- so inside a loader the work does not
         # disappear, it lengthens every workgroup's load -> stage -> MFMA chain
-        # PLYOLO_FUSE_BNBWD=1: pointwise units form dz inside their data gradient's loader (plyolo_conv2d_dgrad_bn: one launch and
-        # one pass over dout / z less per unit, bit-identical).  Off by default: 26 launches fewer per YOLOX-s step and no
-        # measurable change of the step time (profiles/r03_ab_bn_fusion.txt), 2 % slower on YOLOX-x at 1280x1280 without its size limit
-        self.fuse_bnbwd = os.environ.get("PLYOLO_FUSE_BNBWD", "0") == "1"
+        # PLYOLO_FUSE_BNBWD: pointwise units form dz inside their data gradient's loader (plyolo_conv2d_dgrad_bn: one launch and one
+        # pass over dout / z less per unit, bit-identical).  Round 3: 26 launches fewer per YOLOX-s step and no measurable change of the
+        # step time (profiles/r03_ab_bn_fusion.txt), 2 % slower on YOLOX-x at 1280x1280 without its size limit -- off.  Round 4: with the
+        # loader's SiLU instance (the run-time activation switch compiled to a branch per element) and the units of the large maps gone
+        # to plyolo_conv2d_bwd_pw it takes the remaining small-map pointwise units: 15 launches and ~0.4 GB less, 8.66 vs 8.69 / 8.63
+        # vs 8.66 ms -- on by default
+        self.fuse_bnbwd = os.environ.get("PLYOLO_FUSE_BNBWD", "1") == "1"
         self.fwd_res_in_dz = os.environ.get("PLYOLO_RES_IN_DZ", "1") == "1"    # A/B switch: 0 = a copy_add launch per shortcut
         # PLYOLO_FUSE_PWBWD (default on, round 4): the whole backward of a large-map pointwise unit behind its BatchNorm reduction --
         # dz, data gradient and weight gradient -- is ONE persistent launch (plyolo_conv2d_bwd_pw): dout, z and x are read once, dz
