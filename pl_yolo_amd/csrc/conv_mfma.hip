@@ -40,6 +40,7 @@ static inline hipError_t conv3ws_launch(const void*, const void*, void*, double*
 
 namespace plyolo {
 hipError_t conv_mfma_launch_s2(const void* convp, int BN, hipStream_t s);   // conv_mfma_s2.hip
+hipError_t conv_mfma_launch_t4(const void* convp, int BN, int red, hipStream_t s);   // conv_mfma_t4.hip
 // conv_mfma_red.hip: data-gradient instances that fold the upstream BatchNorm-backward reduction into their store loop
 int conv_mfma_red_has(int BN, int CK, int TH, int jobs);
 hipError_t conv_mfma_launch_red(const void* convp, int BN, int CK, int TH, hipStream_t s);
@@ -153,6 +154,16 @@ void pick_tiles(const ConvP& p, int ext_y, bool out_f32, int* BN, int* CK, int* 
   *TH = th;
 }
 
+// 4-row tiles (conv_mfma_t4.hip) for a 3x3 stride-1 launch whose 8-row tiling gives at most PLYOLO_TH4_MAX_WG workgroups
+bool use_t4(const ConvP& p, int ksize, int BN, int CK, int TH, bool plain_bf16) {
+  // stand-alone, batch 32: 128 -> 128 @20x20 (192 workgroups of 8 rows) 16.6 -> 13.8 us, 256 -> 256 @20x20 (384) 32.6 -> 28.6,
+  // 128 -> 128 @40x40 (480) 23.2 -> 23.7: the 20x20 maps take the 4-row tiles
+  const int max_wg = getenv("PLYOLO_TH4_MAX_WG") ? atoi(getenv("PLYOLO_TH4_MAX_WG")) : 400;
+  if (max_wg <= 0 || !plain_bf16 || ksize != 3 || p.si != 1 || p.so != 1 || TH != 8 || CK != 32 || (BN != 128 && BN != 64)) return false;
+  if (!(p.db && p.Cin > CK) || p.ablate || p.OHt <= 4) return false;
+  return p.nmb * ((p.Cout + BN - 1) / BN) <= max_wg;
+}
+
 void set_taps(ConvP& p) {
   p.taps_lo = 0ull;
   p.taps_hi = 0u;
@@ -262,6 +273,15 @@ int conv_mfma_fwd(const plyolo_conv_desc* d, const void* x, const void* wp, cons
     annotate(lab, 2.0 * M * d->Cout * d->Cin * 9.0, M * d->Cout * 2.0 + (double)d->N * d->H * d->W * d->Cin * 2.0);
     return submit(stream, [=](hipStream_t s) { return conv_mfma_launch_s2(&p, bn, s); });
   }
+  if (use_t4(p, d->ksize, BN, CK, TH, !f32 && !p.pre)) {
+    apply_tiles(p, 3, 3, 4);
+    char lab[64];
+    snprintf(lab, sizeof(lab), "conv_mfma_fwd<BN%d,CK32,TH4>", BN);
+    const double M = (double)p.N * p.OHf * p.OWf;
+    annotate(lab, 2.0 * M * d->Cout * d->Cin * 9.0, M * d->Cout * 2.0 + (double)d->N * d->H * d->W * d->Cin * 2.0);
+    const int bn = BN;
+    return submit(stream, [=](hipStream_t s) { return conv_mfma_launch_t4(&p, bn, 0, s); });
+  }
   {
     char lab[64];
     snprintf(lab, sizeof(lab), "conv_mfma_fwd<BN%d,CK%d,TH%d>%s%s", BN, CK, TH, f32 ? "f32out" : "", p.pre ? "+bnact" : "");
@@ -322,6 +342,17 @@ int conv_mfma_dgrad(const plyolo_conv_desc* d, const void* dy, const void* wpd, 
       });
     }
     if (red_fits) { *red_fits = (d->ksize == 3 && !p.ablate) ? conv_mfma_red_has(BN, CK, TH, 0) : 0; return 0; }
+    if (use_t4(p, d->ksize, BN, CK, TH, true)) {
+      const bool r4 = red && red->n > 0;
+      if (r4) p.red = *red;
+      apply_tiles(p, 3, 3, 4);
+      char lab[64];
+      snprintf(lab, sizeof(lab), "conv_mfma_dgrad<BN%d,CK32,TH4>%s", BN, r4 ? "+bnred" : "");
+      const double Mo = (double)d->N * OH * OW, Mi = (double)d->N * d->H * d->W;
+      annotate(lab, 2.0 * Mo * d->Cout * d->Cin * 9.0, (Mo * Kc + Mi * d->Cin * ((accumulate ? 2.0 : 1.0) + (r4 ? 1.0 : 0.0))) * 2.0);
+      const int bn = BN;
+      return submit(stream, [=](hipStream_t s) { return conv_mfma_launch_t4(&p, bn, r4 ? 1 : 0, s); });
+    }
     const bool use_red = red && red->n > 0 && !p.ablate && conv_mfma_red_has(BN, CK, TH, 0);
     if (red && red->n > 0 && !use_red) { set_error("conv_mfma_dgrad: no RED instance for this tile configuration (ask plyolo_conv2d_dgrad_red_fits)"); return -1; }
     if (use_red) p.red = *red;

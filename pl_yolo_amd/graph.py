@@ -325,8 +325,6 @@ class Graph:
         max_mb = float(os.environ.get("PLYOLO_BNRED_MAX_MB", "64"))
         plan, covered = {}, {}
         for (u, v, choff) in views:
-            if v.M * v.C * self.esize > max_mb * 1.0e6:
-                continue
             rv = _res(v)
             last = None
             for (wop, a, ok) in writes:
@@ -335,6 +333,9 @@ class Graph:
             if last is None:
                 continue
             wop, a, ok = last
+            # (the persistent pointwise kernel requests the unit's z with its tile and waits for it behind its MFMAs: twice the limit)
+            if v.M * v.C * self.esize > max_mb * 1.0e6 * (2.0 if getattr(wop, "pw_slabs", 0) else 1.0):
+                continue
             ra = _res(a)
             if not ok or ra[0] != rv[0] or ra[1] > rv[1] or ra[2] < rv[2]:
                 continue
