@@ -328,6 +328,18 @@ int plyolo_resize_pad_u8(const unsigned char* src, int h, int w, int dh, int dw,
 int plyolo_mixup_blend_u8(const unsigned char* origin, int th, int tw, const unsigned char* other, int bh, int bw, int flip, int x_off, int y_off,
                           unsigned char* out, void* stream);
 
+/* Rounding cut-out (reference models/data/augmentation/cutout_round.py:6-55; MosaicDetection applies it to an image before the
+ * mosaic, mosaic_detection.py:90-91, 160-161).  The host draws the holes (numpy.random, in the reference's order), tests them
+ * against the label boxes (bbox_ioa, models/utils/bbox.py:76-94) and forms the fill colour from the strip sums below. */
+/* sums_dev[r][c] (3 per rectangle) = sum of channel c over rectangle r = rects_dev[r] = {y0, y1, x0, x1} (half-open, inside the image) */
+int plyolo_rect_sums_u8(const unsigned char* img, int H, int W, const int* rects_dev, int n, unsigned long long* sums_dev, void* stream);
+#define PLYOLO_MAX_HOLES 8
+typedef struct plyolo_rect { int x1, y1, x2, y2; } plyolo_rect;   /* half-open, inside the image */
+/* img[y1:y2, x1:x2] = uint8(mixup * fill + (1 - mixup) * img[y1:y2, x1:x2]) for every hole IN ORDER (float64, two rounded products
+ * and their rounded sum, truncated); holes_host / fill3_host are HOST memory, copied into the launch */
+int plyolo_cutout_holes_u8(unsigned char* img, int H, int W, const plyolo_rect* holes_host, int n, const double* fill3_host, double mixup,
+                           void* stream);
+
 /* ------------------------------------------------------------ deploy-time folding (inference export)
  * Replaces RepConv._fuse_bn_tensor / get_equivalent_kernel_bias / fuse_conv_bn / fuse_repvgg_block
  * (models/necks/yolov7_neck.py:213-348) and prepares BaseConv.fuseforward (network_blocks.py:39-40): fp32 weights in

@@ -15,7 +15,10 @@ against cv2 itself --
     for Y0); X = (X0 + adelta[x]) >> 5: integer part X >> 5 (saturated to int16), 5 fraction bits; bilinear weights from
     the 32 x 32 table, short(w * 32768) (exact: the products are multiples of 2^-10); pixel = (sum of 4 taps * weights + 2^14) >> 15;
     a tap outside the source reads the border value.
-Copy-paste / cut-paste / rounding cut-out (probabilities 0 in every shipped config) are not restated: a non-zero probability raises.
+Rounding cut-out (models/data/augmentation/cutout_round.py:6-55, models/utils/bbox.py:76-94; pure numpy, so PINNED: the
+reference function itself runs in this container -- tests/golden/cutout_round.npz, tools/gen_golden.py cutout) is restated below;
+copy-paste / cut-paste read `dataset.object_cls` / `.back_cls`, which no dataset class of the reference defines (they cannot run
+there either): a non-zero probability raises.
 csrc/augment.hip implements the same arithmetic; tests compare the two bit for bit."""
 import math
 import random
@@ -229,6 +232,60 @@ def random_perspective(img, targets=(), degrees=10, translate=0.1, scale=(0.5, 1
     return img, affine_labels(targets, M, s, width, height)
 
 
+# ---- rounding cut-out ------------------------------------------------------------------------------------------------------
+def bbox_ioa(box1, box2):
+    """models/utils/bbox.py:76-94: intersection of box1 [4] with every row of box2 [n,4], over the area of the box2 row."""
+    box2 = box2.transpose()
+    b1_x1, b1_y1, b1_x2, b1_y2 = box1[0], box1[1], box1[2], box1[3]
+    b2_x1, b2_y1, b2_x2, b2_y2 = box2[0], box2[1], box2[2], box2[3]
+    inter = (np.minimum(b1_x2, b2_x2) - np.maximum(b1_x1, b2_x1)).clip(0) * (np.minimum(b1_y2, b2_y2) - np.maximum(b1_y1, b2_y1)).clip(0)
+    return inter / ((b2_x2 - b2_x1) * (b2_y2 - b2_y1) + 1e-16)
+
+
+def cutout_strips(labels, h, w):
+    """The one-pixel strips around every label box whose mean colours make up the fill colour (cutout_round.py:14-31), as
+    python slices (rows, cols) in the reference's order: beside the left edge, beside the right edge, above, below -- each only
+    where the box keeps more than a pixel from that image border.  (The reference names them left / top / right / bottom.)"""
+    out = []
+    for i in range(len(labels)):
+        x0, y0, x1, y1 = (int(labels[i, k]) for k in range(4))
+        if labels[i, 0] > 1:
+            out.append((slice(y0, y1), slice(x0 - 1, x0), 0))
+        if labels[i, 2] < w - 1:
+            out.append((slice(y0, y1), slice(x1, x1 + 1), 0))
+        if labels[i, 1] > 1:
+            out.append((slice(y0 - 1, y0), slice(x0, x1), 1))
+        if labels[i, 3] < h - 1:
+            out.append((slice(y1, y1 + 1), slice(x0, x1), 1))
+    return out
+
+
+def cutout_rounding(img, labels, n_hole, cutout_ratio, mixup, ioa_thre):
+    """cutout_round.py:6-55.  Fill colour = mean over the strips of their mean colours (114 without strips); 1..3 rectangles at
+    numpy-random places, each blended `mixup` : 1 - mixup into the image (float64, truncated into the uint8 image, IN ORDER: a later
+    hole blends over an earlier one) unless it covers `ioa_thre` or more of some label box.  Draws: randint for the count, then
+    three randints per hole.  Works on `img` in place (the caller copied it, mosaic_detection.py:80) and returns it."""
+    h, w = img.shape[:2]
+    if len(labels) == 0:
+        return img.astype(np.uint8)
+    fills = [img[rs, cs].mean(ax) for rs, cs, ax in cutout_strips(labels, h, w)]
+    fill_in = np.array(fills).mean(0).reshape(3) if len(fills) != 0 else np.array([114, 114, 114])
+    n = np.random.randint(n_hole[0], n_hole[1] + 1)
+    for _ in range(n):
+        x1 = np.random.randint(0, w)
+        y1 = np.random.randint(0, h)
+        index = np.random.randint(0, len(cutout_ratio))
+        x2 = int(np.clip(x1 + cutout_ratio[index][0] * w, x1, w))
+        y2 = int(np.clip(y1 + cutout_ratio[index][1] * h, y1, h))
+        if bbox_ioa([x1, y1, x2, y2], labels[:, :4]).max() < ioa_thre:
+            cut = np.ones(img[y1:y2, x1:x2, :].shape) * fill_in
+            img[y1:y2, x1:x2, :] = mixup * cut + (1 - mixup) * img[y1:y2, x1:x2, :]
+    return img.astype(np.uint8)
+
+
+CR_NHOLE, CR_RATIO, CR_MIXUP, CR_IOA = (1, 3), [[0.1, 0.1], [0.3, 0.1], [0.1, 0.3], [0.2, 0.2], [0.3, 0.3]], 0.7, 0.2   # mosaic_detection.py:52-55
+
+
 class MosaicDetection:
     """mosaic_detection.py:12-247 over a dataset object with `.annotations[i] = (labels [n,5] xyxy+cls, img_hw, resized_info,
     name)`, `.imgs` (list of uint8 HWC arrays, or None) / `.load_resized_img(i)`, `.img_size`."""
@@ -236,8 +293,8 @@ class MosaicDetection:
     def __init__(self, dataset, img_size, preprocess=None, mosaic_prob=1.0, mosaic_scale=(0.5, 1.5), degrees=10, translate=0.1,
                  shear=2.0, perspective=0.0, mixup_prob=1.0, mixup_scale=(0.5, 1.5), copypaste_prob=0.0,
                  copypaste_scale=(0.5, 1.5), cutpaste_prob=0.0, cutoutR_prob=0.0):
-        if copypaste_prob or cutpaste_prob or cutoutR_prob:
-            raise NotImplementedError("copy-paste / cut-paste / rounding cut-out are not restated")
+        if copypaste_prob or cutpaste_prob:
+            raise NotImplementedError("copy-paste / cut-paste are not restated (they cannot run in the reference either)")
         self._dataset, self.img_size, self.preprocess = dataset, img_size, preprocess
         self.mosaic_prob, self.scale = mosaic_prob, mosaic_scale
         self.degrees, self.translate, self.shear, self.perspective = degrees, translate, shear, perspective
@@ -252,22 +309,25 @@ class MosaicDetection:
         ds = self._dataset
         return ds.imgs[index] if ds.imgs is not None else ds.load_resized_img(index)
 
-    def _unused_draws(self, has_labels, mosaic):
-        """The three per-image augmentations that every shipped config leaves at probability 0 still consume draws (:86-91,
-        :156-161); in the mosaic branch the first one is skipped for an image without labels (short-circuit `and`)."""
+    def _per_image(self, img, labels, mosaic):
+        """The three per-image augmentations (:86-91, :156-161): copy-paste and cut-paste (probability 0) only consume their
+        draws -- in the mosaic branch the first one is skipped for an image without labels (short-circuit `and`) -- the rounding
+        cut-out runs when its draw says so."""
         for k, prob in enumerate(self.off_probs):
-            if k == 0 and mosaic and not has_labels:
+            if k == 0 and mosaic and len(labels) == 0:
                 continue
             if random.random() < prob:
-                raise NotImplementedError
+                if k < 2:
+                    raise NotImplementedError
+                img = cutout_rounding(img, labels, CR_NHOLE, CR_RATIO, CR_MIXUP, CR_IOA)
+        return img
 
     def __getitem__(self, idx):
         ds = self._dataset
         if not random.random() < self.mosaic_prob:                                    # plain branch :148-167
             res, img_hw, _, img_name = ds.annotations[idx]
             ds.img_size = self.img_size
-            img = self._img(idx).copy()
-            self._unused_draws(True, mosaic=False)
+            img = self._per_image(self._img(idx).copy(), res, mosaic=False)
             target = res
             if self.preprocess is not None:
                 img, target = self.preprocess(img, res, self.img_size)
@@ -280,8 +340,7 @@ class MosaicDetection:
         parts = []
         for k, index in enumerate(members):
             boxes, _, _, img_name = ds.annotations[index]
-            img = self._img(index).copy()
-            self._unused_draws(len(boxes) != 0, mosaic=True)
+            img = self._per_image(self._img(index).copy(), boxes, mosaic=True)
             h0, w0 = img.shape[:2]
             scale = min(1. * H / h0, 1. * W / w0)
             img = resize(img, (int(w0 * scale), int(h0 * scale)))

@@ -129,6 +129,13 @@ class AugImage(C.Structure):   # plyolo_aug_image
                 ("hgain", C.c_double), ("sgain", C.c_double), ("vgain", C.c_double)]
 
 
+MAX_HOLES = 8
+
+
+class Rect(C.Structure):         # plyolo_rect
+    _fields_ = [("x1", C.c_int), ("y1", C.c_int), ("x2", C.c_int), ("y2", C.c_int)]
+
+
 class MosaicTile(C.Structure):   # plyolo_mosaic_tile
     _fields_ = [("src", C.c_void_p), ("h", C.c_int), ("w", C.c_int), ("dh", C.c_int), ("dw", C.c_int), ("lx1", C.c_int), ("ly1", C.c_int),
                 ("lx2", C.c_int), ("ly2", C.c_int), ("sx1", C.c_int), ("sy1", C.c_int)]
@@ -198,6 +205,8 @@ SIGNATURES = {
     "plyolo_warp_perspective_u8": (_i, [_vp, _i, _i, _P(_d), _vp, _i, _i, _i, _vp]),
     "plyolo_resize_pad_u8": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
     "plyolo_mixup_blend_u8": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "plyolo_rect_sums_u8": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),
+    "plyolo_cutout_holes_u8": (_i, [_vp, _i, _i, _vp, _i, _vp, C.c_double, _vp]),
     "plyolo_reduce_slabs_plan": (_i, [_i, _sz, _P(_i), _P(_i)]),
     "plyolo_reduce_slabs_multi": (_i, [_vp, _i, _i, _i, _d, _vp]),
     "plyolo_pack_elems": (_i, [_i, _i, _i, _i, _P(_sz), _P(_sz)]),

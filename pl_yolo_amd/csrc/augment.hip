@@ -270,6 +270,57 @@ __global__ void k_mixup_blend(const unsigned char* origin, int th, int tw, const
   }
 }
 
+// ---- rounding cut-out (reference models/data/augmentation/cutout_round.py:6-55)
+// per rectangle r (half-open, inside the image) the three channel sums of its uint8 pixels: one workgroup per rectangle, exact integers --
+// the host divides by the pixel count in float64, which is what numpy's mean of a uint8 strip does (:21-31)
+__global__ __launch_bounds__(256) void k_rect_sums(const unsigned char* img, int W, const int* rects, unsigned long long* sums) {
+  const int y0 = rects[blockIdx.x * 4 + 0], y1 = rects[blockIdx.x * 4 + 1], x0 = rects[blockIdx.x * 4 + 2], x1 = rects[blockIdx.x * 4 + 3];
+  const int rw = x1 - x0, n = (y1 - y0) * rw;
+  unsigned long long a[3] = {0ull, 0ull, 0ull};
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int y = y0 + i / rw, x = x0 + i % rw;
+    const unsigned char* q = img + ((size_t)y * W + x) * 3;
+    a[0] += q[0]; a[1] += q[1]; a[2] += q[2];
+  }
+  __shared__ unsigned long long red[3][256];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) red[c][threadIdx.x] = a[c];
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) red[c][threadIdx.x] += red[c][threadIdx.x + st];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 3) sums[blockIdx.x * 3 + threadIdx.x] = red[threadIdx.x][0];
+}
+
+struct Holes { plyolo_rect r[PLYOLO_MAX_HOLES]; int n; double fill[3]; double mix, keep; };
+
+// every pixel of the holes' bounding box walks the holes IN ORDER: inside one, v = uint8(mix * fill + keep * v) -- two float64 products
+// and their sum, each rounded (numpy evaluates `mixup * cut + (1 - mixup) * img` term by term: no fused multiply-add), truncated by
+// the store into the uint8 image (:52-53); a later hole blends over what an earlier one left
+__global__ void k_cutout_holes(unsigned char* img, int W, Holes hs, int bx0, int by0, int bw, int bh) {
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < bw * bh; idx += gridDim.x * blockDim.x) {
+    const int y = by0 + idx / bw, x = bx0 + idx % bw;
+    unsigned char* q = img + ((size_t)y * W + x) * 3;
+    int v[3] = {q[0], q[1], q[2]};
+    bool hit = false;
+    for (int k = 0; k < hs.n; ++k) {
+      if (x >= hs.r[k].x1 && x < hs.r[k].x2 && y >= hs.r[k].y1 && y < hs.r[k].y2) {
+        hit = true;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const double t = __dadd_rn(__dmul_rn(hs.mix, hs.fill[c]), __dmul_rn(hs.keep, (double)v[c]));
+          v[c] = (t >= 0.0 && t < 256.0) ? (int)t : 0;     // in range for every finite fill colour; a NaN fill (an empty strip) stores 0
+        }
+      }
+    }
+    if (hit) { q[0] = (unsigned char)v[0]; q[1] = (unsigned char)v[1]; q[2] = (unsigned char)v[2]; }
+  }
+}
+
 }  // namespace
 
 using plyolo::submit;
@@ -344,6 +395,42 @@ int plyolo_mixup_blend_u8(const unsigned char* origin, int th, int tw, const uns
   plyolo::annotate("mixup_blend_u8", 0.0, (double)th * tw * 3 * 3.0);
   return submit(stream, [=](hipStream_t s) -> hipError_t {
     hipLaunchKernelGGL(k_mixup_blend, dim3((unsigned)cdiv(th * tw, 256)), dim3(256), 0, s, origin, th, tw, other, bh, bw, flip, x_off, y_off, out);
+    return hipGetLastError();
+  });
+}
+
+int plyolo_rect_sums_u8(const unsigned char* img, int H, int W, const int* rects_dev, int n, unsigned long long* sums_dev, void* stream) {
+  PLY_CHECK_ARG(img && rects_dev && sums_dev && H > 0 && W > 0 && n > 0, "rect_sums_u8: bad arguments");
+  plyolo::annotate("rect_sums_u8", 0.0, 0.0);
+  return submit(stream, [=](hipStream_t s) -> hipError_t {
+    hipLaunchKernelGGL(k_rect_sums, dim3((unsigned)n), dim3(256), 0, s, img, W, rects_dev, sums_dev);
+    return hipGetLastError();
+  });
+}
+
+int plyolo_cutout_holes_u8(unsigned char* img, int H, int W, const plyolo_rect* holes_host, int n, const double* fill3_host, double mixup,
+                           void* stream) {
+  PLY_CHECK_ARG(img && holes_host && fill3_host && H > 0 && W > 0 && n > 0 && n <= PLYOLO_MAX_HOLES, "cutout_holes_u8: bad arguments (at most %d holes per call)", PLYOLO_MAX_HOLES);
+  Holes hs{};
+  hs.n = n;
+  int bx0 = W, by0 = H, bx1 = 0, by1 = 0;
+  for (int k = 0; k < n; ++k) {
+    const plyolo_rect r = holes_host[k];
+    PLY_CHECK_ARG(r.x1 >= 0 && r.y1 >= 0 && r.x2 <= W && r.y2 <= H && r.x1 <= r.x2 && r.y1 <= r.y2, "cutout_holes_u8: hole %d outside the image", k);
+    hs.r[k] = r;
+    if (r.x1 < r.x2 && r.y1 < r.y2) {
+      bx0 = r.x1 < bx0 ? r.x1 : bx0; by0 = r.y1 < by0 ? r.y1 : by0;
+      bx1 = r.x2 > bx1 ? r.x2 : bx1; by1 = r.y2 > by1 ? r.y2 : by1;
+    }
+  }
+  if (bx1 <= bx0 || by1 <= by0) return 0;      // only empty holes
+  for (int c = 0; c < 3; ++c) hs.fill[c] = fill3_host[c];
+  hs.mix = mixup;
+  hs.keep = 1.0 - mixup;                        // (1 - mixup), evaluated once in float64 as python does
+  const int bw = bx1 - bx0, bh = by1 - by0;
+  plyolo::annotate("cutout_holes_u8", 0.0, (double)bw * bh * 6.0);
+  return submit(stream, [=](hipStream_t s) -> hipError_t {
+    hipLaunchKernelGGL(k_cutout_holes, dim3((unsigned)cdiv(bw * bh, 256)), dim3(256), 0, s, img, W, hs, bx0, by0, bw, bh);
     return hipGetLastError();
   });
 }

@@ -20,7 +20,7 @@ import random
 import numpy as np
 import torch
 
-from ._lib import AugImage, MosaicTile, PlyoloError, call
+from ._lib import MAX_HOLES, AugImage, MosaicTile, PlyoloError, Rect, call
 
 
 def _check_image(img):
@@ -282,6 +282,69 @@ def random_perspective(img, targets=(), degrees=10, translate=0.1, scale=(0.5, 1
     return img, targets
 
 
+CR_NHOLE, CR_RATIO, CR_MIXUP, CR_IOA = (1, 3), [[0.1, 0.1], [0.3, 0.1], [0.1, 0.3], [0.2, 0.2], [0.3, 0.3]], 0.7, 0.2   # mosaic_detection.py:52-55
+
+
+def _bbox_ioa(box1, box2):
+    """models/utils/bbox.py:76-94: intersection of box1 with every row of box2 over the area of that row."""
+    box2 = box2.transpose()
+    inter = (np.minimum(box1[2], box2[2]) - np.maximum(box1[0], box2[0])).clip(0) * (np.minimum(box1[3], box2[3]) - np.maximum(box1[1], box2[1])).clip(0)
+    return inter / ((box2[2] - box2[0]) * (box2[3] - box2[1]) + 1e-16)
+
+
+def cutout_rounding(img, labels, n_hole=CR_NHOLE, cutout_ratio=CR_RATIO, mixup=CR_MIXUP, ioa_thre=CR_IOA):
+    """models/data/augmentation/cutout_round.py:6-55 on a uint8 HWC device image, IN PLACE (the caller owns a copy, as the reference's
+    callers do, mosaic_detection.py:80).  The fill colour is the mean over the one-pixel strips around the label boxes of their mean
+    colours: the strip sums come from the device (plyolo_rect_sums_u8, exact integers), the float64 means from numpy like the
+    reference's; the holes are drawn from numpy.random in the reference's order and tested against the boxes here, the accepted ones
+    are blended into the image by ONE launch in their order (plyolo_cutout_holes_u8)."""
+    _check_image(img)
+    h, w = int(img.shape[0]), int(img.shape[1])
+    if len(labels) == 0:
+        return img
+    strips = []      # (rows, cols, number of pixels the reference's mean divides by) in its order: :20-31
+    for i in range(len(labels)):
+        x0, y0, x1, y1 = (int(labels[i, k]) for k in range(4))
+        cand = []
+        if labels[i, 0] > 1:
+            cand.append((slice(y0, y1), slice(x0 - 1, x0)))
+        if labels[i, 2] < w - 1:
+            cand.append((slice(y0, y1), slice(x1, x1 + 1)))
+        if labels[i, 1] > 1:
+            cand.append((slice(y0 - 1, y0), slice(x0, x1)))
+        if labels[i, 3] < h - 1:
+            cand.append((slice(y1, y1 + 1), slice(x0, x1)))
+        for rs, cs in cand:
+            ra, rb, _ = rs.indices(h)
+            ca, cb, _ = cs.indices(w)
+            strips.append((ra, max(ra, rb), ca, max(ca, cb)))
+    if strips:
+        rects = torch.tensor(strips, dtype=torch.int32, device=img.device)
+        sums = torch.zeros(len(strips), 3, dtype=torch.int64, device=img.device)
+        call("plyolo_rect_sums_u8", img.data_ptr(), h, w, rects.data_ptr(), len(strips), sums.data_ptr(), _stream())
+        sums = sums.cpu().numpy().astype(np.float64)       # the one synchronisation of this augmentation
+        with np.errstate(invalid="ignore", divide="ignore"):
+            fills = [(sums[k] / float((r[1] - r[0]) * (r[3] - r[2]))).reshape(1, 3) for k, r in enumerate(strips)]   # an empty strip: nan, as numpy's mean
+        fill_in = np.array(fills).mean(0).reshape(3)
+    else:
+        fill_in = np.array([114, 114, 114])
+    holes = []
+    for _ in range(np.random.randint(n_hole[0], n_hole[1] + 1)):
+        x1 = np.random.randint(0, w)
+        y1 = np.random.randint(0, h)
+        index = np.random.randint(0, len(cutout_ratio))
+        x2 = int(np.clip(x1 + cutout_ratio[index][0] * w, x1, w))
+        y2 = int(np.clip(y1 + cutout_ratio[index][1] * h, y1, h))
+        if _bbox_ioa([x1, y1, x2, y2], labels[:, :4]).max() < ioa_thre:
+            holes.append((x1, y1, x2, y2))
+    fill = (C.c_double * 3)(*[float(v) for v in fill_in])
+    for k in range(0, len(holes), MAX_HOLES):
+        part = holes[k:k + MAX_HOLES]
+        arr = (Rect * len(part))(*[Rect(*hh) for hh in part])
+        call("plyolo_cutout_holes_u8", img.data_ptr(), h, w, arr, len(part), fill, float(mixup), _stream())
+    return img
+
+
 class MosaicDetection:
     """mosaic_detection.py:12-247 on the device.  `dataset` has the reference's shape -- `.annotations[i] = (labels [n,5]
     xyxy + class, img_hw, resized_info, name)`, `.img_size`, `.imgs` (list, or None) / `.load_resized_img(i)` -- with uint8
@@ -293,8 +356,10 @@ class MosaicDetection:
     def __init__(self, dataset, img_size, preprocess=None, mosaic_prob=1.0, mosaic_scale=(0.5, 1.5), degrees=10, translate=0.1,
                  shear=2.0, perspective=0.0, mixup_prob=1.0, mixup_scale=(0.5, 1.5), copypaste_prob=0.0,
                  copypaste_scale=(0.5, 1.5), cutpaste_prob=0.0, cutoutR_prob=0.0):
-        if copypaste_prob or cutpaste_prob or cutoutR_prob:
-            raise NotImplementedError("copy-paste / cut-paste / rounding cut-out (probability 0 in every shipped config) are not built")
+        if copypaste_prob or cutpaste_prob:
+            # both read dataset.object_cls / .back_cls (mosaic_detection.py:87-89), which no dataset class of the reference defines:
+            # they cannot run there either
+            raise NotImplementedError("copy-paste / cut-paste (probability 0 in every shipped config) are not built")
         self._dataset, self.img_size, self.preprocess = dataset, img_size, preprocess
         self.mosaic_prob, self.scale = mosaic_prob, mosaic_scale
         self.degrees, self.translate, self.shear, self.perspective = degrees, translate, shear, perspective
@@ -309,13 +374,16 @@ class MosaicDetection:
         ds = self._dataset
         return _check_image(ds.imgs[index] if ds.imgs is not None else ds.load_resized_img(index))
 
-    def _spend_draws(self, has_labels, mosaic):
-        # the per-image augmentations left at probability 0 still draw (:86-91, :156-161); the copy-paste draw of the mosaic
-        # branch sits behind `not len(_labels) == 0 and`, so an image without labels skips it
-        if has_labels or not mosaic:
+    def _per_image(self, img, labels, mosaic):
+        # the per-image augmentations (:86-91, :156-161): copy-paste and cut-paste (probability 0) only draw -- the copy-paste draw
+        # of the mosaic branch sits behind `not len(_labels) == 0 and`, so an image without labels skips it -- the rounding cut-out
+        # works on a copy of the image (:80, :154)
+        if len(labels) != 0 or not mosaic:
             random.random()
         random.random()
-        random.random()
+        if random.random() < self.cutoutR_prob:
+            img = cutout_rounding(img.clone(), labels, CR_NHOLE, CR_RATIO, CR_MIXUP, CR_IOA)
+        return img
 
     # ---- one sample up to (and excluding) the final transform: (uint8 HWC device image, labels [n,5] xyxy+cls, extra)
     def _build(self, idx):
@@ -323,8 +391,7 @@ class MosaicDetection:
         if not random.random() < self.mosaic_prob:
             res, img_hw, _, name = ds.annotations[idx]
             ds.img_size = self.img_size
-            img = self._img(idx)
-            self._spend_draws(True, mosaic=False)
+            img = self._per_image(self._img(idx), res, mosaic=False)
             return img, res, img_hw, name, False
         H, W = int(ds.img_size[0]), int(ds.img_size[1])
         yc = int(random.uniform(0.5 * H, 1.5 * H))
@@ -334,9 +401,8 @@ class MosaicDetection:
         keep, parts, name = [], [], None
         for k, index in enumerate(members):
             boxes, _, _, name = ds.annotations[index]
-            img = self._img(index)
+            img = self._per_image(self._img(index), boxes, mosaic=True)
             keep.append(img)
-            self._spend_draws(len(boxes) != 0, mosaic=True)
             h0, w0 = int(img.shape[0]), int(img.shape[1])
             scale = min(1. * H / h0, 1. * W / w0)
             w, h = int(w0 * scale), int(h0 * scale)

@@ -142,9 +142,67 @@ def test_mixup_offsets_flip_and_zero_padding():
         assert np.array_equal(got_img.cpu().numpy(), want_img) and np.array_equal(got_lab, want_lab)
 
 
+# ---- rounding cut-out: tests/golden/cutout_round.npz holds what the reference's own function / MosaicDetection return (tools/gen_golden.py cutout)
+CUT = np.load(os.path.join(ROOT, "tests", "golden", "cutout_round.npz"))
+CUT_MD = {"cmosaic": dict(mosaic_prob=1.0, mixup_prob=0.0, cutoutR_prob=1.0), "cplain": dict(mosaic_prob=0.0, cutoutR_prob=1.0),
+          "ccoin": dict(mosaic_prob=0.5, mixup_prob=0.5, cutoutR_prob=0.6)}
+
+
+@pytest.mark.parametrize("tag", ["interior", "edges", "none", "many", "tiny"])
+def test_device_cutout_rounding_matches_the_reference_function(tag):
+    lab = CUT["f_%s_labels" % tag]
+    cur = dev(CUT["f_%s_img" % tag])
+    np.random.seed(int(CUT["f_%s_seed" % tag]))
+    for rep in range(4):
+        cur = pdata.cutout_rounding(cur, lab)
+        assert cur.dtype == torch.uint8 and np.array_equal(cur.cpu().numpy(), CUT["f_%s_out%d" % (tag, rep)]), (tag, rep)
+    assert np.random.randint(0, 1 << 30) == int(CUT["f_%s_state" % tag])
+
+
+@pytest.mark.parametrize("tag", sorted(CUT_MD))
+def test_device_mosaic_with_cutout_matches_reference_samples(tag):
+    ds = ToyDataset(DEV)
+    before = [im.clone() for im in ds.imgs]
+    md = pdata.MosaicDetection(ds, (48, 64), preprocess=pdata.TrainTransform(max_labels=20, flip_prob=0.5, hsv_prob=1.0), **CUT_MD[tag])
+    seed = int(CUT["%s_seed" % tag])
+    random.seed(seed)
+    np.random.seed(seed)
+    for k, idx in enumerate(CUT["%s_idx" % tag]):
+        img, lab, info, ids, name = md[int(idx)]
+        assert np.array_equal(img.cpu().numpy(), CUT["%s_%d_img" % (tag, k)]), (tag, k)
+        assert np.array_equal(np.asarray(lab, dtype=np.float32), CUT["%s_%d_labels" % (tag, k)]), (tag, k)
+    assert [random.random(), float(np.random.randint(0, 1 << 30))] == [float(v) for v in CUT["%s_state" % tag]]
+    assert all(torch.equal(a, b) for a, b in zip(before, ds.imgs))      # the data set's images are never written (the cut-out works on copies)
+
+
+def test_device_cutout_vs_oracle_at_640_with_many_boxes_and_holes():
+    """A 640 x 480 image, 40 boxes (some on the borders), 30 calls on one stream with up to 12 holes per call (more
+    than one launch's PLYOLO_MAX_HOLES): device == oracle bit for bit, same draws."""
+    rng = np.random.RandomState(3)
+    h, w = 480, 640
+    img = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+    x1 = rng.uniform(0, w * 0.8, 40); y1 = rng.uniform(0, h * 0.8, 40)
+    lab = np.stack([x1, y1, np.minimum(x1 + rng.uniform(4, 60, 40), w), np.minimum(y1 + rng.uniform(4, 60, 40), h), rng.randint(0, 80, 40).astype(np.float64)], 1)
+    lab[0, :4] = [0.0, 0.5, 30.0, 20.0]
+    lab[1, :4] = [600.0, 440.0, 640.0, 480.0]
+    ratio = [[0.02, 0.03], [0.05, 0.02], [0.01, 0.01], [0.04, 0.04]]
+    a, b = img.copy(), dev(img)
+    np.random.seed(9)
+    for _ in range(30):
+        a = om.cutout_rounding(a, lab, (4, 12), ratio, 0.7, 0.2)
+    st = np.random.randint(0, 1 << 30)
+    np.random.seed(9)
+    for _ in range(30):
+        b = pdata.cutout_rounding(b, lab, (4, 12), ratio, 0.7, 0.2)
+    assert np.random.randint(0, 1 << 30) == st
+    assert (a != img).any() and np.array_equal(b.cpu().numpy(), a)
+
+
 def test_refusals():
     with pytest.raises(NotImplementedError):
         pdata.MosaicDetection(ToyDataset(DEV), (48, 64), cutpaste_prob=0.1)
+    with pytest.raises(NotImplementedError):
+        pdata.MosaicDetection(ToyDataset(DEV), (48, 64), copypaste_prob=0.1)
     md = pdata.MosaicDetection(ToyDataset(None), (48, 64), preprocess=pdata.TrainTransform())   # host arrays: no CPU path
     with pytest.raises(PlyoloError):
         md[0]

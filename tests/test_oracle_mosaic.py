@@ -50,6 +50,60 @@ def test_oracle_matches_reference_samples(tag):
 def test_unbuilt_augmentations_raise():
     with pytest.raises(NotImplementedError):
         om.MosaicDetection(ToyDataset(), (48, 64), copypaste_prob=0.5)
+    with pytest.raises(NotImplementedError):
+        om.MosaicDetection(ToyDataset(), (48, 64), cutpaste_prob=0.5)
+
+
+# ---- rounding cut-out: the reference function itself ran here (numpy only) -- tests/golden/cutout_round.npz, tools/gen_golden.py cutout
+CUT = np.load(os.path.join(ROOT, "tests", "golden", "cutout_round.npz"))
+CUT_FN = ("interior", "edges", "none", "many", "tiny")
+CUT_MD = {"cmosaic": dict(mosaic_prob=1.0, mixup_prob=0.0, cutoutR_prob=1.0), "cplain": dict(mosaic_prob=0.0, cutoutR_prob=1.0),
+          "ccoin": dict(mosaic_prob=0.5, mixup_prob=0.5, cutoutR_prob=0.6)}
+
+
+@pytest.mark.parametrize("tag", CUT_FN)
+def test_cutout_rounding_matches_the_reference_function(tag):
+    """Four calls on one numpy-random stream, each on the previous result: fill colour from the strips around the boxes (boxes on
+    the image borders lose strips; no boxes: untouched), holes over holes, holes rejected by the box overlap, draw count."""
+    lab = CUT["f_%s_labels" % tag]
+    cur = CUT["f_%s_img" % tag].copy()
+    np.random.seed(int(CUT["f_%s_seed" % tag]))
+    for rep in range(4):
+        cur = om.cutout_rounding(cur, lab, om.CR_NHOLE, om.CR_RATIO, om.CR_MIXUP, om.CR_IOA)
+        assert cur.dtype == np.uint8 and np.array_equal(cur, CUT["f_%s_out%d" % (tag, rep)]), (tag, rep)
+    assert np.random.randint(0, 1 << 30) == int(CUT["f_%s_state" % tag])
+
+
+def test_cutout_fixture_exercises_accepts_rejects_and_overlaps():
+    """The fixture is not vacuous: holes were accepted (pixels changed), some draws were rejected (fewer changed rectangles than
+    drawn holes in at least one call), and the no-label case is the identity."""
+    assert np.array_equal(CUT["f_none_out3"], CUT["f_none_img"])
+    for tag in ("interior", "edges", "many", "tiny"):
+        assert (CUT["f_%s_out3" % tag] != CUT["f_%s_img" % tag]).any()
+    lab = CUT["f_many_labels"]
+    np.random.seed(int(CUT["f_many_seed"]))
+    h, w = CUT["f_many_img"].shape[:2]
+    drawn = accepted = 0
+    for rep in range(4):
+        for _ in range(np.random.randint(om.CR_NHOLE[0], om.CR_NHOLE[1] + 1)):
+            x1, y1, index = np.random.randint(0, w), np.random.randint(0, h), np.random.randint(0, len(om.CR_RATIO))
+            x2 = int(np.clip(x1 + om.CR_RATIO[index][0] * w, x1, w)); y2 = int(np.clip(y1 + om.CR_RATIO[index][1] * h, y1, h))
+            drawn += 1
+            accepted += bool(om.bbox_ioa([x1, y1, x2, y2], lab[:, :4]).max() < om.CR_IOA)
+    assert 0 < accepted < drawn
+
+
+@pytest.mark.parametrize("tag", sorted(CUT_MD))
+def test_oracle_mosaic_with_cutout_matches_reference_samples(tag):
+    md = om.MosaicDetection(ToyDataset(), (48, 64), preprocess=oa.TrainTransform(max_labels=20, flip_prob=0.5, hsv_prob=1.0), **CUT_MD[tag])
+    seed = int(CUT["%s_seed" % tag])
+    random.seed(seed)
+    np.random.seed(seed)
+    for k, idx in enumerate(CUT["%s_idx" % tag]):
+        img, lab, info, ids, name = md[int(idx)]
+        assert np.array_equal(np.asarray(img, dtype=np.float32), CUT["%s_%d_img" % (tag, k)]), (tag, k)
+        assert np.array_equal(np.asarray(lab, dtype=np.float32), CUT["%s_%d_labels" % (tag, k)]), (tag, k)
+    assert [random.random(), float(np.random.randint(0, 1 << 30))] == [float(v) for v in CUT["%s_state" % tag]]
 
 
 def test_mosaic_coordinates_tile_the_canvas():

@@ -823,14 +823,8 @@ def toy_detection_dataset(seed=5, n=7, size=(48, 64)):
     return ds
 
 
-def gen_mosaic():
-    """Mosaic / random-affine / mixup samples (SURVEY 8f rank 3) from the REFERENCE's own MosaicDetection + TrainTransform
-    (models/data/mosaic_detection.py, models/data/augmentation/data_augments.py).  Both files `import cv2`, which cannot be
-    installed here: the import is served by a module whose resize / warpAffine / getRotationMatrix2D / cvtColor / LUT are the
-    oracle's restatements of OpenCV's 8-bit algorithms (oracle/augment.py, oracle/mosaic.py).  What the fixture therefore PINS
-    is everything the reference itself decides -- control flow, the order of the draws from `random` / `numpy.random`, label
-    arithmetic, padding, blending -- given those pixel primitives; the primitives themselves stay unpinned against cv2."""
-    import random
+def _stub_cv2():
+    """`import cv2` inside the reference's data modules, served by the oracle's restatements of the OpenCV calls they make."""
     import types
     sys.path.insert(0, ROOT)
     from oracle import augment as oa, mosaic as om
@@ -854,6 +848,17 @@ def gen_mosaic():
         return out
     cv2.cvtColor = cvt
     sys.modules["cv2"] = cv2
+
+
+def gen_mosaic():
+    """Mosaic / random-affine / mixup samples (SURVEY 8f rank 3) from the REFERENCE's own MosaicDetection + TrainTransform
+    (models/data/mosaic_detection.py, models/data/augmentation/data_augments.py).  Both files `import cv2`, which cannot be
+    installed here: the import is served by a module whose resize / warpAffine / getRotationMatrix2D / cvtColor / LUT are the
+    oracle's restatements of OpenCV's 8-bit algorithms (oracle/augment.py, oracle/mosaic.py).  What the fixture therefore PINS
+    is everything the reference itself decides -- control flow, the order of the draws from `random` / `numpy.random`, label
+    arithmetic, padding, blending -- given those pixel primitives; the primitives themselves stay unpinned against cv2."""
+    import random
+    _stub_cv2()
     from models.data.mosaic_detection import MosaicDetection
     from models.data.augmentation.data_augments import TrainTransform
     d = {}
@@ -883,7 +888,64 @@ def gen_mosaic():
     del sys.modules["cv2"]
 
 
+def gen_cutout():
+    """Rounding cut-out (SURVEY 8f rank 3 remainder).  (1) The reference's own `cutout_rounding`
+    (models/data/augmentation/cutout_round.py -- numpy only, it runs here unchanged) on seeded images and boxes: interior boxes,
+    boxes on every image border, no boxes, many boxes, repeated calls on one numpy-random stream (holes over holes, rejected holes).
+    (2) The reference's MosaicDetection with cutoutR_prob > 0 (cv2 served as in gen_mosaic): the mosaic branch, the plain branch, a
+    mix of both."""
+    import random
+    sys.path.insert(0, REF)
+    from models.data.augmentation.cutout_round import cutout_rounding
+    nhole, ratio, mix, thr = (1, 3), [[0.1, 0.1], [0.3, 0.1], [0.1, 0.3], [0.2, 0.2], [0.3, 0.3]], 0.7, 0.2   # mosaic_detection.py:52-55
+    d = {}
+    rng = np.random.RandomState(77)
+
+    def boxes(k, h, w, edge=False):
+        x1 = rng.uniform(2, w * 0.6, k); y1 = rng.uniform(2, h * 0.6, k)
+        bw = rng.uniform(3, w * 0.3, k); bh = rng.uniform(3, h * 0.3, k)
+        lab = np.stack([x1, y1, np.minimum(x1 + bw, w - 2), np.minimum(y1 + bh, h - 2), rng.randint(0, 80, k).astype(np.float64)], 1)
+        if edge:      # one box on the left / top borders, one on the right / bottom ones
+            lab[0, :4] = [0.4, 0.0, w * 0.3, h * 0.25]
+            lab[1, :4] = [w * 0.7, h * 0.7, float(w), h - 0.5]
+        return lab
+    cases = [("interior", 40, 56, boxes(3, 40, 56)), ("edges", 44, 60, boxes(4, 44, 60, edge=True)), ("none", 32, 48, np.zeros((0, 5))),
+             ("many", 60, 84, boxes(11, 60, 84)), ("tiny", 9, 13, np.array([[3.2, 2.1, 7.9, 6.5, 1.0]]))]
+    for tag, h, w, lab in cases:
+        img = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        d["f_%s_img" % tag], d["f_%s_labels" % tag] = img, lab
+        np.random.seed(1000 + len(tag))
+        d["f_%s_seed" % tag] = np.asarray(1000 + len(tag))
+        cur = img.copy()
+        for rep in range(4):      # four calls on one stream, each on the previous result
+            cur = cutout_rounding(cur, lab, nhole, ratio, mix, thr)
+            d["f_%s_out%d" % (tag, rep)] = cur.copy()
+        d["f_%s_state" % tag] = np.asarray(np.random.randint(0, 1 << 30))
+    _stub_cv2()
+    from models.data.mosaic_detection import MosaicDetection
+    from models.data.augmentation.data_augments import TrainTransform
+    for tag, kw, seed in [("cmosaic", dict(mosaic_prob=1.0, mixup_prob=0.0, cutoutR_prob=1.0), 21), ("cplain", dict(mosaic_prob=0.0, cutoutR_prob=1.0), 22),
+                          ("ccoin", dict(mosaic_prob=0.5, mixup_prob=0.5, cutoutR_prob=0.6), 23)]:
+        ds = toy_detection_dataset()
+        md = MosaicDetection(ds, (48, 64), preprocess=TrainTransform(max_labels=20, flip_prob=0.5, hsv_prob=1.0), **kw)
+        random.seed(seed)
+        np.random.seed(seed)
+        idxs = [0, 3, 5, 2]
+        for k, idx in enumerate(idxs):
+            img, lab, info, ids, name = md[idx]
+            d["%s_%d_img" % (tag, k)] = np.asarray(img, dtype=np.float32)
+            d["%s_%d_labels" % (tag, k)] = np.asarray(lab, dtype=np.float32)
+        d["%s_idx" % tag] = np.asarray(idxs)
+        d["%s_seed" % tag] = np.asarray(seed)
+        d["%s_state" % tag] = np.asarray([random.random(), float(np.random.randint(0, 1 << 30))])
+    save("cutout_round", d)
+    del sys.modules["cv2"]
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "cutout":
+        gen_cutout()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "mosaic":
         gen_mosaic()
         sys.exit(0)
@@ -926,4 +988,5 @@ if __name__ == "__main__":
     gen_deploy()
     gen_cfg1()
     gen_mosaic()
+    gen_cutout()
     gen_schedule()
