@@ -170,7 +170,7 @@ def nms_bench(device, B=16, n=1000, reps=20, cpu=True):
 # stride-2 parity-class jobs are all instances of conv_mfma_kernel / conv_mfma_jobs_kernel
 _KERNEL_OF = {"conv_mfma_fwd": "conv_mfma_kernel", "conv_mfma_dgrad": "conv_mfma_kernel", "conv_mfma_dgrad_s2": "conv_mfma_jobs_kernel",
               "conv_wgrad": "conv_wgrad_kernel", "conv3ws_fwd": "conv3ws_kernel", "conv3ws_dgrad": "conv3ws_kernel", "conv_pw_fwd": "conv_pw_kernel", "conv_pw_dgrad": "conv_pw_kernel",
-              "conv_mfma_fwd_s2": "conv_mfma_kernel", "conv_pw_dgrad_bn": "conv_pw_kernel", "conv_pw_bwd": "conv_pw_bwd_kernel"}
+              "conv_mfma_fwd_s2": "conv_mfma_kernel", "conv_pw_dgrad_bn": "conv_pw_kernel", "conv_pw_bwd": "conv_pw_bwd_kernel", "conv_s2d_dgrad": "conv_s2d_kernel"}
 
 
 def lib_md5():

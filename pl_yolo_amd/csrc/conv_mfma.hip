@@ -42,6 +42,9 @@ namespace plyolo {
 hipError_t conv_mfma_launch_s2(const void* convp, int BN, hipStream_t s);   // conv_mfma_s2.hip
 hipError_t conv_mfma_launch_t4(const void* convp, int BN, int red, hipStream_t s);   // conv_mfma_t4.hip
 // conv_mfma_red.hip: data-gradient instances that fold the upstream BatchNorm-backward reduction into their store loop
+// conv_s2d.hip: 3x3 stride-2 data gradient, the four parity classes on one staged tile
+int conv_s2d_th(int BN);
+hipError_t conv_s2d_launch(const void* convp, int BN, int red, hipStream_t s);
 int conv_mfma_red_has(int BN, int CK, int TH, int jobs);
 hipError_t conv_mfma_launch_red(const void* convp, int BN, int CK, int TH, hipStream_t s);
 hipError_t conv_mfma_launch_jobs_red(const void* jobsp, int BN, int CK, int TH, hipStream_t s);
@@ -364,6 +367,34 @@ int conv_mfma_dgrad(const plyolo_conv_desc* d, const void* dy, const void* wpd, 
     }
     if (use_red) return submit(stream, [=](hipStream_t s) { return conv_mfma_launch_red(&p, BN, CK, TH, s); });
     return submit(stream, [=](hipStream_t s) { return launch_bn<false>(p, BN, CK, TH, s); });
+  }
+  // 3x3 stride 2 into at most 64 channels: all four parity classes on ONE staged dZ tile per workgroup (conv_s2d.hip; PLYOLO_S2D=0: the
+  // four-job launch below).  Same box, batch 32: 64 -> 32 channels @320x320 147 -> 92 us, 128 -> 64 @160x160 74 -> 65 us.  The wider
+  // layers keep the four jobs (4 launches of YOLOX-s, 0.33 ms): one workgroup holds 4 classes x MT fragments x 16 accumulators, and with
+  // two workgroups per CU that leaves MT = 2 -- every weight fragment feeds two MFMAs and the launch is bound by the vector L1 (4-row
+  // tiles 0.37 ms, 64-channel blocks 0.39 ms) -- while MT = 4 with one wave per SIMD exposes the LDS latency (8-row tiles 0.50 ms)
+  {
+    const int s2d = getenv("PLYOLO_S2D") ? atoi(getenv("PLYOLO_S2D")) : 1;            // (read per call: the tests switch them)
+    const int s2d_maxc = getenv("PLYOLO_S2D_MAXC") ? atoi(getenv("PLYOLO_S2D_MAXC")) : 64;
+    const int bn = d->Cin > 64 ? 128 : (d->Cin > 32 ? 64 : 32);
+    if (s2d && d->Cin <= s2d_maxc && d->ksize == 3 && d->stride == 2 && !getenv("PLYOLO_ABLATE")) {
+      if (red_fits) { *red_fits = 1; return 0; }
+      ConvP p = b;
+      const int th = conv_s2d_th(bn);
+      p.OHt = (d->H + 1) / 2; p.OWt = (d->W + 1) / 2;
+      p.so = 2; p.oy_off = 0; p.ox_off = 0; p.iy_off = 0; p.ix_off = 0;
+      p.ntaps = 9;
+      p.tiles_y = (p.OHt + th - 1) / th;
+      p.tiles_x = (p.OWt + TW - 1) / TW;
+      p.nmb = p.N * p.tiles_y * p.tiles_x;
+      const bool use_red = red && red->n > 0;
+      if (use_red) p.red = *red;
+      char lab[64];
+      snprintf(lab, sizeof(lab), "conv_s2d_dgrad<BN%d,TH%d>%s", bn, th, use_red ? "+bnred" : "");
+      const double Mo = (double)d->N * OH * OW, Mi = (double)d->N * d->H * d->W;
+      annotate(lab, 2.0 * Mo * d->Cout * d->Cin * 9.0, (Mo * Kc + Mi * d->Cin * ((accumulate ? 2.0 : 1.0) + (use_red ? 1.0 : 0.0))) * 2.0);
+      return submit(stream, [=](hipStream_t s) { return conv_s2d_launch(&p, bn, use_red ? 1 : 0, s); });
+    }
   }
   // stride 2 (ksize 3 pad 1, or ksize 1): one job per output parity class (1/2/2/4 taps), all four in ONE launch
   ConvJobs jobs{};

@@ -427,6 +427,40 @@ def test_pointwise_unit_backward_in_one_launch(shape, act, grid, monkeypatch):
 
 # (N, H, W, Cin, Cout, k, s, segments of dx channels): data gradients whose store loop folds the BatchNorm-backward reduction of the
 # upstream unit(s); two segments = a concatenated input (one BatchNorm unit per part), a gap = a part without a BatchNorm unit
+@pytest.mark.parametrize("shape", [(2, 32, 32, 64, 128, 3, 2), (1, 64, 64, 32, 64, 3, 2), (2, 26, 38, 128, 256, 3, 2), (3, 17, 23, 24, 40, 3, 2),
+                                   (2, 21, 30, 96, 72, 3, 2), (1, 160, 160, 32, 64, 3, 2)], ids=str)
+@pytest.mark.parametrize("acc", [0, 1])
+def test_stride2_dgrad_fused_parity_classes_equal_the_four_job_launch(shape, acc, monkeypatch):
+    """conv_s2d.hip (the four parity classes of a 3x3 stride-2 data gradient on one staged dZ tile per workgroup; default for at most
+    64 input channels, forced here for every width) against the four-job launch of conv_mfma.hip: the same taps in the same order into
+    every accumulator -- dx bit for bit, odd maps, channel tails, accumulation into dx."""
+    N, H, W, Cin, Cout, k, st = shape
+    dt = BF16
+    torch.manual_seed(sum(shape) + 5)
+    dev = hu.DEV
+    OH, OW = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    Mi, Mo = N * H * W, N * OH * OW
+    w = hu.rnd_bf16(torch.randn(Cout, Cin, k, k, device=dev) / (Cout * k * k) ** 0.5)
+    pk = hu.Packed(w, dt)
+    y_ld, x_ld = (Cout + 7) // 8 * 8 + 8, (Cin + 7) // 8 * 8 + 8
+    dy = torch.zeros(Mo, y_ld, device=dev)
+    dy[:, :Cout] = torch.randn(Mo, Cout, device=dev)
+    dy = dy.to(torch.bfloat16)
+    d = hu.conv_desc(dt, N, H, W, Cin, Cout, k, st, x_ld, y_ld)
+    base = torch.randn(Mi, x_ld, device=dev).to(torch.bfloat16)
+    outs = []
+    for s2d in ("0", "1"):
+        monkeypatch.setenv("PLYOLO_S2D", s2d)
+        monkeypatch.setenv("PLYOLO_S2D_MAXC", "4096")
+        dx = base.clone()
+        call("plyolo_conv2d_dgrad", C.byref(d), dy.data_ptr(), pk.wpd.data_ptr(), dx.data_ptr(), acc, hu.stream())
+        torch.cuda.synchronize()
+        outs.append(dx)
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    assert float((outs[1][:, :Cin].float() - (base[:, :Cin].float() if acc else 0)).abs().max()) > 0
+    assert torch.equal(outs[1][:, Cin:].view(torch.int16), base[:, Cin:].view(torch.int16))      # the pitch padding is never written
+
+
 RED_SHAPES = [(2, 20, 20, 128, 128, 3, 1, [(0, 128)]), (3, 24, 18, 64, 64, 3, 1, [(0, 32), (32, 64)]), (1, 36, 40, 32, 32, 3, 1, [(0, 32)]),
               (2, 32, 32, 64, 128, 3, 2, [(0, 64)]), (1, 64, 64, 32, 64, 3, 2, [(0, 32)]), (2, 26, 38, 128, 256, 3, 2, [(0, 64), (64, 128)]),
               (2, 20, 20, 128, 128, 1, 1, [(0, 128)]), (3, 13, 9, 64, 96, 1, 1, [(8, 40)]), (2, 40, 40, 256, 80, 1, 1, [(0, 128), (128, 256)]),
