@@ -20,6 +20,9 @@
 namespace {
 
 constexpr int S2D_CK = 32, S2D_KS = 2, S2D_CV = 4, S2D_ROWB = S2D_CK * 2 + 16;
+#ifndef S2D_PD
+#define S2D_PD 2
+#endif
 
 // tap t = kh * 3 + kw (the pack's tap order): parity class and tile offset
 constexpr int s2d_py(int t) { return ((t / 3) + 1) & 1; }
@@ -121,8 +124,11 @@ __global__ __launch_bounds__(256, OCC) void conv_s2d_kernel(const ConvP p) {
       if (loff[v] >= 0) *(u32x4*)(smem + boff + loff[v]) = (goff[v] >= 0 && cok) ? hv[v] : zero;
   };
 
-  u32x4 bq[2][KS];
-  load_b(bq[0], 0, 0);
+  // weight fragments PD taps ahead (a tap of this kernel is only 2 x MT MFMAs: one tap of distance does not cover an L2 round trip)
+  constexpr int PD = S2D_PD;
+  u32x4 bq[PD + 1][KS];
+#pragma unroll
+  for (int d = 0; d < PD; ++d) load_b(bq[d], d / 9 < nchunks ? d / 9 : nchunks - 1, d % 9);
   u32x4 hv[HVT];
   halo_load(0, hv);
   halo_store(0, hv, 0);
@@ -133,9 +139,12 @@ __global__ __launch_bounds__(256, OCC) void conv_s2d_kernel(const ConvP p) {
     const int cnext = (chunk + 1) * S2D_CK;   // past Cin on the last chunk: every load collapses to the dummy address
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      // the next tap's fragments (the next chunk's first tap behind the last one; parked on the last chunk)
-      const int nchunk = t < 8 ? chunk : (chunk + 1 < nchunks ? chunk + 1 : chunk);
-      load_b(bq[1], nchunk, t < 8 ? t + 1 : 0);
+      // the fragments of the tap PD ahead (into the next chunk behind the last taps; parked on the last chunk)
+      {
+        constexpr int dummy_pd = PD;
+        const int tn = (t + dummy_pd) % 9, cn = chunk + (t + dummy_pd) / 9;
+        load_b(bq[PD], cn < nchunks ? cn : nchunks - 1, tn);
+      }
       if (t == 0) halo_load(cnext, hv);
       __builtin_amdgcn_sched_barrier(0);   // the prefetch stays ABOVE the MFMA block
       const int toff = boff + s2d_dy(t) * p.rowp + s2d_dx(t) * ROWB;
@@ -161,7 +170,9 @@ __global__ __launch_bounds__(256, OCC) void conv_s2d_kernel(const ConvP p) {
         }
       }
 #pragma unroll
-      for (int kk = 0; kk < KS; ++kk) bq[0][kk] = bq[1][kk];
+      for (int d = 0; d < PD; ++d)
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) bq[d][kk] = bq[d + 1][kk];
     }
     if (chunk + 1 < nchunks) halo_store(cnext, hv, p.bufsz - boff);
     __syncthreads();   // next buffer complete; every wave is done with this one
