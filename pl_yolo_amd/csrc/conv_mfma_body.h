@@ -168,7 +168,10 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
 
   // weight fragments in flight: PD taps ahead.  PD = 2 on the 32-channel double-buffered variant (a tap there is only
   // 256 cycles of MFMA) measured 1.5 % SLOWER on the whole step (+8 VGPRs, same occupancy), so one tap it stays
-  constexpr int PD = 1;
+#ifndef PLYOLO_CONV_PD
+#define PLYOLO_CONV_PD 1
+#endif
+  constexpr int PD = PLYOLO_CONV_PD;
   u32x4 bq[PD + 1][KS];
   // The (chunk, tap) of the next prefetch is tracked incrementally (deriving it from the phase counter cost a scalar
   // integer division -- ~20 SALU instructions -- per tap).  Past the last tap the stream parks on the last fragments:
