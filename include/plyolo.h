@@ -427,6 +427,15 @@ struct plyolo_bn_red;
 int plyolo_conv2d_dgrad_bn_red(const plyolo_conv_desc* d, const plyolo_bn_bwd_fuse* f, const void* wpd, void* dx,
                                int accumulate, const struct plyolo_bn_red* red, void* stream);
 
+/* The weight gradient of a BaseConv unit WITHOUT a data gradient (the first convolution of a network: nothing upstream takes a
+ * gradient) behind plyolo_bn_act_bwd_reduce, with the unit's plyolo_bn_act_bwd_dz in its loader (csrc/conv_wgrad_mfma.hip, BNB
+ * instances): such a unit's dz is read by the weight gradient only, so f->dout and f->z are read once and dz never reaches HBM (f->dz
+ * is ignored and may be NULL).  Same private slabs as plyolo_bn_act_bwd_dz + plyolo_conv2d_wgrad, bit for bit
+ * (plyolo_conv2d_wgrad_slabs(d) of them at dwp); dgamma / dbeta are written as plyolo_bn_act_bwd_dz writes them.
+ * plyolo_conv2d_wgrad_bn_fits: 1 if covered (bf16, 3x3 stride 1, SiLU, at most 64 output and 32 input channels), else 0. */
+int plyolo_conv2d_wgrad_bn_fits(const plyolo_conv_desc* d, int act);
+int plyolo_conv2d_wgrad_bn(const plyolo_conv_desc* d, const plyolo_bn_bwd_fuse* f, const void* x, float* dwp, void* stream);
+
 /* The WHOLE backward of a pointwise BaseConv unit behind plyolo_bn_act_bwd_reduce, in one persistent launch (csrc/conv_pw_bwd.hip):
  * dz = plyolo_bn_act_bwd_dz(dout, z) is formed tile by tile in LDS and feeds both dx (+)= dz . W (== plyolo_conv2d_dgrad, bit for
  * bit) and dW = dz^T . x (== plyolo_conv2d_wgrad up to the order of its fp32 sums); dout, z and x are read once, dz never reaches

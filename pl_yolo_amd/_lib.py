@@ -191,6 +191,8 @@ SIGNATURES = {
     "plyolo_conv2d_dgrad_red_fits": (_i, [_P(ConvDesc)]),
     "plyolo_conv2d_bwd_pw_red": (_i, [_P(ConvDesc), _P(BnBwdFuse), _vp, _vp, _vp, _i, _vp, _P(BnRed), _vp]),
     "plyolo_conv2d_bwd_pw_fits": (_i, [_P(ConvDesc), _i]),
+    "plyolo_conv2d_wgrad_bn_fits": (_i, [_P(ConvDesc), _i]),
+    "plyolo_conv2d_wgrad_bn": (_i, [_P(ConvDesc), _P(BnBwdFuse), _vp, _vp, _vp]),
     "plyolo_conv2d_bwd_pw_slabs": (_i, [_P(ConvDesc)]),
     "plyolo_conv2d_bwd_pw": (_i, [_P(ConvDesc), _P(BnBwdFuse), _vp, _vp, _vp, _i, _vp, _vp]),
     "plyolo_conv2d_wgrad_slabs": (_i, [_P(ConvDesc)]),

@@ -58,6 +58,8 @@ int conv_mfma_dgrad(const plyolo_conv_desc*, const void*, const void*, void*, in
 int conv_mfma_dgrad_red_fits(const plyolo_conv_desc*);
 int conv_mfma_wgrad(const plyolo_conv_desc*, const void*, const void*, float*, void*);
 int conv_mfma_wgrad_slabs(const plyolo_conv_desc*);
+int conv_mfma_wgrad_bn_fits(const plyolo_conv_desc*, int);
+int conv_mfma_wgrad_bn(const plyolo_conv_desc*, const plyolo_bn_bwd_fuse*, const void*, float*, void*);
 bool conv_pw_enabled();
 int conv_pw_fwd(const plyolo_conv_desc*, const void*, const void*, const float*, void*, double*, const float*, int, const void*, int, void*);
 int conv_pw_dgrad(const plyolo_conv_desc*, const void*, const void*, void*, int, const plyolo_bn_red*, void*, int*);
@@ -553,6 +555,18 @@ int plyolo_conv2d_dgrad_bn_red(const plyolo_conv_desc* d, const plyolo_bn_bwd_fu
   PLY_CHECK_ARG(!f->dout2 || (f->dout_split > 0 && f->dout_split < d->Cout && f->dout_split % 8 == 0 && f->dout2_ld % 8 == 0), "conv2d_dgrad_bn: bad output-gradient split");
   PLY_CHECK_ARG(f->par_split == 0 || (f->par_split > 0 && f->par_split < d->Cout), "conv2d_dgrad_bn: bad parameter split");
   return conv_pw_dgrad_bn(d, f, wpd, dx, accumulate, red, stream);
+}
+int plyolo_conv2d_wgrad_bn_fits(const plyolo_conv_desc* d, int act) {
+  if (check_conv(d, "conv2d_wgrad_bn_fits", false)) return -1;
+  return conv_mfma_wgrad_bn_fits(d, act);
+}
+int plyolo_conv2d_wgrad_bn(const plyolo_conv_desc* d, const plyolo_bn_bwd_fuse* f, const void* x, float* dwp, void* stream) {
+  if (check_conv(d, "conv2d_wgrad_bn", false)) return -1;
+  PLY_CHECK_ARG(f && f->dout && f->z && f->coef && f->bslots && x && dwp, "conv2d_wgrad_bn: incomplete arguments");
+  PLY_CHECK_ARG(conv_mfma_wgrad_bn_fits(d, f->act) == 1, "conv2d_wgrad_bn: this unit is not covered (ask plyolo_conv2d_wgrad_bn_fits; use plyolo_bn_act_bwd_dz + plyolo_conv2d_wgrad)");
+  PLY_CHECK_ARG(f->dout_ld % 8 == 0 && f->z_ld % 8 == 0 && f->z_ld >= d->Cout && f->dout_ld >= d->Cout && !f->dout2 && f->par_split == 0,
+                "conv2d_wgrad_bn: pitches must be multiples of 8 and hold Cout channels; one output-gradient matrix, one parameter set");
+  return conv_mfma_wgrad_bn(d, f, x, dwp, stream);
 }
 int plyolo_conv2d_bwd_pw_fits(const plyolo_conv_desc* d, int act) {
   if (check_conv(d, "conv2d_bwd_pw_fits", false)) return -1;

@@ -39,7 +39,21 @@ struct WgP {
   int S;       // spatial splits; the grid is 1-D: S * nslabt workgroups
   int xcd;     // 1: slab tiles of one split adjacent in an XCD-contiguous order (PLYOLO_WG_XCD, default), 0: the round-1 order
   int ablate;  // diagnostics (PLYOLO_ABLATE_WG): 1 skip atomics, 2 skip tile loads after the first, 4 skip MFMA, 8 force S
+  // BNB instances (plyolo_conv2d_wgrad_bn): `dy` is the gradient of the unit's ACTIVATED output; the loader forms
+  // dz = A*du + B*z + Cc (bn.hip: bn_act_bwd_dz, bit for bit) from it and the unit's raw conv output z on the way into LDS
+  const bf16_t* bz;
+  int bz_ld;
+  const float* bcoef;     // (scale | shift | mean | invstd) [4][Cout]
+  const double* bslots;   // [PLYOLO_STAT_SLOTS][2][Cout]
+  const float* bgamma;
+  float *bdgamma, *bdbeta;
+  double bcount;
 };
+
+DEVINL float wg_silu_grad(float u) {      // == act_grad<false>(u, PLYOLO_ACT_SILU) (bn.hip) == pw_act_grad (conv_pw.hip)
+  const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-u));
+  return s * (1.0f + u * (1.0f - s));
+}
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
@@ -303,7 +317,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
 //   * tile loads are raw buffer loads (one descriptor per image): padding, ragged edges, channel tails and "no such tile"
 //     (a zero-record descriptor) all come back as zeros from the range check -- no branches, so every k-step stays one
 //     scheduling region; the per-vector offsets and LDS addresses are computed once per kernel, a tile costs 6 VALU per vector.
-template <int CO_T, int CI_T, int WK, int TH_, int SI, bool PRE>
+// BNB (plyolo_conv2d_wgrad_bn; SiLU units without a data gradient -- the first convolution of a network): the separate
+// bn_act_bwd_dz pass of such a unit writes a dz that ONLY this kernel reads.  Here the dY vectors of a tile arrive as (dout, z) pairs
+// and are turned into dz between the register set and LDS: dout and z are read once, dz never reaches HBM (3 E_out of traffic less).
+template <int CO_T, int CI_T, int WK, int TH_, int SI, bool PRE, bool BNB = false>
 __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WgP p) {
   constexpr int KS = 3, NTAPS = 9;
   constexpr int WCO = CO_T / 32, WCI = CI_T / 32;
@@ -364,6 +381,47 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WgP p) {
     yx[DV + v] = live ? (unsigned)iy | ((unsigned)ix << 16) : NEVER;
     lds[DV + v] = idx < NXV ? DZ_BYTES + pix * XB + vv * 16 : DUMP + tid * 16;
   }
+  // BNB: z offsets of the dY vectors, the (scale, shift, A, B, Cc) of this thread's 8 output channels (the channel vector of a
+  // thread is the same for all its dY vectors: 256 % DZV == 0), dgamma / dbeta from workgroup 0
+  [[maybe_unused]] int relz[BNB ? DV : 1];
+  [[maybe_unused]] float bsc[BNB ? 8 : 1], bsh[BNB ? 8 : 1], bA[BNB ? 8 : 1], bB[BNB ? 8 : 1], bC[BNB ? 8 : 1];
+  if constexpr (BNB) {
+    static_assert(256 % DZV == 0 && !PRE, "BNB: a fixed channel vector per thread");
+#pragma unroll
+    for (int v = 0; v < DV; ++v) {
+      const int idx = tid + v * 256, m = idx / DZV, vv = idx - m * DZV;
+      relz[v] = (((m >> 4) * p.OW + (m & 15)) * p.bz_ld + co0 + vv * 8) * 2;
+    }
+    float* tab = (float*)(smem + 2 * BUFP);      // [5][CO_T], built once per workgroup
+    for (int ch = tid; ch < CO_T; ch += 256) {
+      const int c = co0 + ch;
+      float vsc = 0.f, vsh = 0.f, A = 0.f, B = 0.f, Cc = 0.f;
+      if (c < p.Cout) {
+        double su = 0.0, suz = 0.0;
+#pragma unroll
+        for (int sl = 0; sl < PLYOLO_STAT_SLOTS; ++sl) {
+          su += p.bslots[((size_t)sl * 2 + 0) * p.Cout + c];
+          suz += p.bslots[((size_t)sl * 2 + 1) * p.Cout + c];
+        }
+        const float mean = p.bcoef[2 * p.Cout + c], invstd = p.bcoef[3 * p.Cout + c];
+        A = (p.bgamma ? p.bgamma[c] : 1.f) * invstd;
+        B = (float)(-(double)A * (suz / p.bcount) * (double)invstd);
+        Cc = (float)(-(double)A * (su / p.bcount) - (double)B * (double)mean);
+        vsc = p.bcoef[c]; vsh = p.bcoef[p.Cout + c];
+        if (wg == 0) {
+          if (p.bdbeta) p.bdbeta[c] = (float)su;
+          if (p.bdgamma) p.bdgamma[c] = (float)suz;
+        }
+      }
+      tab[ch] = vsc; tab[CO_T + ch] = vsh; tab[2 * CO_T + ch] = A; tab[3 * CO_T + ch] = B; tab[4 * CO_T + ch] = Cc;
+    }
+    __syncthreads();
+    const int ch0 = (tid % DZV) * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      bsc[i] = tab[ch0 + i]; bsh[i] = tab[CO_T + ch0 + i]; bA[i] = tab[2 * CO_T + ch0 + i]; bB[i] = tab[3 * CO_T + ch0 + i]; bC[i] = tab[4 * CO_T + ch0 + i];
+    }
+  }
   float psc[PRE ? 8 : 1], psh[PRE ? 8 : 1];
   if constexpr (PRE) {
     const int ci = ci0 + (tid % XV) * 8;
@@ -375,8 +433,8 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WgP p) {
   }
 
   struct Tile {
-    __amdgpu_buffer_rsrc_t rd, rx;
-    int oy0, ox0, iy0, ix0, dbase, xbase;
+    __amdgpu_buffer_rsrc_t rd, rx, rz;
+    int oy0, ox0, iy0, ix0, dbase, xbase, zbase;
   };
   const int d_img = ((p.OH * p.OW - 1) * p.dy_ld + ((p.Cout + 7) & ~7)) * 2, x_img = ((p.H * p.W - 1) * p.x_ld + ((p.Cin + 7) & ~7)) * 2;
   auto tile_at = [&](int tile) {      // wave-uniform (blockIdx and kernel arguments only): lives in SGPRs
@@ -390,10 +448,16 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WgP p) {
     t.xbase = (t.iy0 * p.W + t.ix0) * p.x_ld * 2;
     t.rd = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dy + (size_t)n * p.OH * p.OW * p.dy_ld), 0, real ? d_img : 0, 0x00020000);
     t.rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)n * p.H * p.W * p.x_ld), 0, real ? x_img : 0, 0x00020000);
+    if constexpr (BNB) {
+      const int z_img = ((p.OH * p.OW - 1) * p.bz_ld + ((p.Cout + 7) & ~7)) * 2;
+      t.zbase = (t.oy0 * p.OW + t.ox0) * p.bz_ld * 2;
+      t.rz = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bz + (size_t)n * p.OH * p.OW * p.bz_ld), 0, real ? z_img : 0, 0x00020000);
+    }
     return t;
   };
   u32x4 R[NV];
-  unsigned hmask = 0u;                 // lazy input: which X vectors in R are real pixels (padding stays zero)
+  [[maybe_unused]] u32x4 RZ[BNB ? DV : 1];
+  unsigned hmask = 0u;                 // lazy input: which X vectors in R are real pixels (padding stays zero); BNB: which dY vectors are
   auto request = [&](const Tile& t, int v) {   // v: compile-time after unrolling
     const bool isx = v >= DV;
     const int y = (isx ? t.iy0 : t.oy0) + (int)(yx[v] & 0xffffu), x = (isx ? t.ix0 : t.ox0) + (int)(yx[v] >> 16);
@@ -401,9 +465,35 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WgP p) {
     const int off = ok ? (isx ? t.xbase : t.dbase) + rel[v] : (int)0x80000000;   // past any image: the range check returns zeros
     R[v] = __builtin_amdgcn_raw_buffer_load_b128(isx ? t.rx : t.rd, off, 0, 0);
     if constexpr (PRE) { if (isx) hmask = ok ? hmask | (1u << (v - DV)) : hmask & ~(1u << (v - DV)); }
+    if constexpr (BNB) {
+      if (!isx) {
+        // (mask arithmetic, no second use of `ok` as a condition: with two conditional uses the compiler splits the request into an
+        // if / else with a load on either side, and behind a branch the tile pipeline's vector-memory waits become full drains)
+        const unsigned m = 0u - (unsigned)ok;
+        RZ[v < DV ? v : 0] = __builtin_amdgcn_raw_buffer_load_b128(t.rz, (int)(((unsigned)(t.zbase + relz[v < DV ? v : 0]) & m) | (0x80000000u & ~m)), 0, 0);
+        hmask = (hmask & ~(1u << v)) | ((1u << v) & m);           // an absent pixel (or tile) must stage 0, not Cc
+      }
+    }
   };
   auto stage = [&](unsigned char* buf, int v) {
     u32x4 t = R[v];
+    if constexpr (BNB) {
+      if (v < DV) {
+        const u32x4 zz = RZ[v < DV ? v : 0];
+        // an all-ones / all-zeros word ANDed in, not a select: the compiler turns `real ? q : 0` into a branch around the arithmetic,
+        // and behind a branch every vector-memory wait of the tile pipeline becomes a wait for everything in flight
+        const unsigned keep = 0u - ((hmask >> v) & 1u);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float zl = __uint_as_float(zz[i] << 16), zh = __uint_as_float(zz[i] & 0xffff0000u);
+          const float dl = __uint_as_float(t[i] << 16), dh = __uint_as_float(t[i] & 0xffff0000u);
+          const float dul = dl * wg_silu_grad(fmaf(zl, bsc[2 * i], bsh[2 * i]));
+          const float duh = dh * wg_silu_grad(fmaf(zh, bsc[2 * i + 1], bsh[2 * i + 1]));
+          const unsigned q = pack2bf(fmaf(bA[2 * i], dul, fmaf(bB[2 * i], zl, bC[2 * i])), fmaf(bA[2 * i + 1], duh, fmaf(bB[2 * i + 1], zh, bC[2 * i + 1])));
+          t[i] = q & keep;
+        }
+      }
+    }
     if constexpr (PRE) {
       if (v >= DV) {
         const bool real = (hmask >> (v - DV)) & 1u;
@@ -528,6 +618,24 @@ hipError_t launch_wg3(const WgP& p, int S, hipStream_t s) {
 #else
   auto kern = conv_wgrad3_kernel<CO_T, CI_T, WK, TH_, SI, false>;   // lazy inputs are refused at the C ABI (api.hip: check_conv)
 #endif
+  if (hipError_t e = plyolo::ensure_dynamic_lds((const void*)kern, 160 * 1024); e != hipSuccess) return e;
+  const int nco = (p.Cout + CO_T - 1) / CO_T;
+  WgP q = p;
+  q.nslabt = nco * p.nci;
+  q.S = S;
+  static const int xcd = getenv("PLYOLO_WG_XCD") ? atoi(getenv("PLYOLO_WG_XCD")) : 1;
+  q.xcd = xcd;
+  hipLaunchKernelGGL(kern, dim3(S * q.nslabt), dim3(256), lds, s, q);
+  return hipGetLastError();
+}
+
+// BNB instances (plyolo_conv2d_wgrad_bn): the per-channel table sits behind the two tile buffers
+template <int CO_T, int CI_T, int WK, int TH_>
+hipError_t launch_wg3_bnb(const WgP& p, int S, hipStream_t s) {
+  constexpr int SI = 1;
+  constexpr int DZB = pitch_for(CO_T), XB = pitch_for(CI_T);
+  const size_t lds = 2 * ((size_t)TH_ * TW * DZB + (size_t)((TH_ - 1) * SI + 3) * ((TW - 1) * SI + 3) * XB + 4096) + 5 * CO_T * 4;
+  auto kern = conv_wgrad3_kernel<CO_T, CI_T, WK, TH_, SI, false, true>;
   if (hipError_t e = plyolo::ensure_dynamic_lds((const void*)kern, 160 * 1024); e != hipSuccess) return e;
   const int nco = (p.Cout + CO_T - 1) / CO_T;
   WgP q = p;
@@ -703,6 +811,43 @@ int conv_mfma_wgrad(const plyolo_conv_desc* d, const void* x, const void* dy, fl
       case 4: return s2 ? launch_wg<64, 64, 1, 1, 1, 1, 8, 2>(p, S, s) : launch_wg<64, 64, 1, 1, 1, 1, 8, 1>(p, S, s);
       default: return launch_wg<128, 128, 1, 1, 2, 2, 4, 1>(p, S, s);
     }
+  });
+}
+
+
+// 1 when plyolo_conv2d_wgrad_bn covers this unit: bf16, 3x3 stride 1, SiLU, at most 64 output and 32 input channels with the 16-row
+// tiles (the first convolution of a CSPDarknet / ELAN stem)
+int conv_mfma_wgrad_bn_fits(const plyolo_conv_desc* d, int act) {
+  if (d->dtype != PLYOLO_BF16 || d->ksize != 3 || d->stride != 1 || act != PLYOLO_ACT_SILU || d->x_coef) return 0;
+  if (getenv("PLYOLO_WG3") && atoi(getenv("PLYOLO_WG3")) == 0) return 0;
+  const WgPlan w = plan_wgrad(d);
+  if (!((w.id == 2 || w.id == 3) && w.th == 16 && w.trs == 1)) return 0;
+  return ((double)d->H * d->W * d->x_ld * 2.0 < 2.0e9 && (double)w.p.OH * w.p.OW * d->y_ld * 2.0 < 2.0e9) ? 1 : 0;
+}
+
+// the weight gradient of a unit behind plyolo_bn_act_bwd_reduce with the unit's bn_act_bwd_dz in its loader (f->dz is ignored):
+// same slabs as plyolo_bn_act_bwd_dz + plyolo_conv2d_wgrad, bit for bit; dgamma / dbeta are written by workgroup 0
+int conv_mfma_wgrad_bn(const plyolo_conv_desc* d, const plyolo_bn_bwd_fuse* f, const void* x, float* dwp, void* stream) {
+  WgPlan w = plan_wgrad(d);
+  WgP p = w.p;
+  p.x = (const bf16_t*)x;
+  p.dy = (const bf16_t*)f->dout;
+  p.dy_ld = f->dout_ld;
+  p.dw = dwp;
+  p.bz = (const bf16_t*)f->z; p.bz_ld = f->z_ld;
+  p.bcoef = f->coef; p.bslots = f->bslots;
+  p.bgamma = f->gamma; p.bdgamma = f->dgamma; p.bdbeta = f->dbeta;
+  p.bcount = (double)d->N * p.OH * p.OW;
+  const int id = w.id, S = w.S;
+  {
+    char lab[64];
+    snprintf(lab, sizeof(lab), "conv_wgrad_bn<%dx%d,k3>", w.CO_T, w.CI_T);
+    const double Mo = (double)p.N * p.OH * p.OW, Mi = (double)p.N * p.H * p.W;
+    annotate(lab, 2.0 * Mo * d->Cout * d->Cin * 9.0, (2.0 * Mo * d->Cout + Mi * d->Cin) * 2.0 + 4.0 * 9.0 * d->Cout * d->Cin);
+  }
+  return submit(stream, [=](hipStream_t s) -> hipError_t {
+    if (id == 3) return launch_wg3_bnb<32, 32, 4, 16>(p, S, s);
+    return launch_wg3_bnb<64, 32, 2, 16>(p, S, s);
   });
 }
 

@@ -125,6 +125,8 @@ class Graph:
         # to plyolo_conv2d_bwd_pw it takes the remaining small-map pointwise units: 15 launches and ~0.4 GB less, 8.66 vs 8.69 / 8.63
         # vs 8.66 ms -- on by default
         self.fuse_bnbwd = os.environ.get("PLYOLO_FUSE_BNBWD", "1") == "1"
+        # units without a data gradient (the first convolution): dz formed in the weight gradient's loader (plyolo_conv2d_wgrad_bn)
+        self.fuse_wgbn = os.environ.get("PLYOLO_FUSE_WGBN", "1") == "1" and training and dtype == BF16
         self.fwd_res_in_dz = os.environ.get("PLYOLO_RES_IN_DZ", "1") == "1"    # A/B switch: 0 = a copy_add launch per shortcut
         # PLYOLO_FUSE_PWBWD (default on, round 4): the whole backward of a large-map pointwise unit behind its BatchNorm reduction --
         # dz, data gradient and weight gradient -- is ONE persistent launch (plyolo_conv2d_bwd_pw): dout, z and x are read once, dz
@@ -1007,6 +1009,24 @@ class ConvUnitOp:
                 return
             # pointwise units: dz is formed inside the data gradient's loader (one launch and one pass over dout / z less)
             fused = g.fuse_bnbwd and self.need_dgrad and _lib.lib().plyolo_conv2d_dgrad_bn_fits(C.byref(self.desc_d), self.act) == 1
+            # no data gradient at all (the first convolution): dz is only read by the weight gradient -- formed in ITS loader
+            wg_bn = (g.fuse_wgbn and not self.need_dgrad and self.res is None
+                     and _lib.lib().plyolo_conv2d_wgrad_bn_fits(C.byref(self.desc), self.act) == 1)
+            if wg_bn:
+                f = BnBwdFuse()
+                f.dout, f.dout_ld, f.z, f.z_ld, f.coef, f.bslots = dout, self.out.ld, zt, Cout, self.coef.data_ptr(), bslots
+                f.gamma, f.dgamma, f.dbeta = ptr(bn.weight), g.grad_ptr_of(bn.weight), g.grad_ptr_of(bn.bias)
+                f.act = self.act
+                self.keep_f = f
+
+                def wgrad_bn():
+                    call("plyolo_conv2d_wgrad_bn", C.byref(self.desc), C.byref(f), self.xptr, self.pc.dwp, None)
+                    self.pc.reduce_slabs()
+                if lanes:
+                    g.defer_param_grads(me, wgrad_bn)
+                else:
+                    wgrad_bn()
+                return
             if fused:
                 f = BnBwdFuse()
                 f.dout, f.dout_ld, f.z, f.z_ld, f.coef, f.bslots = dout, self.out.ld, zt, Cout, self.coef.data_ptr(), bslots

@@ -427,6 +427,59 @@ def test_pointwise_unit_backward_in_one_launch(shape, act, grid, monkeypatch):
 
 # (N, H, W, Cin, Cout, k, s, segments of dx channels): data gradients whose store loop folds the BatchNorm-backward reduction of the
 # upstream unit(s); two segments = a concatenated input (one BatchNorm unit per part), a gap = a part without a BatchNorm unit
+@pytest.mark.parametrize("shape", [(2, 48, 40, 16, 32), (3, 37, 45, 24, 64), (1, 160, 160, 16, 32), (2, 21, 19, 8, 24), (1, 64, 64, 32, 40)], ids=str)
+def test_weight_gradient_with_bn_backward_in_its_loader(shape):
+    """plyolo_conv2d_wgrad_bn == plyolo_bn_act_bwd_dz + plyolo_conv2d_wgrad (a unit without a data gradient: its dz is read by the weight
+    gradient only): the folded weight gradient, dgamma and dbeta bit for bit -- the loader forms the same bf16 dz values the separate
+    pass would have written, absent pixels of ragged tiles stage zeros -- both slab shapes, odd maps, channel tails."""
+    from pl_yolo_amd._lib import ACT, BnBwdFuse, STAT_SLOTS
+    N, H, W, Cin, Cout = shape
+    dt, a = BF16, ACT["silu"]
+    torch.manual_seed(sum(shape) + 3)
+    dev = hu.DEV
+    M = N * H * W
+    x_ld, d_ld = (Cin + 7) // 8 * 8, (Cout + 7) // 8 * 8 + 8
+    w = hu.rnd_bf16(torch.randn(Cout, Cin, 3, 3, device=dev) / (Cin * 9) ** 0.5)
+    xm = torch.zeros(M, x_ld, device=dev)
+    xm[:, :Cin] = torch.randn(M, Cin, device=dev)
+    xm = xm.to(torch.bfloat16)
+    z = (torch.randn(M, Cout, device=dev) * 1.5).to(torch.bfloat16)
+    dout = torch.zeros(M, d_ld, device=dev)
+    dout[:, :Cout] = torch.randn(M, Cout, device=dev)
+    dout = dout.to(torch.bfloat16)
+    mean, var = z.float().mean(0), z.float().var(0, unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-3)
+    gamma = (torch.rand(Cout, device=dev) + 0.5).contiguous()
+    beta = (torch.randn(Cout, device=dev) * 0.2).contiguous()
+    coef = torch.cat([gamma * invstd, beta - mean * gamma * invstd, mean, invstd]).contiguous()
+    d = hu.conv_desc(dt, N, H, W, Cin, Cout, 3, 1, x_ld, Cout)
+    assert hu._lib.lib().plyolo_conv2d_wgrad_bn_fits(C.byref(d), a) == 1
+    bslots = torch.zeros(STAT_SLOTS * 2 * Cout, dtype=torch.float64, device=dev)
+    call("plyolo_bn_act_bwd_reduce", dt, M, Cout, dout.data_ptr(), d_ld, z.data_ptr(), Cout, coef.data_ptr(), a, bslots.data_ptr(), None, hu.stream())
+    # separate launches
+    dz0 = torch.empty(M, Cout, dtype=torch.bfloat16, device=dev)
+    dg0, db0 = torch.zeros(Cout, device=dev), torch.zeros(Cout, device=dev)
+    call("plyolo_bn_act_bwd_dz", dt, M, Cout, dout.data_ptr(), d_ld, z.data_ptr(), Cout, coef.data_ptr(), bslots.data_ptr(), gamma.data_ptr(),
+         dg0.data_ptr(), db0.data_ptr(), 0, a, dz0.data_ptr(), Cout, None, None, hu.stream())
+    pk0 = hu.Packed(w, dt)
+    pk0.set_slabs(d)
+    call("plyolo_conv2d_wgrad", C.byref(d), xm.data_ptr(), dz0.data_ptr(), pk0.dwp.data_ptr(), hu.stream())
+    dw0 = pk0.unpack().clone()
+    # one launch
+    dg1, db1 = torch.full((Cout,), 7.0, device=dev), torch.full((Cout,), 7.0, device=dev)
+    f = BnBwdFuse()
+    f.dout, f.dout_ld, f.z, f.z_ld, f.coef, f.bslots = dout.data_ptr(), d_ld, z.data_ptr(), Cout, coef.data_ptr(), bslots.data_ptr()
+    f.gamma, f.dgamma, f.dbeta, f.act = gamma.data_ptr(), dg1.data_ptr(), db1.data_ptr(), a
+    pk1 = hu.Packed(w, dt)
+    pk1.set_slabs(d)
+    call("plyolo_conv2d_wgrad_bn", C.byref(d), C.byref(f), xm.data_ptr(), pk1.dwp.data_ptr(), hu.stream())
+    dw1 = pk1.unpack().clone()
+    torch.cuda.synchronize()
+    assert float(dw0.abs().max()) > 0
+    assert torch.equal(dw0, dw1), "weight gradient differs: max %.3e" % float((dw0 - dw1).abs().max())
+    assert torch.equal(dg0, dg1) and torch.equal(db0, db1)
+
+
 @pytest.mark.parametrize("shape", [(2, 32, 32, 64, 128, 3, 2), (1, 64, 64, 32, 64, 3, 2), (2, 26, 38, 128, 256, 3, 2), (3, 17, 23, 24, 40, 3, 2),
                                    (2, 21, 30, 96, 72, 3, 2), (1, 160, 160, 32, 64, 3, 2)], ids=str)
 @pytest.mark.parametrize("acc", [0, 1])
