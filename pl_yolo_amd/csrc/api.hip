@@ -516,7 +516,7 @@ static int check_red(const plyolo_bn_red* r, const plyolo_conv_desc* d, const ch
     const plyolo_bn_red_seg& g = r->seg[k];
     PLY_CHECK_ARG(g.c0 >= 0 && g.c1 > g.c0 && g.c1 <= d->Cin && g.c0 % 8 == 0 && g.c1 % 8 == 0, "%s: segment %d: channels [%d, %d) must be multiples of 8 inside [0, Cin)", who, k, g.c0, g.c1);
     PLY_CHECK_ARG(g.z && g.coef && g.bslots && g.z_ld % 8 == 0 && g.z_ld >= g.c1 - g.c0 && g.coef_ld >= g.c1 - g.c0 && g.slot_ld >= g.c1 - g.c0, "%s: segment %d: incomplete", who, k);
-    PLY_CHECK_ARG(g.act >= PLYOLO_ACT_NONE && g.act <= PLYOLO_ACT_GELU, "%s: segment %d: bad activation", who, k);
+    PLY_CHECK_ARG(g.act >= PLYOLO_ACT_NONE && g.act <= PLYOLO_ACT_LRELU, "%s: segment %d: the folded reduction carries none / silu / relu / lrelu (hswish and gelu units keep plyolo_bn_act_bwd_reduce)", who, k);
     for (int j = 0; j < k; ++j) PLY_CHECK_ARG(g.c0 >= r->seg[j].c1 || g.c1 <= r->seg[j].c0, "%s: segments %d and %d overlap", who, j, k);
   }
   return 0;

@@ -39,6 +39,22 @@ DEVINL void bnred_init(BnRedThread& t, const plyolo_bn_red& r, const int co) {
 
 DEVINL u32x4 bnred_load(const BnRedThread& t, const size_t pix) { return *(const u32x4*)(t.z + pix * t.z_ld); }
 
+// derivative of the activations a folded reduction carries (== act_grad<false> for them).  hswish / gelu stay out: this runs in the
+// unrolled store loops of the convolution kernels, 8 rows x 8 channels per thread, and the erff expansion in every element of a
+// run-time switch made the 128-channel pointwise RED instance 15 k instructions long (61 KB: the instruction cache of a CU pair)
+// although no shipped config ever takes that branch; such units keep their plyolo_bn_act_bwd_reduce launch (api.hip: check_red)
+DEVINL float bnred_act_grad(const float u, const int act) {
+  switch (act) {
+    case PLYOLO_ACT_SILU: {
+      const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-u));
+      return s * (1.0f + u * (1.0f - s));
+    }
+    case PLYOLO_ACT_RELU: return u > 0.f ? 1.f : 0.f;
+    case PLYOLO_ACT_LRELU: return u > 0.f ? 1.f : 0.1f;
+    default: return 1.f;
+  }
+}
+
 // dx = the stored (bf16-rounded) gradient vector, zz = the unit's z at the same pixel and channels
 template <int ACT>
 DEVINL void bnred_add(BnRedThread& t, const u32x4 dx, const u32x4 zz) {
@@ -46,8 +62,8 @@ DEVINL void bnred_add(BnRedThread& t, const u32x4 dx, const u32x4 zz) {
   for (int i = 0; i < 4; ++i) {
     const float zl = __uint_as_float(zz[i] << 16), zh = __uint_as_float(zz[i] & 0xffff0000u);
     const float dl = __uint_as_float(dx[i] << 16), dh = __uint_as_float(dx[i] & 0xffff0000u);
-    const float dul = dl * act_grad<false>(fmaf(zl, t.sc[2 * i], t.sh[2 * i]), ACT >= 0 ? ACT : t.act);
-    const float duh = dh * act_grad<false>(fmaf(zh, t.sc[2 * i + 1], t.sh[2 * i + 1]), ACT >= 0 ? ACT : t.act);
+    const float dul = dl * bnred_act_grad(fmaf(zl, t.sc[2 * i], t.sh[2 * i]), ACT >= 0 ? ACT : t.act);
+    const float duh = dh * bnred_act_grad(fmaf(zh, t.sc[2 * i + 1], t.sh[2 * i + 1]), ACT >= 0 ? ACT : t.act);
     t.s1[2 * i] += dul;
     t.s1[2 * i + 1] += duh;
     t.s2[2 * i] += dul * ((zl - t.mu[2 * i]) * t.is[2 * i]);

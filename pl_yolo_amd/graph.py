@@ -291,6 +291,8 @@ class Graph:
         lib = _lib.lib()
         views = []     # (unit, Act view, channel offset inside the unit)
         for op in self.ops:
+            if op.__class__ in (ConvUnitOp, ConvPairOp) and op.act > ACT["lrelu"]:
+                continue       # hswish / gelu units keep their reduce launch (the folded form carries the three cheap activations only)
             if isinstance(op, ConvUnitOp) and op.bn is not None and op.conv_b is None and hasattr(op, "coef"):
                 views.append((op, op.out, 0))
             elif isinstance(op, ConvPairOp) and hasattr(op, "coef"):
