@@ -452,8 +452,8 @@ int plyolo_conv2d_wgrad_bn(const plyolo_conv_desc* d, const plyolo_bn_bwd_fuse* 
  * reads dx and z_U again.  Up to PLYOLO_BN_RED_SEGS channel segments [c0, c1) of dx (a concatenated input: one segment per
  * producing unit; a segment without a BatchNorm unit is simply left out); every pointer is pre-offset to the segment's first
  * channel; z [M][..] pitch z_ld; coef rows (scale | shift | mean | invstd) coef_ld apart; bslots [PLYOLO_STAT_SLOTS][2][slot_ld]
- * of the unit (slot_ld = its channel count).  c0 / c1 multiples of 8.  The caller zeroes bslots, and must be the LAST writer of
- * those dx channels. */
+ * of the unit (slot_ld = its channel count).  c0 / c1 multiples of 8.  act: none / silu / relu / lrelu (a hswish or gelu unit keeps
+ * its plyolo_bn_act_bwd_reduce launch).  The caller zeroes bslots, and must be the LAST writer of those dx channels. */
 #define PLYOLO_BN_RED_SEGS 3
 typedef struct plyolo_bn_red_seg {
   int c0, c1;
