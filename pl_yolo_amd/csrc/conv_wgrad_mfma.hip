@@ -671,6 +671,8 @@ hipError_t launch_wg(const WgP& p, int S, hipStream_t s) {
 
 namespace plyolo {
 
+hipError_t conv_wgrad1_launch(const void* x, const void* dz, float* dw, int M, int Cout, int Cin, int x_ld, int dz_ld, int G, hipStream_t s);   // conv_wgrad1.hip
+
 struct WgPlan { WgP p; int id, S, WK, CO_T, CI_T, th, trs; };
 
 static WgPlan plan_wgrad(const plyolo_conv_desc* d) {
@@ -782,6 +784,20 @@ int conv_mfma_wgrad(const plyolo_conv_desc* d, const void* x, const void* dy, fl
     const double Mo = (double)p.N * p.OH * p.OW, Mi = (double)p.N * p.H * p.W;
     annotate(lab, 2.0 * Mo * d->Cout * d->Cin * ks * ks, (Mo * d->Cout + Mi * d->Cin) * 2.0 + 4.0 * ks * ks * d->Cout * d->Cin);
   }
+#ifdef PLYOLO_OPTIN
+  // 1x1 stride 1 with 128+ channels on both sides: the persistent streaming kernel (conv_wgrad1.hip), opt-in (make OPTIN=1,
+  // PLYOLO_WG1=1).  Round 4, same box: its launches are 28 % shorter (24 launches of YOLOX-s 0.631 -> 0.455 ms, 1.5 -> 2.1 TB/s) and
+  // the step is LONGER -- YOLOX-s 8.548 vs 8.498 ms, YOLOX-x 1280 98.6 vs 97.5, YOLOX-l 16.79 vs 16.86: the weight-gradient lane is
+  // not the critical one, and a launch that streams harder takes HBM bandwidth from the data-gradient chain beside it
+  {
+    const int wg1 = getenv("PLYOLO_WG1") ? atoi(getenv("PLYOLO_WG1")) : 0;
+    if (wg1 && id == 5 && !p.pre && !p.ablate) {
+      const int M = d->N * d->H * d->W, cout = d->Cout, cin = d->Cin, xl = d->x_ld, yl = d->y_ld;
+      const void* xp = x; const void* dyp = dy;
+      return submit(stream, [=](hipStream_t s) -> hipError_t { return conv_wgrad1_launch(xp, dyp, dwp, M, cout, cin, xl, yl, S, s); });
+    }
+  }
+#endif
   // 3x3, unsplit: the round-2 kernel with the tile pipeline inside the MFMA phase (PLYOLO_WG3=0: the phase-alternating kernel);
   // its buffer descriptors address one image with 31-bit offsets
   static const int wg3_env = getenv("PLYOLO_WG3") ? atoi(getenv("PLYOLO_WG3")) : 1;
