@@ -20,6 +20,7 @@
 // the 1/2/2/4 taps that reach that class (so no zero-stuffing and no atomics).
 
 
+#define PLYOLO_CONV_PD 2   // forward instances: weight fragments two taps ahead (see the A/B in profiles/r04_ab_fusions.txt)
 #include "conv_mfma_body.h"
 
 namespace plyolo {

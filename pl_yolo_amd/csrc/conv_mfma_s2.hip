@@ -4,6 +4,7 @@
 // of the same maps: their 17 x 33 halo tile took the index-arithmetic loader (two exposed memory round trips per 32-channel chunk,
 // no double buffer) and every fragment read hit LDS 2-way conflicted (pixels two columns apart).  Own translation unit: co-compiled
 // template instances perturb each other's code (see conv_mfma_body.h).
+#define PLYOLO_CONV_PD 2   // forward instances: weight fragments two taps ahead (see the A/B in profiles/r04_ab_fusions.txt)
 #include "conv_mfma_body.h"
 
 namespace {
