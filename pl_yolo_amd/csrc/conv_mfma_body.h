@@ -167,7 +167,9 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
   const unsigned wtapB = (unsigned)p.nnb * (unsigned)p.nkb * 1024u;
 
   // weight fragments in flight: PD taps ahead.  PD = 2 on the 32-channel double-buffered variant (a tap there is only
-  // 256 cycles of MFMA) measured 1.5 % SLOWER on the whole step (+8 VGPRs, same occupancy), so one tap it stays
+  // 256 cycles of MFMA) measured 1.5 % SLOWER on the whole step in round 2 (+8 VGPRs, same occupancy); round 4: launches 2-5 %
+  // shorter, step unchanged when every instance has it, -0.03 ms when only the FORWARD translation units do (conv_mfma.hip,
+  // conv_mfma_s2.hip define PLYOLO_CONV_PD 2: the forward has no co-runner whose share of the CU the extra registers cost)
 #ifndef PLYOLO_CONV_PD
 #define PLYOLO_CONV_PD 1
 #endif
