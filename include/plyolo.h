@@ -399,13 +399,14 @@ int plyolo_bn_act_bwd_dz(int dtype, int M, int C, const void* dout, int d_ld, co
                          float* dbeta, int accumulate, int act, void* dz, int dz_ld,
                          const plyolo_split* dout_split, const plyolo_bn_bwd_split* par2, void* stream);
 
-/* Data gradient of a POINTWISE (1x1, stride 1) BaseConv unit with the unit's own BatchNorm + activation backward fused in:
+/* Data gradient of a POINTWISE (1x1, stride 1) or -- round 5 -- 3x3 stride-1 BaseConv unit with the unit's own BatchNorm + activation backward fused in:
  * what autograd does for act(bn(conv(x))) between the gradient of the activated output and dx (network_blocks.py:30-37).
  * The rows of dz = plyolo_bn_act_bwd_dz(dout, z) are formed while they are staged for the matrix cores -- dout and z are read
  * once, dz is written once (for plyolo_conv2d_wgrad) and never read back by this path, dx (+)= dz . W.  Bit-identical to the
  * two separate launches.  bslots must hold the sums of plyolo_bn_act_bwd_reduce; dgamma / dbeta are written (not accumulated).
  * plyolo_conv2d_dgrad_bn_fits: 1 if the unit is covered (bf16, 1x1 stride 1, act none/silu/relu/lrelu, Cout % 8 == 0, Cin spans
- * at most two output blocks of the kernel), else 0. */
+ * at most two output blocks of the kernel; or 3x3 stride 1, SiLU, Cout % 8 == 0, Cout <= 512, tiles with a loader instance --
+ * csrc/conv_mfma_bnb.hip: the halo tile is requested as (dout, z) pairs and staged as dz, padding stays zero), else 0. */
 typedef struct plyolo_bn_bwd_fuse {
   const void* dout; int dout_ld;        /* gradient of the activated output [M][Cout] */
   const void* dout2; int dout2_ld;      /* merged pairs: channels [dout_split, Cout) live here (NULL: one matrix) */
@@ -417,7 +418,9 @@ typedef struct plyolo_bn_bwd_fuse {
   int par_split;                        /* merged pairs: parameters of channels >= par_split come from the second set (0: none) */
   const float* gamma2; float* dgamma2; float* dbeta2;
   int act;
-  void* dz; int dz_ld;                  /* out: [M][Cout] */
+  void* dz; int dz_ld;                  /* out: [M][Cout] (3x3 units: may be NULL when nothing reads dz) */
+  void* fwd_to; int fwd_ld;             /* 3x3 units only, optional: dout is also COPIED here (the Bottleneck shortcut's share of the
+                                         * gradient, network_blocks.py:89-90, when this unit is its first writer); NULL: not forwarded */
 } plyolo_bn_bwd_fuse;
 int plyolo_conv2d_dgrad_bn_fits(const plyolo_conv_desc* d, int act);
 int plyolo_conv2d_dgrad_bn(const plyolo_conv_desc* d, const plyolo_bn_bwd_fuse* f, const void* wpd, void* dx,

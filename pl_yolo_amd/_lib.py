@@ -53,7 +53,7 @@ class BnBwdFuse(C.Structure):      # plyolo_bn_bwd_fuse
                 ("z", C.c_void_p), ("z_ld", C.c_int), ("coef", C.c_void_p), ("bslots", C.c_void_p),
                 ("gamma", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("par_split", C.c_int),
                 ("gamma2", C.c_void_p), ("dgamma2", C.c_void_p), ("dbeta2", C.c_void_p), ("act", C.c_int),
-                ("dz", C.c_void_p), ("dz_ld", C.c_int)]
+                ("dz", C.c_void_p), ("dz_ld", C.c_int), ("fwd_to", C.c_void_p), ("fwd_ld", C.c_int)]
 
 
 class BnRedSeg(C.Structure):       # plyolo_bn_red_seg

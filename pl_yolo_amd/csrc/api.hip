@@ -56,6 +56,8 @@ int conv_mfma_fwd(const plyolo_conv_desc*, const void*, const void*, const float
 void conv_mfma_pack_elems(int Cout_total, int Cin_p, int ksize, size_t* wp, size_t* wpd);
 int conv_mfma_dgrad(const plyolo_conv_desc*, const void*, const void*, void*, int, const plyolo_bn_red*, void*, int*);
 int conv_mfma_dgrad_red_fits(const plyolo_conv_desc*);
+int conv_mfma_dgrad_bn_fits(const plyolo_conv_desc*, int);
+int conv_mfma_dgrad_bn(const plyolo_conv_desc*, const plyolo_bn_bwd_fuse*, const void*, void*, int, const plyolo_bn_red*, void*);
 int conv_mfma_wgrad(const plyolo_conv_desc*, const void*, const void*, float*, void*);
 int conv_mfma_wgrad_slabs(const plyolo_conv_desc*);
 int conv_mfma_wgrad_bn_fits(const plyolo_conv_desc*, int);
@@ -540,6 +542,7 @@ int plyolo_conv2d_dgrad_red(const plyolo_conv_desc* d, const void* dy, const voi
 }
 int plyolo_conv2d_dgrad_bn_fits(const plyolo_conv_desc* d, int act) {
   if (check_conv(d, "conv2d_dgrad_bn_fits", false)) return -1;
+  if (d->ksize == 3) return conv_mfma_dgrad_bn_fits(d, act);
   return conv_pw_dgrad_bn_fits(d, act);
 }
 int plyolo_conv2d_dgrad_bn(const plyolo_conv_desc* d, const plyolo_bn_bwd_fuse* f, const void* wpd, void* dx, int accumulate, void* stream) {
@@ -549,7 +552,16 @@ int plyolo_conv2d_dgrad_bn_red(const plyolo_conv_desc* d, const plyolo_bn_bwd_fu
                                const plyolo_bn_red* red, void* stream) {
   if (check_conv(d, "conv2d_dgrad_bn", false)) return -1;
   if (red && red->n > 0 && check_red(red, d, "conv2d_dgrad_bn_red")) return -1;
-  PLY_CHECK_ARG(f && f->dout && f->z && f->coef && f->bslots && f->dz, "conv2d_dgrad_bn: incomplete plyolo_bn_bwd_fuse");
+  PLY_CHECK_ARG(f && f->dout && f->z && f->coef && f->bslots && (f->dz || d->ksize == 3), "conv2d_dgrad_bn: incomplete plyolo_bn_bwd_fuse");
+  if (d->ksize == 3) {
+    PLY_CHECK_ARG(conv_mfma_dgrad_bn_fits(d, f->act) == 1, "conv2d_dgrad_bn: this 3x3 unit is not covered (ask plyolo_conv2d_dgrad_bn_fits; use plyolo_bn_act_bwd_dz + plyolo_conv2d_dgrad)");
+    PLY_CHECK_ARG(f->dout_ld % 8 == 0 && f->z_ld % 8 == 0 && f->z_ld >= d->Cout && (!f->dz || (f->dz_ld % 8 == 0 && f->dz_ld >= d->Cout)) && (!f->fwd_to || (f->fwd_ld % 8 == 0 && f->fwd_ld >= d->Cout && !f->dout2)),
+                  "conv2d_dgrad_bn: pitches must be multiples of 8 and hold Cout channels (a forwarded gradient needs a single output-gradient matrix)");
+    PLY_CHECK_ARG(!f->dout2 || (f->dout_split > 0 && f->dout_split < d->Cout && f->dout_split % 32 == 0 && f->dout2_ld % 8 == 0), "conv2d_dgrad_bn: bad output-gradient split (3x3 units: a multiple of 32)");
+    PLY_CHECK_ARG(f->par_split == 0 || (f->par_split > 0 && f->par_split < d->Cout), "conv2d_dgrad_bn: bad parameter split");
+    PLY_CHECK_ARG(wpd && dx, "conv2d_dgrad_bn: null weights / dx");
+    return conv_mfma_dgrad_bn(d, f, wpd, dx, accumulate, red, stream);
+  }
   PLY_CHECK_ARG(conv_pw_dgrad_bn_fits(d, f->act) == 1, "conv2d_dgrad_bn: this unit is not covered (ask plyolo_conv2d_dgrad_bn_fits; use plyolo_bn_act_bwd_dz + plyolo_conv2d_dgrad)");
   PLY_CHECK_ARG(f->dout_ld % 8 == 0 && f->z_ld % 8 == 0 && f->dz_ld % 8 == 0 && f->dz_ld >= d->Cout && f->z_ld >= d->Cout, "conv2d_dgrad_bn: pitches must be multiples of 8 and hold Cout channels");
   PLY_CHECK_ARG(!f->dout2 || (f->dout_split > 0 && f->dout_split < d->Cout && f->dout_split % 8 == 0 && f->dout2_ld % 8 == 0), "conv2d_dgrad_bn: bad output-gradient split");

@@ -47,6 +47,9 @@ hipError_t conv_mfma_launch_t4(const void* convp, int BN, int red, hipStream_t s
 int conv_s2d_th(int BN);
 hipError_t conv_s2d_launch(const void* convp, int BN, int red, hipStream_t s);
 int conv_mfma_red_has(int BN, int CK, int TH, int jobs);
+// conv_mfma_bnb.hip: 3x3 stride-1 data gradients with the unit's BatchNorm + SiLU backward in the halo loader
+int conv_mfma_bnb_has(int BN, int CK, int TH, int multi_chunk);
+hipError_t conv_mfma_launch_bnb(const void* convp, int BN, int CK, int TH, hipStream_t s);
 hipError_t conv_mfma_launch_red(const void* convp, int BN, int CK, int TH, hipStream_t s);
 hipError_t conv_mfma_launch_jobs_red(const void* jobsp, int BN, int CK, int TH, hipStream_t s);
 }
@@ -456,6 +459,80 @@ int conv_mfma_dgrad(const plyolo_conv_desc* d, const void* dy, const void* wpd, 
   return submit(stream, [=](hipStream_t s) { return launch_jobs(jobs, bn, ck, th, s); });
 }
 
+
+// ---- 3x3 stride-1 data gradient with the unit's BatchNorm + SiLU backward in the halo loader (plyolo_conv2d_dgrad_bn, ksize 3)
+namespace {
+// the ConvP of the stride-1 data gradient (as conv_mfma_dgrad builds it) with its tiles chosen; false: no BNB instance runs these tiles
+bool setup_dgrad_bnb(const plyolo_conv_desc* d, ConvP& p, int* BN, int* CK, int* TH) {
+  const int Kc = (d->Cout + 7) & ~7;
+  p.N = d->N; p.H = d->H; p.W = d->W;      // (3x3, pad 1, stride 1: the output gradient has the input's extent)
+  p.Cin = Kc; p.Cout = d->Cin; p.x_ld = d->y_ld; p.y_ld = d->x_ld;
+  p.OHf = d->H; p.OWf = d->W;
+  p.nkb = (d->Cout + 15) / 16;
+  p.nnb = (d->Cin + 31) / 32;
+  p.si = 1;
+  p.OHt = p.OHf; p.OWt = p.OWf;
+  p.so = 1; p.oy_off = 0; p.ox_off = 0;
+  p.iy_off = -1; p.ix_off = -1;
+  p.ntaps = 9;
+  for (int dy_ = 0; dy_ < 3; ++dy_)
+    for (int dx_ = 0; dx_ < 3; ++dx_) {
+      const int t = dy_ * 3 + dx_;
+      p.tap_dy[t] = (signed char)dy_; p.tap_dx[t] = (signed char)dx_;
+      p.tap_w[t] = (signed char)((2 - dy_) * 3 + (2 - dx_));
+    }
+  finish(p, 3, 3, false, BN, CK, TH);
+  if (p.ablate || !p.db) return false;
+  if (use_t4(p, 3, *BN, *CK, *TH, true)) {
+    apply_tiles(p, 3, 3, 4);
+    *TH = 4;
+  }
+  return plyolo::conv_mfma_bnb_has(*BN, *CK, *TH, p.Cin > *CK ? 1 : 0) == 1;
+}
+}  // namespace
+
+// 1 when plyolo_conv2d_dgrad_bn covers this 3x3 unit: bf16, stride 1, SiLU, whole channel vectors, the per-channel table fits beside the
+// halo buffers (<= 512 channels), the tiles it runs have a BNB instance, dx spans at most PLYOLO_FUSE_BNBWD3_BLK (default 2) output
+// blocks (every block re-derives dz for the whole contraction length) and the output gradient is at most PLYOLO_FUSE_BNBWD3_MB
+int conv_mfma_dgrad_bn_fits(const plyolo_conv_desc* d, int act) {
+  if (d->dtype != PLYOLO_BF16 || d->ksize != 3 || d->stride != 1 || act != PLYOLO_ACT_SILU) return 0;
+  if (d->Cout % 8 != 0 || d->Cout > 512 || d->x_coef) return 0;
+  const double max_mb = getenv("PLYOLO_FUSE_BNBWD3_MB") ? atof(getenv("PLYOLO_FUSE_BNBWD3_MB")) : 1.0e9;
+  if ((double)d->N * d->H * d->W * d->Cout * 2.0 > max_mb * 1.0e6) return 0;
+  ConvP p{};
+  int BN, CK, TH;
+  if (!setup_dgrad_bnb(d, p, &BN, &CK, &TH)) return 0;
+  const int maxblk = getenv("PLYOLO_FUSE_BNBWD3_BLK") ? atoi(getenv("PLYOLO_FUSE_BNBWD3_BLK")) : 2;
+  return (d->Cin + BN - 1) / BN <= maxblk ? 1 : 0;
+}
+
+int conv_mfma_dgrad_bn(const plyolo_conv_desc* d, const plyolo_bn_bwd_fuse* f, const void* wpd, void* dx, int accumulate, const plyolo_bn_red* red,
+                       void* stream) {
+  ConvP p{};
+  p.x = (const bf16_t*)f->dout;
+  p.w = (const bf16_t*)wpd;
+  p.y = dx;
+  p.accumulate = accumulate;
+  int BN, CK, TH;
+  if (!setup_dgrad_bnb(d, p, &BN, &CK, &TH)) { set_error("conv_mfma_dgrad_bn: no BNB instance for this unit (ask plyolo_conv2d_dgrad_bn_fits)"); return -1; }
+  p.x_ld = f->dout_ld;
+  if (red && red->n > 0) p.red = *red;
+  p.bz = (const bf16_t*)f->z; p.bz_ld = f->z_ld;
+  p.bx2 = (const bf16_t*)f->dout2; p.bx2_ld = f->dout2_ld; p.bsplit = f->dout2 ? f->dout_split : 0;
+  p.bcoef = f->coef; p.bslots = f->bslots;
+  p.bgamma = f->gamma; p.bdgamma = f->dgamma; p.bdbeta = f->dbeta;
+  p.bpsplit = f->par_split; p.bgamma2 = f->gamma2; p.bdgamma2 = f->dgamma2; p.bdbeta2 = f->dbeta2;
+  p.bdz = (bf16_t*)f->dz; p.bdz_ld = f->dz_ld;
+  p.bfwd = (bf16_t*)f->fwd_to; p.bfwd_ld = f->fwd_ld;
+  {
+    char lab[64];
+    snprintf(lab, sizeof(lab), "conv_mfma_dgrad_bn<BN%d,CK%d,TH%d>%s", BN, CK, TH, p.red.n > 0 ? "+bnred" : "");
+    const double M = (double)d->N * d->H * d->W;
+    annotate(lab, 2.0 * M * d->Cout * d->Cin * 9.0,
+             (M * d->Cout * (2.0 + (f->dz ? 1.0 : 0.0) + (f->fwd_to ? 1.0 : 0.0)) + M * d->Cin * ((accumulate ? 2.0 : 1.0) + (p.red.n > 0 ? 1.0 : 0.0))) * 2.0);
+  }
+  return submit(stream, [=](hipStream_t s) { return conv_mfma_launch_bnb(&p, BN, CK, TH, s); });
+}
 
 // 1 when conv_mfma_dgrad(d, ..., red) has a RED instance for the tiles this data gradient runs on (asked with the launch's own
 // tile selection, nothing is submitted)

@@ -46,6 +46,24 @@ struct ConvP {
   unsigned int taps_hi;
   int ablate;  // diagnostics (PLYOLO_ABLATE): 1 skip epilogue, 4 reload no halo after chunk 0, 8 skip MFMA, 16 skip weight loads, 32 skip LDS fragment reads
   plyolo_bn_red red;  // RED instances (data gradients): BatchNorm-backward reduction of the unit(s) whose output gradient this launch completes
+  // BNB instances (plyolo_conv2d_dgrad_bn on a 3x3 unit, conv_mfma_bnb.hip): x is the gradient of the unit's ACTIVATED output (channels
+  // >= bsplit in a second matrix for merged pairs); the halo tile is staged as dz = A*du + B*z + Cc, du = x * act'(z*sc + sh) -- exactly
+  // bn_act_bwd_dz (bn.hip) --, padding stays 0, and the workgroups of output block 0 write the dz of their own tile's pixels once for
+  // the weight gradient (and forward the shortcut's share of x, bfwd)
+  const bf16_t* bz;      // raw conv output z of the unit, pitch bz_ld
+  int bz_ld;
+  const bf16_t* bx2;
+  int bx2_ld, bsplit;
+  const float* bcoef;    // (scale | shift | mean | invstd) [4][Cin] of the unit's forward
+  const double* bslots;  // fp64 backward stat slots [PLYOLO_STAT_SLOTS][2][Cin] (sum du, sum du*zhat)
+  const float *bgamma, *bgamma2;
+  float *bdgamma, *bdbeta, *bdgamma2, *bdbeta2;
+  int bpsplit;
+  bf16_t* bdz;           // out: dz [N*H*W][bdz_ld], or NULL (nothing reads it: the weight gradient forms its own)
+  int bdz_ld;
+  bf16_t* bfwd;          // out: x copied here (the Bottleneck shortcut's gradient, first writer), or NULL
+  int bfwd_ld;
+  int btab;              // LDS byte offset of the per-channel table (behind the halo buffers)
 };
 
 DEVINL unsigned tap_code(const ConvP& p, int t) {
@@ -99,9 +117,11 @@ DEVINL u32x4 pre_apply(u32x4 t, const float* __restrict__ pre, int pre_ld, int a
 // are neighbours in LDS again (pitch CK*2+16: conflict-free ds_read_b128; side by side as they lie in the image they are 2*pitch
 // apart and every read is 2-way conflicted).  Tap (dy, dx) reads region dx & 1 at column offset dx >> 1.
 // RED (conv_mfma_red.hip, data gradients): the store loop also folds the BatchNorm-backward reduction of the upstream unit(s) (bnred.h)
-template <int BN, int CK, int TH, bool OUT_F32, int ABL, bool DB = false, bool PRE = false, bool MF16 = false, bool S2 = false, bool RED = false>
+// BNB (conv_mfma_bnb.hip, 3x3 stride-1 data gradients of SiLU units): the halo loader takes (dout, z) pairs and stages dz (ConvP::bz ...)
+template <int BN, int CK, int TH, bool OUT_F32, int ABL, bool DB = false, bool PRE = false, bool MF16 = false, bool S2 = false, bool RED = false, bool BNB = false>
 DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
   static_assert(!RED || !OUT_F32, "RED instances store bf16 gradients");
+  static_assert(!BNB || (!OUT_F32 && !PRE && !S2), "BNB instances: stride-1 bf16 data gradients");
   static_assert(!MF16 || (CK == 32 && !OUT_F32 && !PRE && DB), "MF16 instances: 32-channel double-buffered bf16 tiles");
   static_assert(!S2 || (DB && !MF16 && !PRE && !OUT_F32), "S2 instances: double-buffered bf16 tiles");
   constexpr int BM = TH * TW;
@@ -220,6 +240,7 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
   const bf16_t* xn = p.x + (size_t)n * p.H * p.W * p.x_ld;
   const int cvt = tid % CV;                                // 256 % CV == 0: a thread always owns the same channel vector
   int goff[HVT], loff[HVT];
+  [[maybe_unused]] unsigned own = 0u;   // BNB: bit v = vector v is a pixel of this tile's own output rows / columns (its dz is written here)
   if (fastpath) {
 #pragma unroll
     for (int v = 0; v < HVT; ++v) {
@@ -231,7 +252,15 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
         const int iy = pix / p.ITW, ix = pix - iy * p.ITW;
         const int gy = iy0 + iy, gx = ix0 + ix;
         loff[v] = iy * p.rowp + (S2 ? ((ix & 1) ? 17 + (ix >> 1) : (ix >> 1)) : ix) * ROWB + cvt * 16;
-        if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) goff[v] = (gy * p.W + gx) * p.x_ld + cvt * 8;
+        if constexpr (BNB) {
+          // the pixel index: the loader addresses up to four matrices of different pitch with it
+          if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+            goff[v] = gy * p.W + gx;
+            if (gy >= oy0 && gy < oy0 + TH && gx >= ox0 && gx < ox0 + TW) own |= 1u << v;
+          }
+        } else {
+          if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) goff[v] = (gy * p.W + gx) * p.x_ld + cvt * 8;
+        }
       }
     }
   }
@@ -257,6 +286,107 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
 #pragma unroll
       for (int v = 0; v < HVT; ++v)
         if (loff[v] >= 0) *(u32x4*)(smem + boff + loff[v]) = (goff[v] >= 0 && cok) ? hv[v] : zero;
+    }
+  };
+  // ---- BNB loader: (dout, z) vector pairs -> dz.  Requests are unconditional like the plain loader's; the dz / shortcut stores
+  // are raw buffer stores whose offset is pushed out of range for the vectors that are not written (dropped by the hardware):
+  // no branch between the vector-memory instructions of the tap loop, the compiler's vmcnt bookkeeping stays exact
+  [[maybe_unused]] const size_t img = (size_t)n * p.H * p.W;
+  // every matrix of the loader is addressed through a per-image buffer descriptor (uniform) + a 32-bit byte offset per vector:
+  // out-of-image / out-of-range vectors get an offset beyond the descriptor's extent -- loads return zeros, stores are dropped
+  [[maybe_unused]] const unsigned ibytes = (unsigned)(p.H * p.W) * 2u;   // bytes of one image per channel of pitch
+  [[maybe_unused]] auto halo_load_bnb = [&](const int c0, u32x4* hv, u32x4* zv) {
+    if constexpr (BNB) {
+      const int c = c0 + cvt * 8;
+      const bool cok = c < p.Cin;
+      const bool second = p.bsplit > 0 && c0 >= p.bsplit;     // wave-uniform: the split is a multiple of the chunk (checked on the host)
+      const bf16_t* dbase = second ? p.bx2 + img * p.bx2_ld : xn;
+      const int dld = second ? p.bx2_ld : p.x_ld;
+      const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)dbase, 0, (int)(ibytes * (unsigned)dld), 0x00020000);
+      const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bz + img * p.bz_ld), 0, (int)(ibytes * (unsigned)p.bz_ld), 0x00020000);
+      const int cd2 = (second ? c - p.bsplit : c) * 2, dld2 = dld * 2, zld2 = p.bz_ld * 2;
+#pragma unroll
+      for (int v = 0; v < HVT; ++v) {
+        const bool ok = goff[v] >= 0 && cok;
+        hv[v] = __builtin_amdgcn_raw_buffer_load_b128(rd, ok ? goff[v] * dld2 + cd2 : (int)0x80000000, 0, 0);
+        zv[v] = __builtin_amdgcn_raw_buffer_load_b128(rz, ok ? goff[v] * zld2 + c * 2 : (int)0x80000000, 0, 0);
+      }
+    }
+  };
+  [[maybe_unused]] auto halo_store_bnb = [&](const int c0, const u32x4* hv, u32x4* zv, const int boff) {
+    if constexpr (BNB) {
+      const int c = c0 + cvt * 8;
+      const bool cok = c < p.Cin;
+      const u32x4 zero = {0u, 0u, 0u, 0u};
+      const float* tab = (const float*)(smem + p.btab);
+      const int Kp = p.Cin, cc = cok ? c : 0;
+      const bool wr = blockIdx.y == 0 && cok;
+      const __amdgpu_buffer_rsrc_t rdz = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bdz + img * p.bdz_ld), 0, p.bdz ? (int)(ibytes * (unsigned)p.bdz_ld) : 0, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rfw = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bfwd + img * p.bfwd_ld), 0, p.bfwd ? (int)(ibytes * (unsigned)p.bfwd_ld) : 0, 0x00020000);
+      // the shortcut's copy first: its data is the untouched request
+#pragma unroll
+      for (int v = 0; v < HVT; ++v) {
+        const bool w = wr && goff[v] >= 0 && ((own >> v) & 1u);
+        __builtin_amdgcn_raw_buffer_store_b128(hv[v], rfw, w ? (goff[v] * p.bfwd_ld + c) * 2 : (int)0x80000000, 0, 0);
+      }
+      // one channel PAIR (a dword of every vector) at a time, ten coefficients from the table per pair, results in place of the z
+      // vectors: the kernel sits at the three-waves-per-SIMD edge (whole-vector coefficient sets and a third register set spilled)
+      typedef __attribute__((ext_vector_type(2))) float f32x2;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f32x2 sc = *(const f32x2*)(tab + cc + 2 * i), sh = *(const f32x2*)(tab + Kp + cc + 2 * i), A = *(const f32x2*)(tab + 2 * Kp + cc + 2 * i),
+                    B = *(const f32x2*)(tab + 3 * Kp + cc + 2 * i), Cc = *(const f32x2*)(tab + 4 * Kp + cc + 2 * i);
+#pragma unroll
+        for (int v = 0; v < HVT; ++v) {
+          const unsigned zz = zv[v][i], dd = hv[v][i];
+          const float zl = __uint_as_float(zz << 16), zh = __uint_as_float(zz & 0xffff0000u);
+          const float dl = __uint_as_float(dd << 16), dh = __uint_as_float(dd & 0xffff0000u);
+          const float dul = dl * bnred_act_grad(fmaf(zl, sc[0], sh[0]), PLYOLO_ACT_SILU);
+          const float duh = dh * bnred_act_grad(fmaf(zh, sc[1], sh[1]), PLYOLO_ACT_SILU);
+          zv[v][i] = pack2bf(fmaf(A[0], dul, fmaf(B[0], zl, Cc[0])), fmaf(A[1], duh, fmaf(B[1], zh, Cc[1])));
+        }
+      }
+#pragma unroll
+      for (int v = 0; v < HVT; ++v) {
+        const bool ok = goff[v] >= 0 && cok;
+        if (loff[v] >= 0) *(u32x4*)(smem + boff + loff[v]) = ok ? zv[v] : zero;
+        const bool w = wr && ok && ((own >> v) & 1u);
+        __builtin_amdgcn_raw_buffer_store_b128(zv[v], rdz, w ? (goff[v] * p.bdz_ld + c) * 2 : (int)0x80000000, 0, 0);
+      }
+    }
+  };
+  // per-channel table (scale, shift, A, B, Cc) of the unit, built by every workgroup from the fp64 slots while its first halo
+  // vectors are in flight (conv_pw.hip does the same); tile 0 of output block 0 publishes dgamma / dbeta as bn_act_bwd_dz does
+  [[maybe_unused]] auto bnb_table = [&]() {
+    if constexpr (BNB) {
+      float* tab = (float*)(smem + p.btab);
+      const int Kp = p.Cin;
+      const double cnt = (double)p.N * p.H * p.W;
+      for (int ch = tid; ch < Kp; ch += 256) {
+        double su = 0.0, suz = 0.0;
+#pragma unroll
+        for (int sl = 0; sl < PLYOLO_STAT_SLOTS; ++sl) {
+          su += p.bslots[((size_t)sl * 2 + 0) * Kp + ch];
+          suz += p.bslots[((size_t)sl * 2 + 1) * Kp + ch];
+        }
+        const float mean = p.bcoef[2 * Kp + ch], invstd = p.bcoef[3 * Kp + ch];
+        const bool sec = p.bpsplit > 0 && ch >= p.bpsplit;
+        const int cp = sec ? ch - p.bpsplit : ch;
+        const float* gam = sec ? p.bgamma2 : p.bgamma;
+        const float A = (gam ? gam[cp] : 1.f) * invstd;
+        const float B = (float)(-(double)A * (suz / cnt) * (double)invstd);
+        tab[ch] = p.bcoef[ch];
+        tab[Kp + ch] = p.bcoef[Kp + ch];
+        tab[2 * Kp + ch] = A;
+        tab[3 * Kp + ch] = B;
+        tab[4 * Kp + ch] = (float)(-(double)A * (su / cnt) - (double)B * (double)mean);
+        if (tile == 0 && blockIdx.y == 0) {
+          float* db_ = sec ? p.bdbeta2 : p.bdbeta;
+          float* dg_ = sec ? p.bdgamma2 : p.bdgamma;
+          if (db_) db_[cp] = (float)su;
+          if (dg_) dg_[cp] = (float)suz;
+        }
+      }
     }
   };
   // generic loader (stride-2 forward tiles): batches of HV 16-byte loads in flight before the first LDS write
@@ -309,8 +439,34 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
     // of step kk are issued, so that no MFMA waits on a ds_read issued just before it
     if constexpr (MF16) {
       // two halves of HALF16 fragments: the second half's A fragments are requested from LDS before the first half's MFMAs
-      bf16x8 a16[HALF16], an16[HALF16];
       const bf16x8 b0 = *(const bf16x8*)&bq[0][0], b1 = *(const bf16x8*)&bq[0][1];
+      if constexpr (BNB && MT16 >= 8) {
+        // BNB instances with 8 fragments per wave hold the next chunk's (dout, z) vectors through the taps: the second half's A fragments are
+        // requested in QUARTERS behind the first MFMAs instead of as a second register set (16 VGPRs: the three-waves-per-SIMD edge)
+        constexpr int Q = HALF16 / 2;
+        bf16x8 a16[Q], an16[Q];
+#pragma unroll
+        for (int j = 0; j < Q; ++j) a16[j] = *(const bf16x8*)(smem + arow16[j] + toff);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (q < 3) {
+#pragma unroll
+            for (int j = 0; j < Q; ++j) an16[j] = *(const bf16x8*)(smem + arow16[(q + 1) * Q + j] + toff);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < Q; ++j) {
+            acc16[q * Q + j][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a16[j], b0, acc16[q * Q + j][0], 0, 0, 0);
+            acc16[q * Q + j][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a16[j], b1, acc16[q * Q + j][1], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (q < 3) {
+#pragma unroll
+            for (int j = 0; j < Q; ++j) a16[j] = an16[j];
+          }
+        }
+      } else {
+      bf16x8 a16[HALF16], an16[HALF16];
 #pragma unroll
       for (int j = 0; j < HALF16; ++j) a16[j] = *(const bf16x8*)(smem + arow16[j] + toff);
 #pragma unroll
@@ -330,6 +486,7 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
 #pragma unroll
           for (int j = 0; j < HALF16; ++j) a16[j] = an16[j];
         }
+      }
       }
 #pragma unroll
       for (int kk = 0; kk < KS; ++kk) {
@@ -380,15 +537,29 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
     // weights) and are written to the OTHER LDS buffer after the last tap.  One barrier per chunk, no exposed
     // global-load latency between chunks.
     u32x4 hv[HVT];
-    halo_load(0, hv);
-    halo_store(0, hv, 0);
+    [[maybe_unused]] u32x4 zv[BNB ? HVT : 1];
+    if constexpr (BNB) {
+      halo_load_bnb(0, hv, zv);
+      bnb_table();
+      __syncthreads();
+      halo_store_bnb(0, hv, zv, 0);
+    } else {
+      halo_load(0, hv);
+      halo_store(0, hv, 0);
+    }
     __syncthreads();
     for (int chunk = 0; chunk < nchunks; ++chunk) {
       const int boff = (chunk & 1) * p.bufsz;
       const int cnext = (chunk + 1) * CK;   // past Cin on the last chunk: every load collapses to the dummy address
-      run_tap(0, boff, [&]() { halo_load(cnext, hv); });
+      run_tap(0, boff, [&]() {
+        if constexpr (BNB) halo_load_bnb(cnext, hv, zv);
+        else halo_load(cnext, hv);
+      });
       for (int t = 1; t < p.ntaps; ++t) run_tap(t, boff, []() {});
-      if (chunk + 1 < nchunks) halo_store(cnext, hv, p.bufsz - boff);
+      if (chunk + 1 < nchunks) {
+        if constexpr (BNB) halo_store_bnb(cnext, hv, zv, p.bufsz - boff);
+        else halo_store(cnext, hv, p.bufsz - boff);
+      }
       __syncthreads();  // next buffer complete; every wave is done with this one
     }
   } else {
@@ -396,7 +567,15 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
       const int c0 = chunk * CK;
       __syncthreads();  // every wave is done reading the previous chunk's halo tile
       if (!(abl & 4) || chunk == 0) {
-        if (fastpath) {
+        if constexpr (BNB) {   // (the launcher only takes tiles the descriptor loader covers)
+          u32x4 hv[HVT], zv[HVT];
+          halo_load_bnb(c0, hv, zv);
+          if (chunk == 0) {
+            bnb_table();
+            __syncthreads();
+          }
+          halo_store_bnb(c0, hv, zv, 0);
+        } else if (fastpath) {
           u32x4 hv[HVT];
           halo_load(c0, hv);
           halo_store(c0, hv, 0);
@@ -621,9 +800,9 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
   }
 }
 
-template <int BN, int CK, int TH, bool OUT_F32, int ABL = 0, bool DB = false, bool PRE = false, bool MF16 = false, bool S2 = false, bool RED = false>
+template <int BN, int CK, int TH, bool OUT_F32, int ABL = 0, bool DB = false, bool PRE = false, bool MF16 = false, bool S2 = false, bool RED = false, bool BNB = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvP p) {
-  conv_mfma_body<BN, CK, TH, OUT_F32, ABL, DB, PRE, MF16, S2, RED>(p, (int)blockIdx.x, (int)gridDim.x);
+  conv_mfma_body<BN, CK, TH, OUT_F32, ABL, DB, PRE, MF16, S2, RED, BNB>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // MF16 instances (stride-1 tiles of 8 rows, 32-channel double-buffered chunks, bf16 output): launch with the wider pixel pitch

@@ -125,6 +125,9 @@ class Graph:
         # to plyolo_conv2d_bwd_pw it takes the remaining small-map pointwise units: 15 launches and ~0.4 GB less, 8.66 vs 8.69 / 8.63
         # vs 8.66 ms -- on by default
         self.fuse_bnbwd = os.environ.get("PLYOLO_FUSE_BNBWD", "1") == "1"
+        # PLYOLO_FUSE_BNBWD3 (default on, round 5): the same for the 3x3 stride-1 units -- the halo loader of their data gradient takes
+        # (dout, z) pairs and stages dz (csrc/conv_mfma_bnb.hip); the bn_act_bwd_dz launch of the unit leaves the data-gradient chain
+        self.fuse_bnbwd3 = os.environ.get("PLYOLO_FUSE_BNBWD3", "1") == "1" and dtype == BF16 and training
         # units without a data gradient (the first convolution): dz formed in the weight gradient's loader (plyolo_conv2d_wgrad_bn)
         self.fuse_wgbn = os.environ.get("PLYOLO_FUSE_WGBN", "1") == "1" and training and dtype == BF16
         self.fwd_res_in_dz = os.environ.get("PLYOLO_RES_IN_DZ", "1") == "1"    # A/B switch: 0 = a copy_add launch per shortcut
@@ -306,11 +309,11 @@ class Graph:
                     writes.append((op, op.res, False))
                 if op.need_dgrad:
                     ok = op.bn is not None and hasattr(op, "desc_d") and (bool(op.pw_slabs) or lib.plyolo_conv2d_dgrad_red_fits(C.byref(op.desc_d)) == 1)
-                    bnb = self.fuse_bnbwd and not op.pw_slabs and op.bn is not None and lib.plyolo_conv2d_dgrad_bn_fits(C.byref(op.desc_d), op.act) == 1
+                    bnb = not op.pw_slabs and op.bn is not None and hasattr(op, "desc_d") and self.dgrad_bn_fits(op.desc_d, op.act)
                     writes.append((op, op.x, ok or bnb))
             elif isinstance(op, ConvPairOp):
                 ok = hasattr(op, "desc_d") and (bool(op.pw_slabs) or lib.plyolo_conv2d_dgrad_red_fits(C.byref(op.desc_d)) == 1)
-                bnb = self.fuse_bnbwd and not op.pw_slabs and lib.plyolo_conv2d_dgrad_bn_fits(C.byref(op.desc_d), op.act) == 1
+                bnb = not op.pw_slabs and hasattr(op, "desc_d") and self.dgrad_bn_fits(op.desc_d, op.act) and (op.k != 3 or op.Ca % 32 == 0)
                 writes.append((op, op.x, ok or bnb))
             elif isinstance(op, HeadPredOp):
                 writes.append((op, op.reg_feat, lib.plyolo_conv2d_dgrad_red_fits(C.byref(op.dgrad_descs()[0])) == 1))
@@ -393,6 +396,13 @@ class Graph:
                 if last is None or id(last[0]) != opid or id(last[1]) != aid:
                     raise _lib.PlyoloError("plan_bn_red: the planned last writer of a unit's output gradient is not the recorded one "
                                            "(%s planned, %s recorded)" % (opid, type(last[0]).__name__ if last else None))
+
+    def dgrad_bn_fits(self, desc_d, act):
+        """True when the unit's dz is formed inside its data gradient's loader (plyolo_conv2d_dgrad_bn): pointwise units
+        (PLYOLO_FUSE_BNBWD) and 3x3 stride-1 units (PLYOLO_FUSE_BNBWD3)."""
+        if not (self.fuse_bnbwd3 if desc_d.ksize == 3 else self.fuse_bnbwd):
+            return False
+        return _lib.lib().plyolo_conv2d_dgrad_bn_fits(C.byref(desc_d), act) == 1
 
     def pw_bwd_slabs(self, desc, act, ok=True):
         """Private weight-gradient slabs of plyolo_conv2d_bwd_pw for this unit, or 0 when the unit keeps the separate
@@ -978,14 +988,15 @@ class ConvUnitOp:
         plan, lanes, me = g.plan, g.use_lanes, self.lane
         pw_one = bool(self.pw_slabs)          # dz + data gradient + weight gradient in one launch (plyolo_conv2d_bwd_pw)
         dz, key = (None, None) if pw_one else g.dz_buffer(self, M * Cout)
-        fused = False
         # the shortcut's share of the gradient (network_blocks.py:89-90): forwarded by the bn_act_bwd_dz pass that reads dout anyway;
         # units without that pass (no BatchNorm, fused pointwise path) copy it with a launch of its own
-        res_in_dz = (self.res is not None and bn is not None and g.fwd_res_in_dz and not pw_one
-                     and not (g.fuse_bnbwd and self.need_dgrad and _lib.lib().plyolo_conv2d_dgrad_bn_fits(C.byref(self.desc_d), self.act) == 1))
+        fused = bn is not None and not pw_one and self.need_dgrad and g.dgrad_bn_fits(self.desc_d, self.act)
+        res_in_dz = self.res is not None and bn is not None and g.fwd_res_in_dz and not pw_one and not fused
+        res_in_dgrad = False      # a fused 3x3 data gradient copies the shortcut's share while it reads dout (first writer only)
         if self.res is not None:
             acc_res = g.grad_mode(self.res)
-            if not res_in_dz:
+            res_in_dgrad = fused and self.k == 3 and acc_res == 0 and g.fwd_res_in_dz
+            if not (res_in_dz or res_in_dgrad):
                 call("plyolo_copy_add", g.dtype, M, Cout, dout, self.out.ld, g.gptr(self.res), self.res.ld, acc_res, None)
         if bn is None:
             # BaseConv(norm=None): out = act(z)  (ecmnet.py:158 Bottleneck.conv1) -> dz = dout * act'(z)
@@ -1009,8 +1020,7 @@ class ConvUnitOp:
                 else:
                     self.pc.reduce_slabs()
                 return
-            # pointwise units: dz is formed inside the data gradient's loader (one launch and one pass over dout / z less)
-            fused = g.fuse_bnbwd and self.need_dgrad and _lib.lib().plyolo_conv2d_dgrad_bn_fits(C.byref(self.desc_d), self.act) == 1
+            # pointwise and 3x3 stride-1 units: dz is formed inside the data gradient's loader (one launch and one pass over dout / z less)
             # no data gradient at all (the first convolution): dz is only read by the weight gradient -- formed in ITS loader
             wg_bn = (g.fuse_wgbn and not self.need_dgrad and self.res is None
                      and _lib.lib().plyolo_conv2d_wgrad_bn_fits(C.byref(self.desc), self.act) == 1)
@@ -1034,6 +1044,8 @@ class ConvUnitOp:
                 f.dout, f.dout_ld, f.z, f.z_ld, f.coef, f.bslots = dout, self.out.ld, zt, Cout, self.coef.data_ptr(), bslots
                 f.gamma, f.dgamma, f.dbeta = ptr(bn.weight), g.grad_ptr_of(bn.weight), g.grad_ptr_of(bn.bias)
                 f.act, f.dz, f.dz_ld = self.act, dz, Cout
+                if res_in_dgrad:
+                    f.fwd_to, f.fwd_ld = g.gptr(self.res), self.res.ld
                 self.keep_f = f
             else:
                 sp = None
@@ -1180,8 +1192,8 @@ class ConvPairOp:
                 self.pc.reduce_slabs()
             return
         dz, key = g.dz_buffer(self, M * Cout)
-        fused = g.fuse_bnbwd and _lib.lib().plyolo_conv2d_dgrad_bn_fits(C.byref(self.desc_d), self.act) == 1
-        if fused:    # pointwise pair (CSP conv1 || conv2): dz is formed inside the data gradient's loader
+        fused = g.dgrad_bn_fits(self.desc_d, self.act) and (self.k != 3 or self.Ca % 32 == 0)   # (3x3 loader: whole 32-channel chunks per matrix)
+        if fused:    # pair (CSP conv1 || conv2, the first 3x3 round of a head level): dz is formed inside the data gradient's loader
             f = BnBwdFuse()
             f.dout, f.dout_ld, f.dout2, f.dout2_ld, f.dout_split = g.gptr(self.out_a), self.out_a.ld, dsp.p2, dsp.ld2, self.Ca
             f.z, f.z_ld, f.coef, f.bslots = zt, Cout, self.coef.data_ptr(), bslots

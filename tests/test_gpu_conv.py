@@ -314,6 +314,112 @@ def test_pointwise_dgrad_with_fused_bn_backward(shape, act):
         assert float(dz1.float().abs().max()) > 0
 
 
+# (N, H, W, Cin, Cout, split, TH4 allowed): 3x3 stride-1 units, one per loader instance -- 128 / 64 / 32 channel blocks of dx, 8- and 4-row
+# tiles, one chunk and several, two output blocks (only block 0 writes dz), merged pairs (two output-gradient matrices), ragged maps
+BNB3_SHAPES = [(2, 20, 20, 128, 128, 0, 1), (2, 20, 20, 128, 128, 0, 0), (3, 24, 20, 64, 64, 0, 0), (3, 24, 20, 64, 64, 0, 1), (2, 40, 40, 256, 128, 0, 0),
+               (2, 40, 40, 128, 256, 128, 0), (1, 13, 29, 64, 96, 32, 1), (2, 48, 40, 32, 32, 0, 0), (2, 37, 45, 32, 64, 0, 0), (1, 21, 19, 24, 40, 0, 0)]
+
+
+@pytest.mark.parametrize("shape", BNB3_SHAPES, ids=str)
+def test_conv3x3_dgrad_with_fused_bn_backward(shape, monkeypatch):
+    """plyolo_conv2d_dgrad_bn on a 3x3 stride-1 SiLU unit == plyolo_bn_act_bwd_dz + plyolo_conv2d_dgrad (+ the shortcut's copy), bit for
+    bit: dz (written once, by the workgroups of output block 0), dx (overwrite and accumulate), dgamma, dbeta, the forwarded shortcut
+    gradient; padding pixels of the halo stage zeros (a zero dout would stage Cc); dz == NULL writes nothing; and with the
+    BatchNorm-backward reduction of the unit upstream folded into the same launch."""
+    from pl_yolo_amd._lib import ACT, BnBwdFuse, Split, BnBwdSplit, STAT_SLOTS, BnRed
+    N, H, W, Cin, Cout, split, t4 = shape
+    if not t4:
+        monkeypatch.setenv("PLYOLO_TH4_MAX_WG", "0")
+    dt, M = BF16, N * H * W
+    torch.manual_seed(sum(shape) + 11)
+    dev = hu.DEV
+    w = hu.rnd_bf16(torch.randn(Cout, Cin, 3, 3, device=dev) / (9 * Cout) ** 0.5)
+    pk = hu.Packed(w, dt)
+    z = (torch.randn(M, Cout, device=dev) * 1.5).to(torch.bfloat16)
+    Ca = split if split else Cout
+    d_ld = Ca + 8
+    dout = torch.randn(M, d_ld, device=dev).to(torch.bfloat16)
+    dout2 = torch.randn(M, Cout - Ca + 16, device=dev).to(torch.bfloat16) if split else None
+    gamma, gamma2 = torch.rand(Cout, device=dev) + 0.5, torch.rand(Cout, device=dev) + 0.5
+    mean, invstd = torch.randn(Cout, device=dev) * 0.1, torch.rand(Cout, device=dev) + 0.5
+    beta = torch.randn(Cout, device=dev) * 0.1
+    g_eff = torch.cat([gamma[:Ca], gamma2[:Cout - Ca]]) if split else gamma
+    scale = g_eff * invstd
+    coef = torch.cat([scale, beta - mean * scale, mean, invstd]).contiguous()
+    bslots = torch.zeros(STAT_SLOTS * 2 * Cout, dtype=torch.float64, device=dev)
+    sp = Split()
+    if split:
+        sp.split, sp.p2, sp.ld2 = Ca, dout2.data_ptr(), dout2.shape[1]
+    a = ACT["silu"]
+    call("plyolo_bn_act_bwd_reduce", dt, M, Cout, dout.data_ptr(), d_ld, z.data_ptr(), Cout, coef.data_ptr(), a, bslots.data_ptr(),
+         C.byref(sp) if split else None, hu.stream())
+    x_ld = Cin + 8
+    d = hu.conv_desc(dt, N, H, W, Cin, Cout, 3, 1, x_ld, Cout)
+    lib = hu._lib.lib()
+    assert lib.plyolo_conv2d_dgrad_bn_fits(C.byref(d), a) == 1
+    assert lib.plyolo_conv2d_dgrad_bn_fits(C.byref(d), ACT["lrelu"]) == 0      # the 3x3 loader carries SiLU only
+    base = torch.randn(M, x_ld, device=dev).to(torch.bfloat16)
+    fwd_ld = Cout + 24
+    for acc in (0, 1):
+        # reference: the separate launches
+        dz0 = torch.zeros(M, Cout, dtype=torch.bfloat16, device=dev)
+        dg0, db0, dg0b, db0b = (torch.zeros(Cout, device=dev) for _ in range(4))
+        p2 = BnBwdSplit()
+        if split:
+            p2.split, p2.gamma2, p2.dgamma2, p2.dbeta2 = Ca, gamma2.data_ptr(), dg0b.data_ptr(), db0b.data_ptr()
+        call("plyolo_bn_act_bwd_dz", dt, M, Cout, dout.data_ptr(), d_ld, z.data_ptr(), Cout, coef.data_ptr(), bslots.data_ptr(), gamma.data_ptr(),
+             dg0.data_ptr(), db0.data_ptr(), 0, a, dz0.data_ptr(), Cout, C.byref(sp) if split else None, C.byref(p2) if split else None, hu.stream())
+        dx0 = base.clone()
+        call("plyolo_conv2d_dgrad", C.byref(d), dz0.data_ptr(), pk.wpd.data_ptr(), dx0.data_ptr(), acc, hu.stream())
+        # fused
+        dz1 = torch.full((M, Cout), 7.0, dtype=torch.bfloat16, device=dev)
+        fw1 = torch.full((M, fwd_ld), 5.0, dtype=torch.bfloat16, device=dev)
+        dg1, db1, dg1b, db1b = (torch.zeros(Cout, device=dev) for _ in range(4))
+        f = BnBwdFuse()
+        f.dout, f.dout_ld, f.z, f.z_ld, f.coef, f.bslots = dout.data_ptr(), d_ld, z.data_ptr(), Cout, coef.data_ptr(), bslots.data_ptr()
+        if split:
+            f.dout2, f.dout2_ld, f.dout_split = dout2.data_ptr(), dout2.shape[1], Ca
+            f.par_split, f.gamma2, f.dgamma2, f.dbeta2 = Ca, gamma2.data_ptr(), dg1b.data_ptr(), db1b.data_ptr()
+        else:
+            f.fwd_to, f.fwd_ld = fw1.data_ptr(), fwd_ld
+        f.gamma, f.dgamma, f.dbeta, f.act, f.dz, f.dz_ld = gamma.data_ptr(), dg1.data_ptr(), db1.data_ptr(), a, dz1.data_ptr(), Cout
+        dx1 = base.clone()
+        call("plyolo_conv2d_dgrad_bn", C.byref(d), C.byref(f), pk.wpd.data_ptr(), dx1.data_ptr(), acc, hu.stream())
+        torch.cuda.synchronize()
+        assert torch.equal(dz0.view(torch.int16), dz1.view(torch.int16)), "dz differs"
+        assert torch.equal(dx0[:, :Cin].view(torch.int16), dx1[:, :Cin].view(torch.int16)), "dx differs"
+        assert torch.equal(dx1[:, Cin:], base[:, Cin:]), "pad columns of dx touched"
+        for u, v in ((dg0, dg1), (db0, db1), (dg0b, dg1b), (db0b, db1b)):
+            assert torch.equal(u, v)
+        assert float(dz1.float().abs().max()) > 0
+        if not split:
+            assert torch.equal(fw1[:, :Cout].view(torch.int16), dout[:, :Cout].view(torch.int16)), "forwarded shortcut gradient differs"
+            assert torch.all(fw1[:, Cout:].float() == 5.0)
+        # no dz reader: nothing is written there
+        f.dz, f.dz_ld, f.fwd_to, f.fwd_ld = None, 0, None, 0
+        dx2 = base.clone()
+        call("plyolo_conv2d_dgrad_bn", C.byref(d), C.byref(f), pk.wpd.data_ptr(), dx2.data_ptr(), acc, hu.stream())
+        # ... and with the reduction of the unit that produced x folded in (two segments with a gap when Cin allows)
+        f.dz, f.dz_ld = dz1.data_ptr(), Cout
+        zu = (torch.randn(M, Cin, device=dev) * 1.5).to(torch.bfloat16)
+        cu = torch.cat([torch.rand(Cin, device=dev) + 0.5, torch.randn(Cin, device=dev) * 0.2, torch.randn(Cin, device=dev) * 0.1, torch.rand(Cin, device=dev) + 0.5]).contiguous()
+        su = torch.zeros(STAT_SLOTS * 2 * Cin, dtype=torch.float64, device=dev)
+        red = BnRed()
+        red.n = 1
+        sg = red.seg[0]
+        sg.c0, sg.c1, sg.z, sg.z_ld, sg.coef, sg.coef_ld, sg.bslots, sg.slot_ld, sg.act = 0, Cin, zu.data_ptr(), Cin, cu.data_ptr(), Cin, su.data_ptr(), Cin, ACT["silu"]
+        dx3 = base.clone()
+        call("plyolo_conv2d_dgrad_bn_red", C.byref(d), C.byref(f), pk.wpd.data_ptr(), dx3.data_ptr(), acc, C.byref(red), hu.stream())
+        ref = torch.zeros(STAT_SLOTS * 2 * Cin, dtype=torch.float64, device=dev)
+        dxs = dx3[:, :Cin].contiguous()
+        call("plyolo_bn_act_bwd_reduce", dt, M, Cin, dxs.data_ptr(), Cin, zu.data_ptr(), Cin, cu.data_ptr(), ACT["silu"], ref.data_ptr(), None, hu.stream())
+        torch.cuda.synchronize()
+        assert torch.equal(dx2.view(torch.int16), dx1.view(torch.int16)), "dx differs without a dz reader"
+        assert torch.equal(dx3.view(torch.int16), dx1.view(torch.int16)), "dx differs with the folded reduction"
+        got, want = su.view(STAT_SLOTS, 2, Cin).sum(0), ref.view(STAT_SLOTS, 2, Cin).sum(0)
+        assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
+
+
 # (N, H, W, Cin, Cout, split): pointwise units of the shapes plyolo_conv2d_bwd_pw instantiates; 3x20x20 and 1x13x9 end in a ragged pixel tile
 PWBWD_SHAPES = [(2, 40, 40, 128, 128, 0), (3, 20, 20, 64, 64, 0), (2, 40, 40, 64, 64, 32), (1, 13, 9, 32, 32, 8), (2, 24, 24, 64, 128, 0),
                 (2, 24, 24, 128, 64, 32), (1, 40, 40, 32, 64, 0), (1, 40, 40, 64, 32, 0)]
