@@ -20,7 +20,11 @@
 // the 1/2/2/4 taps that reach that class (so no zero-stuffing and no atomics).
 
 
-#define PLYOLO_CONV_PD 2   // forward instances: weight fragments two taps ahead (see the A/B in profiles/r04_ab_fusions.txt)
+// Every instance of THIS translation unit fetches its weight fragments two taps ahead: the forward launches and -- the same template
+// instances -- the plain data gradients launched from here (conv_mfma_dgrad without a folded reduction: launch_bn<false>, launch_jobs).
+// The RED / 4-row / stride-2-dgrad instances (conv_mfma_red.hip, conv_mfma_t4.hip, conv_s2d.hip), i.e. almost every data gradient of a
+// training plan, keep one tap (measured in profiles/r04_ab_fusions.txt: two taps everywhere made the launches shorter and the step no shorter)
+#define PLYOLO_CONV_PD 2
 #include "conv_mfma_body.h"
 
 namespace plyolo {
@@ -524,6 +528,7 @@ int conv_mfma_dgrad_bn(const plyolo_conv_desc* d, const plyolo_bn_bwd_fuse* f, c
   p.bpsplit = f->par_split; p.bgamma2 = f->gamma2; p.bdgamma2 = f->dgamma2; p.bdbeta2 = f->dbeta2;
   p.bdz = (bf16_t*)f->dz; p.bdz_ld = f->dz_ld;
   p.bfwd = (bf16_t*)f->fwd_to; p.bfwd_ld = f->fwd_ld;
+  p.bdu = getenv("PLYOLO_BNB_DU_HACK") ? atoi(getenv("PLYOLO_BNB_DU_HACK")) : 0;   // TIMING EXPERIMENT ONLY (wrong results): the loader without its activation arithmetic
   {
     char lab[64];
     snprintf(lab, sizeof(lab), "conv_mfma_dgrad_bn<BN%d,CK%d,TH%d>%s", BN, CK, TH, p.red.n > 0 ? "+bnred" : "");

@@ -64,6 +64,7 @@ struct ConvP {
   bf16_t* bfwd;          // out: x copied here (the Bottleneck shortcut's gradient, first writer), or NULL
   int bfwd_ld;
   int btab;              // LDS byte offset of the per-channel table (behind the halo buffers)
+  int bdu;               // 1: x already holds du = dout * act'(u) (written by the producer's folded reduction, plyolo_bn_red_seg::store_du): the loader is affine
 };
 
 DEVINL unsigned tap_code(const ConvP& p, int t) {
@@ -188,8 +189,9 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
 
   // weight fragments in flight: PD taps ahead.  PD = 2 on the 32-channel double-buffered variant (a tap there is only
   // 256 cycles of MFMA) measured 1.5 % SLOWER on the whole step in round 2 (+8 VGPRs, same occupancy); round 4: launches 2-5 %
-  // shorter, step unchanged when every instance has it, -0.03 ms when only the FORWARD translation units do (conv_mfma.hip,
-  // conv_mfma_s2.hip define PLYOLO_CONV_PD 2: the forward has no co-runner whose share of the CU the extra registers cost)
+  // shorter, step unchanged when every instance has it, -0.03 ms when only the translation units of the FORWARD launches do
+  // (conv_mfma.hip, conv_mfma_s2.hip define PLYOLO_CONV_PD 2: the forward has no co-runner whose share of the CU the extra registers
+  // cost; the plain, un-folded data gradients are instances of conv_mfma.hip too and share the setting -- a training plan launches few)
 #ifndef PLYOLO_CONV_PD
 #define PLYOLO_CONV_PD 1
 #endif
@@ -336,6 +338,15 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
       for (int i = 0; i < 4; ++i) {
         const f32x2 sc = *(const f32x2*)(tab + cc + 2 * i), sh = *(const f32x2*)(tab + Kp + cc + 2 * i), A = *(const f32x2*)(tab + 2 * Kp + cc + 2 * i),
                     B = *(const f32x2*)(tab + 3 * Kp + cc + 2 * i), Cc = *(const f32x2*)(tab + 4 * Kp + cc + 2 * i);
+        if (p.bdu) {   // (wave-uniform)
+#pragma unroll
+          for (int v = 0; v < HVT; ++v) {
+            const unsigned zz = zv[v][i], dd = hv[v][i];
+            const float zl = __uint_as_float(zz << 16), zh = __uint_as_float(zz & 0xffff0000u);
+            const float dul = __uint_as_float(dd << 16), duh = __uint_as_float(dd & 0xffff0000u);
+            zv[v][i] = pack2bf(fmaf(A[0], dul, fmaf(B[0], zl, Cc[0])), fmaf(A[1], duh, fmaf(B[1], zh, Cc[1])));
+          }
+        } else {
 #pragma unroll
         for (int v = 0; v < HVT; ++v) {
           const unsigned zz = zv[v][i], dd = hv[v][i];
@@ -344,6 +355,7 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
           const float dul = dl * bnred_act_grad(fmaf(zl, sc[0], sh[0]), PLYOLO_ACT_SILU);
           const float duh = dh * bnred_act_grad(fmaf(zh, sc[1], sh[1]), PLYOLO_ACT_SILU);
           zv[v][i] = pack2bf(fmaf(A[0], dul, fmaf(B[0], zl, Cc[0])), fmaf(A[1], duh, fmaf(B[1], zh, Cc[1])));
+        }
         }
       }
 #pragma unroll

@@ -672,6 +672,10 @@ hipError_t launch_wg(const WgP& p, int S, hipStream_t s) {
 namespace plyolo {
 
 hipError_t conv_wgrad1_launch(const void* x, const void* dz, float* dw, int M, int Cout, int Cin, int x_ld, int dz_ld, int G, hipStream_t s);   // conv_wgrad1.hip
+// conv_wgrad1w.hip: wide pointwise layers (160+ channels on both sides) as a deep-K GEMM on 256 x 256 / 192 x 192 tiles
+int conv_wgrad1w_tiles(int Cout, int Cin);
+int conv_wgrad1w_tile(int Cout, int Cin);
+hipError_t conv_wgrad1w_launch(const void* x, const void* dz, float* dw, int M, int Cout, int Cin, int x_ld, int dz_ld, int S, hipStream_t s);
 
 struct WgPlan { WgP p; int id, S, WK, CO_T, CI_T, th, trs; };
 
@@ -758,8 +762,30 @@ static WgPlan plan_wgrad(const plyolo_conv_desc* d) {
   if (d->ksize == 3 && w.trs == 1 && S * nco * p.nci > 256) S = 256 / (nco * p.nci);
   if (S < 1) S = 1;
   if (S > p.ntiles) S = p.ntiles;
+  //  id 6: 1x1 wide (160+ channels on both sides): 256 x 256 / 192 x 192 tiles, one workgroup per CU (conv_wgrad1w.hip; PLYOLO_WG1W=0: id 5)
+  {
+    static const int wg1w = getenv("PLYOLO_WG1W") ? atoi(getenv("PLYOLO_WG1W")) : 1;
+    const int wt = (wg1w && d->ksize == 1 && d->stride == 1 && !d->x_coef) ? conv_wgrad1w_tiles(true_cout, d->Cin) : 0;
+    if (wt) {
+      w.id = 6;
+      w.CO_T = w.CI_T = conv_wgrad1w_tile(true_cout, d->Cin);
+      const int nstage = (int)(((size_t)d->N * d->H * d->W + 31) / 32);
+      int cus = 256;
+      if (const char* e = getenv("PLYOLO_WG1W_WGS")) { const int v = atoi(e); if (v >= 8) cus = v; }
+      S = cus / wt;
+      // slab bytes per layer (written once, read once by the fold).  Same box, two alternations, ms/step at 16 / 40 / 80 MB: YOLOX-x 1280 98.8 /
+      // 99.3 / 99.3 (128 x 128 slabs: 100.3), YOLOv7 27.8 / 28.2 / - (28.4), YOLOX-l 17.3 / 17.5 / - (17.3): the lighter launch wins again
+      double b1 = 16.0e6;
+      if (const char* e = getenv("PLYOLO_WG1W_BUDGET_MB")) { const double v = atof(e); if (v >= 1.0) b1 = v * 1.0e6; }
+      const int sb = (int)(b1 / dw_bytes);
+      if (S > sb) S = sb;
+      if (S < 1) S = 1;
+      if (S > nstage / 4) S = nstage / 4 > 0 ? nstage / 4 : 1;      // at least four stages per range
+    }
+  }
   if (const char* e = getenv("PLYOLO_WG_S")) { const int v = atoi(e); if (v > 0) S = v < p.ntiles ? v : p.ntiles; }
   if (const char* e = getenv("PLYOLO_ABLATE_WG")) p.ablate = atoi(e);
+  if (d->ksize == 1) if (const char* e = getenv("PLYOLO_ABLATE_WG1")) p.ablate = atoi(e);   // diagnostics (results are wrong): the 1x1 weight gradients only
   p.Cout = true_cout;  // slabs are [tap][Cout][Cin] with the TRUE Cout
   w.S = S;
   return w;
@@ -783,6 +809,11 @@ int conv_mfma_wgrad(const plyolo_conv_desc* d, const void* x, const void* dy, fl
     snprintf(lab, sizeof(lab), "conv_wgrad<%dx%d,k%d>%s", w.CO_T, w.CI_T, ks, p.pre ? "+bnact" : "");
     const double Mo = (double)p.N * p.OH * p.OW, Mi = (double)p.N * p.H * p.W;
     annotate(lab, 2.0 * Mo * d->Cout * d->Cin * ks * ks, (Mo * d->Cout + Mi * d->Cin) * 2.0 + 4.0 * ks * ks * d->Cout * d->Cin);
+  }
+  if (id == 6 && !p.ablate) {
+    const int M = d->N * d->H * d->W, cout = d->Cout, cin = d->Cin, xl = d->x_ld, yl = d->y_ld;
+    const void* xp = x; const void* dyp = dy;
+    return submit(stream, [=](hipStream_t s) -> hipError_t { return conv_wgrad1w_launch(xp, dyp, dwp, M, cout, cin, xl, yl, S, s); });
   }
 #ifdef PLYOLO_OPTIN
   // 1x1 stride 1 with 128+ channels on both sides: the persistent streaming kernel (conv_wgrad1.hip), opt-in (make OPTIN=1,

@@ -125,9 +125,9 @@ class Graph:
         # to plyolo_conv2d_bwd_pw it takes the remaining small-map pointwise units: 15 launches and ~0.4 GB less, 8.66 vs 8.69 / 8.63
         # vs 8.66 ms -- on by default
         self.fuse_bnbwd = os.environ.get("PLYOLO_FUSE_BNBWD", "1") == "1"
-        # PLYOLO_FUSE_BNBWD3 (default on, round 5): the same for the 3x3 stride-1 units -- the halo loader of their data gradient takes
+        # PLYOLO_FUSE_BNBWD3 (default OFF, round 5: bit-identical and slower -- the SiLU-backward arithmetic of the 1.4x halo is as long as the tile's MFMA work, profiles/r05_ab_dz_on_load.txt): the same for the 3x3 stride-1 units -- the halo loader of their data gradient takes
         # (dout, z) pairs and stages dz (csrc/conv_mfma_bnb.hip); the bn_act_bwd_dz launch of the unit leaves the data-gradient chain
-        self.fuse_bnbwd3 = os.environ.get("PLYOLO_FUSE_BNBWD3", "1") == "1" and dtype == BF16 and training
+        self.fuse_bnbwd3 = os.environ.get("PLYOLO_FUSE_BNBWD3", "0") == "1" and dtype == BF16 and training
         # units without a data gradient (the first convolution): dz formed in the weight gradient's loader (plyolo_conv2d_wgrad_bn)
         self.fuse_wgbn = os.environ.get("PLYOLO_FUSE_WGBN", "1") == "1" and training and dtype == BF16
         self.fwd_res_in_dz = os.environ.get("PLYOLO_RES_IN_DZ", "1") == "1"    # A/B switch: 0 = a copy_add launch per shortcut
@@ -301,9 +301,36 @@ class Graph:
             elif isinstance(op, ConvPairOp) and hasattr(op, "coef"):
                 views.append((op, op.out_a, 0))
                 views.append((op, op.out_b, op.Ca))
+        # which ops will run their backward at all?  An op whose output receives no gradient returns early (`if not g.grad_ready(self.out)`)
+        # and writes nothing: listing it as a writer would plan a fold into a launch that never happens (check_bn_red would then refuse
+        # the whole graph).  Same readiness rule as the bwd methods, simulated over the views: all channels of an output written.
+        sim, live = {}, set()
+
+        def _ready(a):
+            f = sim.get(id(a.storage))
+            return f is not None and all(f[a.c_off:a.c_off + a.C])
+
+        def _mark(a):
+            f = sim.setdefault(id(a.storage), [False] * a.storage.ld)
+            for i in range(a.c_off, a.c_off + a.C):
+                f[i] = True
+        for op in reversed(self.ops):
+            try:
+                ins, outs = op_io(op)
+            except TypeError:
+                ins, outs = [], []
+            aouts = [o for o in outs if isinstance(o, Act)]
+            if aouts and not any(_ready(o) for o in aouts):
+                continue
+            live.add(id(op))
+            for a in ins:
+                if isinstance(a, Act) and not (a is getattr(op, "x", None) and getattr(op, "need_dgrad", True) is False):
+                    _mark(a)
         # gradient writes in backward order: (op, input Act, is a convolution data gradient with a RED instance)
         writes = []
         for op in reversed(self.ops):
+            if id(op) not in live:
+                continue
             if isinstance(op, ConvUnitOp):
                 if op.res is not None:
                     writes.append((op, op.res, False))
@@ -987,7 +1014,10 @@ class ConvUnitOp:
         dout, zt = g.gptr(self.out), self.z.tensor.data_ptr()
         plan, lanes, me = g.plan, g.use_lanes, self.lane
         pw_one = bool(self.pw_slabs)          # dz + data gradient + weight gradient in one launch (plyolo_conv2d_bwd_pw)
-        dz, key = (None, None) if pw_one else g.dz_buffer(self, M * Cout)
+        # no data gradient at all (the first convolution): dz is only read by the weight gradient -- formed in ITS loader, never stored
+        wg_bn = (bn is not None and not pw_one and g.fuse_wgbn and not self.need_dgrad and self.res is None
+                 and _lib.lib().plyolo_conv2d_wgrad_bn_fits(C.byref(self.desc), self.act) == 1)
+        dz, key = (None, None) if (pw_one or wg_bn) else g.dz_buffer(self, M * Cout)
         # the shortcut's share of the gradient (network_blocks.py:89-90): forwarded by the bn_act_bwd_dz pass that reads dout anyway;
         # units without that pass (no BatchNorm, fused pointwise path) copy it with a launch of its own
         fused = bn is not None and not pw_one and self.need_dgrad and g.dgrad_bn_fits(self.desc_d, self.act)
@@ -1021,9 +1051,6 @@ class ConvUnitOp:
                     self.pc.reduce_slabs()
                 return
             # pointwise and 3x3 stride-1 units: dz is formed inside the data gradient's loader (one launch and one pass over dout / z less)
-            # no data gradient at all (the first convolution): dz is only read by the weight gradient -- formed in ITS loader
-            wg_bn = (g.fuse_wgbn and not self.need_dgrad and self.res is None
-                     and _lib.lib().plyolo_conv2d_wgrad_bn_fits(C.byref(self.desc), self.act) == 1)
             if wg_bn:
                 f = BnBwdFuse()
                 f.dout, f.dout_ld, f.z, f.z_ld, f.coef, f.bslots = dout, self.out.ld, zt, Cout, self.coef.data_ptr(), bslots

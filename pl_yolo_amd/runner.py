@@ -374,26 +374,21 @@ def _check_generation(ctx, s):
 
 
 def _accumulating(runner, s):
-    """`.grad` still being the flat view AND untouched since the last backward means the caller neither dropped nor zeroed the
-    gradients (gradient accumulation over micro-batches, Lightning's accumulate_grad_batches): autograd would ADD the new
-    gradient, while the backward plan overwrites the flat buffer.  The published versions are kept per RUNNER -- every traced
-    shape of a model shares the one flat gradient buffer (multi-scale training).  EVERY used parameter is looked at: the flat
-    buffer is set aside and added back as a whole, so a caller that zeroed or dropped only some of the gradients (an optimizer
-    that owns part of the model, a frozen stem, zero_grad on one parameter group) cannot be served and is refused."""
-    pv = runner.flat.get("published") if runner.flat else None
-    if not s.used_params or not pv:
-        return False
-    kept = 0
+    """The (parameter, flat view) pairs whose `.grad` still IS the flat view of the previous backward: the caller did not drop those
+    gradients, so autograd would ADD the new gradient to whatever they hold now -- the previous micro-batch (gradient accumulation,
+    Lightning's accumulate_grad_batches), zeros (zero_grad(set_to_none=False)), a clipped or masked gradient -- while the backward plan
+    overwrites the flat buffer.  Decided per parameter and by identity only: the views share ONE version counter with their flat
+    buffer, so an in-place change of one gradient is indistinguishable from a change of all of them; adding the current contents back
+    is right in every case (it costs two passes over 4 bytes per parameter on such steps; dropping the gradients --
+    zero_grad(set_to_none=True), torch's default -- costs nothing).  Returns (kept pairs, all kept?)."""
+    if not s.used_params or not runner.flat:
+        return [], False
+    kept = []
     for p, gv in zip(s.used_params, s.grad_views):
         g = p.grad
-        if g is not None and g.data_ptr() == gv.data_ptr() and pv.get(id(p)) == g._version:
-            kept += 1
-    if kept not in (0, len(s.used_params)):
-        raise PlyoloError("backward over partially cleared gradients: %d of %d parameters still hold the previous backward's "
-                          "gradient and the others were zeroed or dropped; the HIP plan writes ONE flat gradient buffer, so "
-                          "clear (or keep, to accumulate) the gradients of all parameters of the model together"
-                          % (kept, len(s.used_params)))
-    return kept > 0
+        if g is not None and g.data_ptr() == gv.data_ptr():
+            kept.append((p, gv))
+    return kept, len(kept) == len(s.used_params)
 
 
 def _publish_grads(runner, s):
@@ -409,32 +404,34 @@ def _publish_grads(runner, s):
             p.grad = gv
         else:
             g.add_(gv)
-    pub = runner.flat.setdefault("published", {})
-    if not isinstance(pub, dict):
-        pub = runner.flat["published"] = {}
-    for p in s.used_params:
-        if p.grad is not None:
-            pub[id(p)] = p.grad._version
 
 
 class _Accumulate:
     """Around a backward replay: when the caller is accumulating (see _accumulating) the gradient of the previous micro-batches
     is set aside before the plan overwrites the flat buffer and added back behind it -- two extra passes over the 4 bytes per
-    parameter (36 MB for YOLOX-s), only on accumulating steps; `.grad` keeps pointing at the flat buffer.  In a process group
-    the plan's buckets average the NEW gradient only; the part set aside is already the cross-rank mean."""
+    parameter (36 MB for YOLOX-s), only on accumulating steps; `.grad` keeps pointing at the flat buffer.  When only SOME parameters
+    kept their gradient (zero_grad on one parameter group, a masked or dropped gradient) the part set aside is added back for exactly
+    those.  In a process group the plan's buckets average the NEW gradient only; the part set aside is already the cross-rank mean."""
 
     def __init__(self, runner, s):
         self.runner, self.prev = runner, None
-        self.acc = _accumulating(runner, s)
+        self.kept, self.all = _accumulating(runner, s)
 
     def __enter__(self):
-        if self.acc:
+        if self.kept:
             self.prev = self.runner.flat["g"].clone()
         return self
 
     def __exit__(self, et, ev, tb):
-        if self.acc and et is None:
-            self.runner.flat["g"].add_(self.prev)
+        if self.kept and et is None:
+            flat = self.runner.flat["g"]
+            if self.all:
+                flat.add_(self.prev)
+            else:   # only some gradients were kept: add the part set aside back parameter by parameter (rare; a few hundred small adds)
+                base, esz = flat.data_ptr(), flat.element_size()
+                for _, gv in self.kept:
+                    off = (gv.data_ptr() - base) // esz
+                    gv.add_(self.prev[off:off + gv.numel()].view_as(gv))
         self.prev = None
         return False
 

@@ -41,6 +41,15 @@ SHAPES = [
     (2, 160, 160, 64, 64, 3, 2),    # stride 2 dgrad parity classes on 16x16 tiles
     (3, 26, 38, 64, 128, 3, 2),     # stride-2 forward instances (4-row tiles, de-interleaved halo): ragged 13 x 19 output, two chunks
     (2, 22, 46, 96, 64, 3, 2),      # ... Cin 96 = three chunks, 11 x 23 output, 64-channel block
+    # one small-spatial case per instance class the WIDE plans select (yolox_x.yaml: 320 / 640 / 1280 / 2560 channels; yolox_l.yaml and
+    # yolov7.yaml: 1024 / 2048): many input chunks x several output blocks, channel counts that are not powers of two
+    (2, 20, 20, 320, 320, 3, 1),    # ten chunks, three output blocks (the last one 64 of 128 channels)
+    (1, 10, 10, 640, 640, 3, 1),
+    (1, 8, 8, 1024, 1024, 3, 1),
+    (1, 12, 12, 2560, 1280, 1, 1),  # SPP bottleneck conv2 of YOLOX-x
+    (1, 12, 12, 2048, 1024, 1, 1),
+    (2, 20, 20, 80, 160, 1, 1),     # 80 = a 64 + 16 channel chunk tail
+    (1, 16, 16, 640, 1280, 3, 2),
 ]
 
 
@@ -172,6 +181,31 @@ def test_conv_wgrad(dt, shape):
     err = hu.relerr(got, ref)
     print("conv_wgrad", shape, "relerr %.3g" % err)
     assert err <= 1e-4
+
+
+# (N, H, W, Cin, Cout): wide pointwise layers on the deep-K GEMM tiles of csrc/conv_wgrad1w.hip -- 256 x 256 and 192 x 192 tiles, several
+# channel tiles per side, channel tails inside a tile (160 = 5 x 32 of 192; 200 of 256), a pixel count that is no multiple of the
+# 32-pixel stage, one and many pixel ranges (slabs)
+WGRAD1W_SHAPES = [(1, 13, 9, 160, 160), (2, 20, 20, 320, 160), (1, 25, 25, 640, 320), (3, 7, 11, 168, 200), (1, 40, 40, 256, 512), (4, 40, 40, 320, 320),
+                  (2, 16, 16, 1280, 640)]
+
+
+@pytest.mark.parametrize("shape", WGRAD1W_SHAPES, ids=str)
+@pytest.mark.parametrize("wgs", [0, 24])
+def test_wide_pointwise_wgrad_tiles(shape, wgs, monkeypatch):
+    """plyolo_conv2d_wgrad of a wide 1x1 layer (conv_wgrad1w.hip) against torch's fp32 weight gradient of the same bf16 operands, with the
+    planned number of pixel ranges and with a small one (many stages per range, ranges that end inside the last stage), and against
+    the 128 x 128-slab kernel it replaces (PLYOLO_WG1W=0) -- same products, another summation order."""
+    N, H, W, Cin, Cout = shape
+    if wgs:
+        monkeypatch.setenv("PLYOLO_WG1W_WGS", str(wgs))
+    full = (N, H, W, Cin, Cout, 1, 1)
+    test_conv_wgrad(BF16, full)
+    d = hu.conv_desc(BF16, N, H, W, Cin, Cout, 1, 1, Cin + 8, Cout + 8)
+    ns = hu._lib.lib().plyolo_conv2d_wgrad_slabs(C.byref(d))
+    assert ns >= 1
+    print("wide wgrad", shape, "slabs", ns)
+
 
 
 @pytest.mark.parametrize("cout", [80, 5])

@@ -769,6 +769,41 @@ def test_stale_forward_is_refused_and_gradients_accumulate():
             assert float((p.grad - g2[n]).abs().max()) <= 1e-5 * max(float(g2[n].abs().max()), 1e-6), n
 
 
+def test_partially_cleared_gradients_accumulate_per_parameter():
+    """A backward over PARTIALLY cleared gradients behaves like autograd, parameter by parameter: kept gradients (the previous backward's
+    views, untouched) accumulate, gradients zeroed in place or dropped (zero_grad on one parameter group, a frozen stem, a second
+    optimizer) are overwritten -- the three cases of runner._accumulating: all kept, all cleared, partial."""
+    g, model = _golden_model("fp32")
+    model.train()
+    x = torch.from_numpy(g["x"]).to(hu.DEV)
+    labels = torch.from_numpy(g["labels"]).to(hu.DEV)
+    model(x, labels)["loss"].backward()
+    torch.cuda.synchronize()
+    g1 = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    names = sorted(g1)
+    dropped = [n for n in names if n.startswith("backbone.stem")]
+    zeroed = [n for n in names if n.startswith("head.")]
+    kept = [n for n in names if n not in dropped and n not in zeroed]
+    assert dropped and zeroed and kept
+    params = dict(model.named_parameters())
+    for n in dropped:
+        params[n].grad = None
+    for n in zeroed:
+        params[n].grad.zero_()
+    model(x, labels)["loss"].backward()       # same batch again
+    torch.cuda.synchronize()
+    for n in names:      # (the fp32 parity weight gradient sums with atomics: equal up to summation order)
+        want = 2.0 * g1[n] if n in kept else g1[n]
+        assert float((params[n].grad - want).abs().max()) <= 2e-5 * max(float(g1[n].abs().max()), 1e-6), n
+    # all cleared -> plain overwrite; all kept -> everything doubles again
+    model.zero_grad(set_to_none=True)
+    model(x, labels)["loss"].backward()
+    model(x, labels)["loss"].backward()
+    torch.cuda.synchronize()
+    for n in names:
+        assert float((params[n].grad - 2.0 * g1[n]).abs().max()) <= 2e-5 * max(float(g1[n].abs().max()), 1e-6), n
+
+
 def _step_with_env(env, dtype, g):
     """One training step of the golden toy model with environment switches applied while its plans are recorded."""
     old = {k: os.environ.get(k) for k in env}

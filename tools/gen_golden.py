@@ -800,6 +800,85 @@ def gen_cfg1():
     save("cfg1_nano416", d)
 
 
+def gen_wide(which=("yolox_l", "yolox_x", "yolov7")):
+    """BASELINE.json configs[2..4] at their FULL width (yolox_l.yaml, yolox_x.yaml, yolov7.yaml unchanged) through the REFERENCE on
+    a small synthetic batch (128x128, batch 2): seeded initialisation (manual_seed(96), checked by the first convolution's weights
+    and a parameter checksum), the raw head maps of the labels=None path, the loss scalars, ~20 whole gradients (every prediction
+    bias, one convolution / BatchNorm per stage, small enough to store) and the L2 norm of EVERY parameter's gradient."""
+    for name in which:
+        fam = "yolov7" if name.startswith("yolov7") else "yolox"
+        with open(os.path.join(ROOT, "configs", "model", fam, name + ".yaml")) as f:
+            cfg = yaml.safe_load(f)
+        C = 80
+        torch.manual_seed(96)
+        model = build_model(cfg, C)
+        model.train()
+        B, S, num_gt, max_gt = 2, 128, 6, 20
+
+        def batch(seed):
+            g = torch.Generator().manual_seed(seed)
+            imgs = torch.rand(B, 3, S, S, generator=g) * 255
+            labels = torch.zeros(B, max_gt, 5)
+            labels[:, :num_gt, 0] = torch.randint(0, C, (B, num_gt), generator=g).float()
+            labels[:, :num_gt, 1:3] = (0.15 + 0.7 * torch.rand(B, num_gt, 2, generator=g)) * S
+            labels[:, :num_gt, 3:5] = 8 + torch.rand(B, num_gt, 2, generator=g) * 0.3 * S
+            return imgs, labels
+
+        seed = 4321
+        if fam == "yolox":
+            # SimOTA is discrete: among a few candidate batches keep the one whose k-th cost boundary is widest (as network_yolox_s_warm does),
+            # so that an fp32 re-implementation cannot legitimately flip an assignment
+            sd_init = {k: v.clone() for k, v in model.state_dict().items()}
+            best = (-1.0, seed)
+            for cand in range(4321, 4333):
+                model.load_state_dict(sd_init)
+                _calls.clear()
+                with torch.no_grad():
+                    model(*batch(cand))
+                gap = min([c["gap"] for c in _calls] + [float("inf")])
+                best = max(best, (gap, cand))
+            model.load_state_dict(sd_init)
+            seed = best[1]
+            print("%s: data seed %d (k-th cost boundary gap %.4g)" % (name, seed, best[0]))
+        imgs, labels = batch(seed)
+        d = dict(batch=B, size=S, num_classes=C, seed_weights=96, seed_data=seed, num_gt=num_gt, max_gt=max_gt)
+        params = list(model.named_parameters())
+        d["param_sum"] = float(sum(p.double().sum() for _, p in params))
+        d["param_abs_sum"] = float(sum(p.double().abs().sum() for _, p in params))
+        d["first_weight"] = params[0][1].detach().clone()
+        d["n_params"] = len(params)
+        sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+        with torch.no_grad():
+            maps = model(imgs, None)          # raw NCHW head maps (train-mode BatchNorm: batch statistics)
+        for i, m in enumerate(maps):
+            d["maps/%d" % i] = m.detach().clone()
+        model.load_state_dict(sd0)             # (the running statistics moved; the trained step starts from the seeded state)
+        _calls.clear()
+        out = model(imgs, labels)
+        loss = out["loss"].sum()
+        loss.backward()
+        for k, v in out.items():
+            d["out/" + k] = v.detach().clone().reshape(-1) if torch.is_tensor(v) else float(v)
+        if fam == "yolox":
+            d["boundary_gap"] = min([c["gap"] for c in _calls] + [float("inf")])
+            d["num_fg"] = sum(c["num_fg"] for c in _calls)
+        names = [n for n, _ in params]
+        pick = [n for n in names if n.startswith("head") and (n.endswith(".bias") and "norm" not in n or n.endswith(".implicit"))]
+        small = [n for n, p in params if p.dim() == 4 and p.numel() <= 120000 and n not in pick]
+        pick += [small[i] for i in sorted({int(round(j * (len(small) - 1) / 5.0)) for j in range(6)})]
+        norms = [n for n, p in params if p.dim() == 1 and n.endswith("norm.weight")]
+        pick += [norms[i] for i in sorted({0, len(norms) // 3, 2 * len(norms) // 3, len(norms) - 1})]
+        for n in pick:
+            d["grad/" + n] = dict(params)[n].grad.clone()
+        d["grad_names"] = np.array(names)
+        d["grad_norms"] = np.array([float(p.grad.double().norm()) if p.grad is not None else -1.0 for _, p in params])
+        d["grad_sq_sum"] = float(sum((p.grad.double() ** 2).sum() for _, p in params if p.grad is not None))
+        print("%s fixture: loss=%.6f  %d stored gradients, %d parameters with a gradient" %
+              (name, float(loss), len(pick), int((d["grad_norms"] >= 0).sum())), {k: v for k, v in d.items() if k in ("num_fg", "boundary_gap")})
+        save("wide_" + name, d)
+
+
+
 def toy_detection_dataset(seed=5, n=7, size=(48, 64)):
     """A tiny in-memory data set in the shape MosaicDetection reads (cocoDataset: annotations / imgs / img_size): images of
     assorted sizes and aspect ratios, one of them without labels."""
@@ -967,6 +1046,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "cfg1":
         gen_cfg1()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "wide":
+        gen_wide(tuple(sys.argv[2:]) or ("yolox_l", "yolox_x", "yolov7"))
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "repconv":
         gen_repconv()
         sys.exit(0)
@@ -987,6 +1069,7 @@ if __name__ == "__main__":
     gen_format_outputs()
     gen_deploy()
     gen_cfg1()
+    gen_wide()
     gen_mosaic()
     gen_cutout()
     gen_schedule()
