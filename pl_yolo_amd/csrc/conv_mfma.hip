@@ -528,7 +528,6 @@ int conv_mfma_dgrad_bn(const plyolo_conv_desc* d, const plyolo_bn_bwd_fuse* f, c
   p.bpsplit = f->par_split; p.bgamma2 = f->gamma2; p.bdgamma2 = f->dgamma2; p.bdbeta2 = f->dbeta2;
   p.bdz = (bf16_t*)f->dz; p.bdz_ld = f->dz_ld;
   p.bfwd = (bf16_t*)f->fwd_to; p.bfwd_ld = f->fwd_ld;
-  p.bdu = getenv("PLYOLO_BNB_DU_HACK") ? atoi(getenv("PLYOLO_BNB_DU_HACK")) : 0;   // TIMING EXPERIMENT ONLY (wrong results): the loader without its activation arithmetic
   {
     char lab[64];
     snprintf(lab, sizeof(lab), "conv_mfma_dgrad_bn<BN%d,CK%d,TH%d>%s", BN, CK, TH, p.red.n > 0 ? "+bnred" : "");

@@ -64,7 +64,6 @@ struct ConvP {
   bf16_t* bfwd;          // out: x copied here (the Bottleneck shortcut's gradient, first writer), or NULL
   int bfwd_ld;
   int btab;              // LDS byte offset of the per-channel table (behind the halo buffers)
-  int bdu;               // 1: x already holds du = dout * act'(u) (written by the producer's folded reduction, plyolo_bn_red_seg::store_du): the loader is affine
 };
 
 DEVINL unsigned tap_code(const ConvP& p, int t) {
@@ -338,15 +337,6 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
       for (int i = 0; i < 4; ++i) {
         const f32x2 sc = *(const f32x2*)(tab + cc + 2 * i), sh = *(const f32x2*)(tab + Kp + cc + 2 * i), A = *(const f32x2*)(tab + 2 * Kp + cc + 2 * i),
                     B = *(const f32x2*)(tab + 3 * Kp + cc + 2 * i), Cc = *(const f32x2*)(tab + 4 * Kp + cc + 2 * i);
-        if (p.bdu) {   // (wave-uniform)
-#pragma unroll
-          for (int v = 0; v < HVT; ++v) {
-            const unsigned zz = zv[v][i], dd = hv[v][i];
-            const float zl = __uint_as_float(zz << 16), zh = __uint_as_float(zz & 0xffff0000u);
-            const float dul = __uint_as_float(dd << 16), duh = __uint_as_float(dd & 0xffff0000u);
-            zv[v][i] = pack2bf(fmaf(A[0], dul, fmaf(B[0], zl, Cc[0])), fmaf(A[1], duh, fmaf(B[1], zh, Cc[1])));
-          }
-        } else {
 #pragma unroll
         for (int v = 0; v < HVT; ++v) {
           const unsigned zz = zv[v][i], dd = hv[v][i];
@@ -355,7 +345,6 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
           const float dul = dl * bnred_act_grad(fmaf(zl, sc[0], sh[0]), PLYOLO_ACT_SILU);
           const float duh = dh * bnred_act_grad(fmaf(zh, sc[1], sh[1]), PLYOLO_ACT_SILU);
           zv[v][i] = pack2bf(fmaf(A[0], dul, fmaf(B[0], zl, Cc[0])), fmaf(A[1], duh, fmaf(B[1], zh, Cc[1])));
-        }
         }
       }
 #pragma unroll

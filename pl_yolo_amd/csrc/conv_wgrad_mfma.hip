@@ -61,7 +61,15 @@ DEVINL s16x4 tr_read(const unsigned char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
 }
 
+// LDS row pitch of a pixel row of `ch` channels.  Rows of a multiple of 128 bytes need a pad that keeps the four pixel rows of a transposed
+// read on distinct banks: 64 bytes did (rounds 1-4); 16 bytes do as well (4 * pitch = 64 mod 256, the rule of conv_pw_bwd.hip) and shrink
+// the two tiles of the 64 x 64 3x3 variant from 126 KB to 97 KB -- room for a data-gradient workgroup of the main lane on the same CU
+// (PLYOLO_WG_PAD64 at build time restores the old pitch)
+#ifdef PLYOLO_WG_PAD64
 constexpr int pitch_for(int ch) { return ch * 2 + ((ch * 2) % 128 == 0 ? 64 : 0); }
+#else
+constexpr int pitch_for(int ch) { return ch * 2 + ((ch * 2) % 128 == 0 ? 16 : 0); }
+#endif
 
 // CO_T x CI_T: dW slab of the workgroup; MTC x MTI: 32x32 MFMA tiles per wave along co / ci;
 // WK: waves that split the k-steps (tile rows) of one slab (small-channel layers); TH_: tile rows.
@@ -320,7 +328,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
 // BNB (plyolo_conv2d_wgrad_bn; SiLU units without a data gradient -- the first convolution of a network): the separate
 // bn_act_bwd_dz pass of such a unit writes a dz that ONLY this kernel reads.  Here the dY vectors of a tile arrive as (dout, z) pairs
 // and are turned into dz between the register set and LDS: dout and z are read once, dz never reaches HBM (3 E_out of traffic less).
-template <int CO_T, int CI_T, int WK, int TH_, int SI, bool PRE, bool BNB = false>
+template <int CO_T, int CI_T, int WK, int TH_, int SI, bool PRE, bool BNB = false, bool WIN = true>
 __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WgP p) {
   constexpr int KS = 3, NTAPS = 9;
   constexpr int WCO = CO_T / 32, WCI = CI_T / 32;
@@ -539,12 +547,34 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WgP p) {
       const s16x4 lo = tr_read(ap + j * TW * DZB);
       const s16x4 hi = tr_read(ap + j * TW * DZB + 4 * DZB);
       af = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      if constexpr (SI == 1 && WIN) {
+        // stride 1: the three taps of one kernel row read the SAME halo row shifted by 0 / 1 / 2 pixels.  A lane's fragment is 8
+        // consecutive pixels of one channel, so a 12-pixel window (three transposed reads) holds all three: dx = 0 and dx = 2 are
+        // register renames, dx = 1 is four v_alignbit -- 9 LDS reads per k-step for the X operand instead of 18.  The LDS read port
+        // is what bounds this kernel (one fragment read per MFMA with a 32 x 32 block per wave and tap); the window's last two
+        // pixels of the upper half-wave (columns 18, 19) are the next halo row's first two -- read, never used
+#pragma unroll
+        for (int dy = 0; dy < KS; ++dy) {
+          const unsigned char* rp = bp + (j + dy) * ITW_ * XB;
+          const s16x4 w0 = tr_read(rp), w1 = tr_read(rp + 4 * XB), w2 = tr_read(rp + 8 * XB);
+          typedef __attribute__((ext_vector_type(2))) unsigned u32x2_;
+          const u32x2_ a0 = *(const u32x2_*)&w0, a1 = *(const u32x2_*)&w1, a2 = *(const u32x2_*)&w2;
+          const unsigned D0 = a0[0], D1 = a0[1], D2 = a1[0], D3 = a1[1], D4 = a2[0];
+          const u32x4 t0 = {D0, D1, D2, D3}, t2 = {D1, D2, D3, D4};
+          const u32x4 t1 = {__builtin_amdgcn_alignbit(D1, D0, 16), __builtin_amdgcn_alignbit(D2, D1, 16), __builtin_amdgcn_alignbit(D3, D2, 16),
+                            __builtin_amdgcn_alignbit(D4, D3, 16)};
+          bfv[dy * KS + 0] = *(const s16x8*)&t0;
+          bfv[dy * KS + 1] = *(const s16x8*)&t1;
+          bfv[dy * KS + 2] = *(const s16x8*)&t2;
+        }
+      } else {
 #pragma unroll
       for (int t = 0; t < NTAPS; ++t) {
         const int o = ((j * SI + t / KS) * ITW_ + t % KS) * XB;
         const s16x4 l2 = tr_read(bp + o);
         const s16x4 h2 = tr_read(bp + o + 4 * SI * XB);
         bfv[t] = __builtin_shufflevector(l2, h2, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
       }
     };
     auto mm = [&](const s16x8& af, const s16x8 (&bfv)[NTAPS]) {
@@ -561,12 +591,13 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WgP p) {
           request(t2, v);
         }
     };
-    auto pattern = [&]() {   // [MFMA + 5 LDS reads] x 4: the next k-step's fragments first; then the tile pipeline's share
+    auto pattern = [&]() {   // [MFMA + 5 LDS reads] x 4 (windowed X operand: 3 reads): the next k-step's fragments first; then the tile pipeline's share
       constexpr int SV = (NV + NJ - 1) / NJ;
+      constexpr int RD = (SI == 1 && WIN) ? 3 : 5;
 #pragma unroll
       for (int i = 0; i < NTAPS; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (i < 4) __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+        if (i < 4) __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
         else if (i - 4 < SV) {
           __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
@@ -617,6 +648,10 @@ hipError_t launch_wg3(const WgP& p, int S, hipStream_t s) {
   auto kern = p.pre ? conv_wgrad3_kernel<CO_T, CI_T, WK, TH_, SI, true> : conv_wgrad3_kernel<CO_T, CI_T, WK, TH_, SI, false>;
 #else
   auto kern = conv_wgrad3_kernel<CO_T, CI_T, WK, TH_, SI, false>;   // lazy inputs are refused at the C ABI (api.hip: check_conv)
+  if constexpr (SI == 1) {      // PLYOLO_WG_WIN=0: the X fragments of every tap read from LDS on their own (round 2 .. 4; A/B switch)
+    static const int win = getenv("PLYOLO_WG_WIN") ? atoi(getenv("PLYOLO_WG_WIN")) : 1;
+    if (!win) kern = conv_wgrad3_kernel<CO_T, CI_T, WK, TH_, SI, false, false, false>;
+  }
 #endif
   if (hipError_t e = plyolo::ensure_dynamic_lds((const void*)kern, 160 * 1024); e != hipSuccess) return e;
   const int nco = (p.Cout + CO_T - 1) / CO_T;

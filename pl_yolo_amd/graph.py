@@ -125,7 +125,7 @@ class Graph:
         # to plyolo_conv2d_bwd_pw it takes the remaining small-map pointwise units: 15 launches and ~0.4 GB less, 8.66 vs 8.69 / 8.63
         # vs 8.66 ms -- on by default
         self.fuse_bnbwd = os.environ.get("PLYOLO_FUSE_BNBWD", "1") == "1"
-        # PLYOLO_FUSE_BNBWD3 (default OFF, round 5: bit-identical and slower -- the SiLU-backward arithmetic of the 1.4x halo is as long as the tile's MFMA work, profiles/r05_ab_dz_on_load.txt): the same for the 3x3 stride-1 units -- the halo loader of their data gradient takes
+        # PLYOLO_FUSE_BNBWD3 (default OFF, round 5: bit-identical and slower -- the fused launch reads dout AND z over the 1.4x halo and still writes dz for the weight gradient: 4.8 E in a bandwidth-bound kernel against 5.4 E split over a stream-rate pass and an MFMA-bound one, profiles/r05_ab_dz_on_load.txt): the same for the 3x3 stride-1 units -- the halo loader of their data gradient takes
         # (dout, z) pairs and stages dz (csrc/conv_mfma_bnb.hip); the bn_act_bwd_dz launch of the unit leaves the data-gradient chain
         self.fuse_bnbwd3 = os.environ.get("PLYOLO_FUSE_BNBWD3", "0") == "1" and dtype == BF16 and training
         # units without a data gradient (the first convolution): dz formed in the weight gradient's loader (plyolo_conv2d_wgrad_bn)
@@ -257,6 +257,8 @@ class Graph:
         costs an event on the main lane (a ~7 us bubble between two kernels), so it is paid once per
         WGRAD_BATCH conv units instead of once per unit: with private dz buffers the queued wgrads may start
         any time after their dz kernel, a few layers of lag cost nothing."""
+        if os.environ.get("PLYOLO_DIAG_SKIP_WG", "0") == "1":     # diagnostics only (results are wrong): no weight-gradient launches at all
+            return
         q = self.pending.setdefault(lane, [])
         q.append(fn)
         if len(q) >= WGRAD_BATCH:
