@@ -196,7 +196,7 @@ def load_pmc_traffic(args):
     and the entry says which build it belongs to."""
     if (args.model, args.size, args.batch) != ("yolox_s", 640, 32):
         return None
-    for tag in ("r04", "r03", "r02", "r01"):
+    for tag in ("r06", "r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", "%s_pmc_hbm_traffic.json" % tag)
         try:
             with open(path) as f:
