@@ -46,6 +46,7 @@ static inline hipError_t conv3ws_launch(const void*, const void*, void*, double*
 namespace plyolo {
 hipError_t conv_mfma_launch_s2(const void* convp, int BN, hipStream_t s);   // conv_mfma_s2.hip
 hipError_t conv_mfma_launch_t4(const void* convp, int BN, int red, hipStream_t s);   // conv_mfma_t4.hip
+hipError_t conv_mfma_launch_flat(const void* convp, int red, hipStream_t s);         // conv_mfma_flat.hip
 // conv_mfma_red.hip: data-gradient instances that fold the upstream BatchNorm-backward reduction into their store loop
 // conv_s2d.hip: 3x3 stride-2 data gradient, the four parity classes on one staged tile
 int conv_s2d_th(int BN);
@@ -175,6 +176,23 @@ bool use_t4(const ConvP& p, int ksize, int BN, int CK, int TH, bool plain_bf16) 
   return p.nmb * ((p.Cout + BN - 1) / BN) <= max_wg;
 }
 
+// row-flattened tiles (conv_mfma_flat.hip) for a 3x3 stride-1 launch on a 20- or 40-wide map with 128-channel output blocks;
+// prepares the ConvP when taken.  PLYOLO_FLAT=0: the rectangular tiles (8 x 16, or 4 x 16 below PLYOLO_TH4_MAX_WG workgroups); 1 (default):
+// the 20-wide maps (stand-alone, batch 32: 128 -> 128 13.8 -> 13.4 us, 256 -> 256 29.4 -> 27.0 forward, 28.6 -> 25.9 backward); 2: the 40-wide
+// maps too -- measured SLOWER there (128 -> 128 @40x40 23.6 -> 27.2 us forward, 22.7 -> 25.8 backward): ten fragments per wave leave one
+// fragment set and no room for the software pipeline of the 8 x 16 tile, which the 17 % of saved rows do not pay for
+bool use_flat(ConvP& p, int ksize, int BN, int CK, bool plain_bf16) {
+  const int mode = getenv("PLYOLO_FLAT") ? atoi(getenv("PLYOLO_FLAT")) : 1;
+  if (mode == 0 || (mode == 1 && p.OWt != 20)) return false;
+  if (!plain_bf16 || ksize != 3 || p.si != 1 || p.so != 1 || CK != 32 || BN != 128 || !(p.db && p.Cin > CK) || p.ablate) return false;
+  if ((p.OWt != 20 && p.OWt != 40) || p.OHt % 4 != 0 || p.OWt != p.W || p.OHt != p.H) return false;
+  p.tw = p.OWt; p.trows = 4; p.twinv = (65536 + p.tw - 1) / p.tw;
+  p.ITH = p.trows + 2; p.ITW = p.tw + 2;
+  p.tiles_x = 1; p.tiles_y = p.OHt / p.trows;
+  p.nmb = p.N * p.tiles_y;
+  return true;
+}
+
 void set_taps(ConvP& p) {
   p.taps_lo = 0ull;
   p.taps_hi = 0u;
@@ -284,6 +302,13 @@ int conv_mfma_fwd(const plyolo_conv_desc* d, const void* x, const void* wp, cons
     annotate(lab, 2.0 * M * d->Cout * d->Cin * 9.0, M * d->Cout * 2.0 + (double)d->N * d->H * d->W * d->Cin * 2.0);
     return submit(stream, [=](hipStream_t s) { return conv_mfma_launch_s2(&p, bn, s); });
   }
+  if (use_flat(p, d->ksize, BN, CK, !f32 && !p.pre && !bias && !ep_coef && !ep_res)) {
+    char lab[64];
+    snprintf(lab, sizeof(lab), "conv_mfma_fwd<BN128,CK32,FLAT%d>", p.tw);
+    const double M = (double)p.N * p.OHf * p.OWf;
+    annotate(lab, 2.0 * M * d->Cout * d->Cin * 9.0, M * d->Cout * 2.0 + (double)d->N * d->H * d->W * d->Cin * 2.0);
+    return submit(stream, [=](hipStream_t s) { return conv_mfma_launch_flat(&p, 0, s); });
+  }
   if (use_t4(p, d->ksize, BN, CK, TH, !f32 && !p.pre)) {
     apply_tiles(p, 3, 3, 4);
     char lab[64];
@@ -353,6 +378,15 @@ int conv_mfma_dgrad(const plyolo_conv_desc* d, const void* dy, const void* wpd, 
       });
     }
     if (red_fits) { *red_fits = (d->ksize == 3 && !p.ablate) ? conv_mfma_red_has(BN, CK, TH, 0) : 0; return 0; }
+    if (use_flat(p, d->ksize, BN, CK, true)) {
+      const bool rf = red && red->n > 0;
+      if (rf) p.red = *red;
+      char lab[64];
+      snprintf(lab, sizeof(lab), "conv_mfma_dgrad<BN128,CK32,FLAT%d>%s", p.tw, rf ? "+bnred" : "");
+      const double Mo = (double)d->N * OH * OW, Mi = (double)d->N * d->H * d->W;
+      annotate(lab, 2.0 * Mo * d->Cout * d->Cin * 9.0, (Mo * Kc + Mi * d->Cin * ((accumulate ? 2.0 : 1.0) + (rf ? 1.0 : 0.0))) * 2.0);
+      return submit(stream, [=](hipStream_t s) { return conv_mfma_launch_flat(&p, rf ? 1 : 0, s); });
+    }
     if (use_t4(p, d->ksize, BN, CK, TH, true)) {
       const bool r4 = red && red->n > 0;
       if (r4) p.red = *red;

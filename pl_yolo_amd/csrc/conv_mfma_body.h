@@ -64,6 +64,9 @@ struct ConvP {
   bf16_t* bfwd;          // out: x copied here (the Bottleneck shortcut's gradient, first writer), or NULL
   int bfwd_ld;
   int btab;              // LDS byte offset of the per-channel table (behind the halo buffers)
+  // FLAT instances (conv_mfma_flat.hip): a tile is `trows` FULL image rows of a `tw`-wide map (tw = 20 / 40), its pixels numbered row-major;
+  // twinv = ceil(65536 / tw): row of pixel m = (m * twinv) >> 16 for every m of a tile
+  int tw, trows, twinv;
 };
 
 DEVINL unsigned tap_code(const ConvP& p, int t) {
@@ -118,15 +121,26 @@ DEVINL u32x4 pre_apply(u32x4 t, const float* __restrict__ pre, int pre_ld, int a
 // apart and every read is 2-way conflicted).  Tap (dy, dx) reads region dx & 1 at column offset dx >> 1.
 // RED (conv_mfma_red.hip, data gradients): the store loop also folds the BatchNorm-backward reduction of the upstream unit(s) (bnred.h)
 // BNB (conv_mfma_bnb.hip, 3x3 stride-1 data gradients of SiLU units): the halo loader takes (dout, z) pairs and stages dz (ConvP::bz ...)
-template <int BN, int CK, int TH, bool OUT_F32, int ABL, bool DB = false, bool PRE = false, bool MF16 = false, bool S2 = false, bool RED = false, bool BNB = false>
+// FLAT (conv_mfma_flat.hip, 3x3 stride 1 on 20- / 40-wide maps): the TH*16 pixels of a tile are `trows` whole image rows instead of a TH x 16
+// rectangle -- the 16-pixel fragments run over the row-major pixel list (per-lane LDS row addresses are free in this kernel: the tap shifts
+// already use them), so a 20-wide map is covered at 100 % instead of 62 % (4 x 16 tiles) and a 40-wide one at 100 % instead of 83 %
+template <int BN, int CK, int TH, bool OUT_F32, int ABL, bool DB = false, bool PRE = false, bool MF16 = false, bool S2 = false, bool RED = false, bool BNB = false,
+          bool FLAT = false>
 DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
   static_assert(!RED || !OUT_F32, "RED instances store bf16 gradients");
   static_assert(!BNB || (!OUT_F32 && !PRE && !S2), "BNB instances: stride-1 bf16 data gradients");
+  static_assert(!FLAT || (MF16 && !S2 && !BNB && !OUT_F32), "FLAT instances: stride-1 bf16 tiles on the 16x16x32 path");
   static_assert(!MF16 || (CK == 32 && !OUT_F32 && !PRE && DB), "MF16 instances: 32-channel double-buffered bf16 tiles");
   static_assert(!S2 || (DB && !MF16 && !PRE && !OUT_F32), "S2 instances: double-buffered bf16 tiles");
   constexpr int BM = TH * TW;
   constexpr int WN = BN / 32, WM = 4 / WN, MT = BM / (32 * WM);
-  constexpr int MT16 = 2 * MT, HALF16 = MT;   // MF16: 16-pixel fragments per wave / per software-pipeline half
+  constexpr int MT16 = FLAT ? BM / (16 * WM) : 2 * MT;   // MF16: 16-pixel fragments per wave ...
+  constexpr int HALF16 = (MT16 + 1) / 2, HALF16B = MT16 - HALF16;   // ... and per software-pipeline half (5 = 3 + 2 on the 80-pixel FLAT tile)
+  // pixel m of a tile -> (row, column) inside the tile
+  auto tile_rc = [&](const int m, int& rr, int& cc) {
+    if constexpr (FLAT) { rr = (int)(((unsigned)m * (unsigned)p.twinv) >> 16); cc = m - rr * p.tw; }
+    else { rr = m >> 4; cc = m & 15; }
+  };
   constexpr int ROWB = CK * 2 + (MF16 ? 32 : 16);  // LDS row pitch in bytes (pad: 16 B; MF16: 32 B)
   constexpr int CV = CK / 8;         // 16-byte vectors per row
   constexpr int KS = CK / 16;        // k-steps per chunk
@@ -147,7 +161,7 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
   const int t2 = tile / p.tiles_x;
   const int tyi = t2 % p.tiles_y;
   const int n = t2 / p.tiles_y;
-  const int oy0 = tyi * TH, ox0 = txi * TW;
+  const int oy0 = tyi * (FLAT ? p.trows : TH), ox0 = txi * TW;
   const int iy0 = oy0 * p.si + p.iy_off, ix0 = ox0 * p.si + p.ix_off;
   const int cout0 = blockIdx.y * BN;
   const int nb = blockIdx.y * WN + wn;  // this wave's 32-channel block of the packed weights
@@ -170,6 +184,11 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
   if constexpr (MF16) {
 #pragma unroll
     for (int j = 0; j < MT16; ++j) {
+      if constexpr (FLAT) {
+        int rr, cc;
+        tile_rc((wm * MT16 + j) * 16 + (lane & 15), rr, cc);
+        arow16[j] = rr * p.rowp + cc * ROWB + (lane >> 4) * 16;
+      } else
       arow16[j] = ((wm * MT16 + j) * p.si) * p.rowp + ((lane & 15) * p.si) * ROWB + (lane >> 4) * 16;
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) acc16[j][hh] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -235,7 +254,7 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
   // vectors is the same for every Cin chunk, so it is computed ONCE per tile: in-kernel stamps showed the halo
   // phases at ~10k cycles each, most of it the per-vector index arithmetic (a runtime division by the tile
   // width, bounds tests, 64-bit addresses) repeated for the loads, again for the LDS stores, and per chunk.
-  constexpr int HVT = S2 ? ((2 * TH + 1) * 33 * CV + 255) / 256 : ((TH + 2) * 18 * CV + 255) / 256;   // vectors per thread of a 3x3 halo tile
+  constexpr int HVT = S2 ? ((2 * TH + 1) * 33 * CV + 255) / 256 : (FLAT ? (6 * 42 * CV + 255) / 256 : ((TH + 2) * 18 * CV + 255) / 256);   // vectors per thread of a 3x3 halo tile
   const int nvec = p.ITH * p.ITW * CV;
   const bool fastpath = nvec <= HVT * 256;                 // stride-2 forward tiles take the generic loop
   const bf16_t* xn = p.x + (size_t)n * p.H * p.W * p.x_ld;
@@ -466,6 +485,27 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
             for (int j = 0; j < Q; ++j) a16[j] = an16[j];
           }
         }
+      } else if constexpr (FLAT) {
+      // uneven halves (5 fragments = 3 + 2 on the 80-pixel tile, 10 = 5 + 5 on the 160-pixel one), ONE fragment set: the second half is
+      // requested behind the first half's MFMAs (a second set costs the 160-pixel tile its third wave per SIMD: 179 -> 159 VGPRs)
+      bf16x8 a16[HALF16];
+#pragma unroll
+      for (int j = 0; j < HALF16; ++j) a16[j] = *(const bf16x8*)(smem + arow16[j] + toff);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < HALF16; ++j) {
+        acc16[j][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a16[j], b0, acc16[j][0], 0, 0, 0);
+        acc16[j][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a16[j], b1, acc16[j][1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < HALF16B; ++j) a16[j] = *(const bf16x8*)(smem + arow16[HALF16 + j] + toff);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < HALF16B; ++j) {
+        acc16[HALF16 + j][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a16[j], b0, acc16[HALF16 + j][0], 0, 0, 0);
+        acc16[HALF16 + j][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a16[j], b1, acc16[HALF16 + j][1], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
       } else {
       bf16x8 a16[HALF16], an16[HALF16];
 #pragma unroll
@@ -614,7 +654,13 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
         for (int j = 0; j < MT16; ++j)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const bool valid = (oy0 + wm * MT16 + j < p.OHt) && (ox0 + kq * 4 + i < p.OWt);
+            bool valid;
+            if constexpr (FLAT) {
+              int rr, cc;
+              tile_rc((wm * MT16 + j) * 16 + kq * 4 + i, rr, cc);
+              valid = oy0 + rr < p.OHt;      // (every column of a full-width row is a pixel)
+            } else
+            valid = (oy0 + wm * MT16 + j < p.OHt) && (ox0 + kq * 4 + i < p.OWt);
             const float v = valid ? acc16[j][hh][i] : 0.f;
             s1 += v;
             s2 = fmaf(v, v, s2);
@@ -758,13 +804,21 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
       const int v = tid % VPR, co = cout0 + v * 8;
       BnRedThread rt;
       bnred_init(rt, p.red, co);
-      u32x4 zq[NIT], old[NIT];
-      size_t pixs[NIT];
-      bool ok[NIT];
+      // (FLAT tiles with ten rows per thread run the loop in two halves: ten z vectors + ten old rows in flight cost the 160-pixel tile its third
+      // wave per SIMD -- 189 VGPRs)
+      constexpr int NPASS = (FLAT && NIT > 8) ? 2 : 1, NIP = NIT / NPASS;
+      static_assert(NIT % NPASS == 0, "RED: whole passes");
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int m = (tid + it * 256) / VPR;
-        const int a = oy0 + (m >> 4), b = ox0 + (m & 15);
+      for (int ps = 0; ps < NPASS; ++ps) {
+      u32x4 zq[NIP], old[NIP];
+      size_t pixs[NIP];
+      bool ok[NIP];
+#pragma unroll
+      for (int it = 0; it < NIP; ++it) {
+        const int m = (tid + (ps * NIP + it) * 256) / VPR;
+        int rr_, cc_;
+        tile_rc(m, rr_, cc_);
+        const int a = oy0 + rr_, b = ox0 + cc_;
         ok[it] = a < p.OHt && b < p.OWt && co < p.Cout;
         const int oy = a * p.so + p.oy_off, ox = b * p.so + p.ox_off;
         pixs[it] = ok[it] ? (size_t)(n * p.OHf + oy) * p.OWf + ox : 0;
@@ -772,8 +826,8 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
         old[it] = p.accumulate ? *(const u32x4*)(y + pixs[it] * p.y_ld + (co < p.Cout ? co : 0)) : u32x4{0u, 0u, 0u, 0u};
       }
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int m = (tid + it * 256) / VPR;
+      for (int it = 0; it < NIP; ++it) {
+        const int m = (tid + (ps * NIP + it) * 256) / VPR;
         if (ok[it]) {
           u32x4 val = *(const u32x4*)(smem + m * SROW + v * 16);
           if (p.accumulate) val = add_bf16x8(old[it], val);
@@ -781,12 +835,15 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
           if (rt.z) bnred_add_any(rt, val, zq[it]);
         }
       }
+      }
       __syncthreads();   // every thread is done with the staging rows: the fold reuses them
       bnred_flush<256, VPR>(rt, p.red, cout0, (float*)smem, tid, tile % PLYOLO_STAT_SLOTS);
     } else {
     for (int idx = tid; idx < BM * VPR; idx += 256) {
       const int m = idx / VPR, v = idx - m * VPR;
-      const int a = oy0 + (m >> 4), b = ox0 + (m & 15), co = cout0 + v * 8;
+      int rr_, cc_;
+      tile_rc(m, rr_, cc_);
+      const int a = oy0 + rr_, b = ox0 + cc_, co = cout0 + v * 8;
       if (a < p.OHt && b < p.OWt && co < p.Cout) {
         const int oy = a * p.so + p.oy_off, ox = b * p.so + p.ox_off;
         u32x4 val = *(const u32x4*)(smem + m * SROW + v * 16);
@@ -801,9 +858,10 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
   }
 }
 
-template <int BN, int CK, int TH, bool OUT_F32, int ABL = 0, bool DB = false, bool PRE = false, bool MF16 = false, bool S2 = false, bool RED = false, bool BNB = false>
+template <int BN, int CK, int TH, bool OUT_F32, int ABL = 0, bool DB = false, bool PRE = false, bool MF16 = false, bool S2 = false, bool RED = false, bool BNB = false,
+          bool FLAT = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvP p) {
-  conv_mfma_body<BN, CK, TH, OUT_F32, ABL, DB, PRE, MF16, S2, RED, BNB>(p, (int)blockIdx.x, (int)gridDim.x);
+  conv_mfma_body<BN, CK, TH, OUT_F32, ABL, DB, PRE, MF16, S2, RED, BNB, FLAT>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // MF16 instances (stride-1 tiles of 8 rows, 32-channel double-buffered chunks, bf16 output): launch with the wider pixel pitch

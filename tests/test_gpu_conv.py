@@ -50,6 +50,11 @@ SHAPES = [
     (1, 12, 12, 2048, 1024, 1, 1),
     (2, 20, 20, 80, 160, 1, 1),     # 80 = a 64 + 16 channel chunk tail
     (1, 16, 16, 640, 1280, 3, 2),
+    # row-flattened tiles of the 20- / 40-wide maps (conv_mfma_flat.hip): 80- and 160-pixel tiles of four whole rows, forward and data gradient
+    (2, 40, 40, 128, 128, 3, 1),
+    (1, 12, 40, 64, 192, 3, 1),     # Cout 192 = a block and a half; dgrad: dx 64 channels -> rectangular tiles
+    (3, 8, 20, 96, 256, 3, 1),      # three input chunks, two output blocks
+    (2, 20, 20, 256, 256, 3, 1),
 ]
 
 
@@ -181,6 +186,42 @@ def test_conv_wgrad(dt, shape):
     err = hu.relerr(got, ref)
     print("conv_wgrad", shape, "relerr %.3g" % err)
     assert err <= 1e-4
+
+
+@pytest.mark.parametrize("shape", [(2, 40, 40, 128, 128), (1, 12, 40, 192, 192), (3, 8, 20, 96, 256), (2, 20, 20, 256, 256), (5, 24, 20, 128, 160)], ids=str)
+def test_row_flattened_tiles_match_rectangular_tiles(shape, monkeypatch):
+    """conv_mfma_flat.hip (tiles of four whole rows on 20- / 40-wide maps) against the rectangular 8 x 16 / 4 x 16 tiles (PLYOLO_FLAT=0): every
+    output element is the same sum in the same order (chunk, tap, k), so forward, data gradient (overwrite and accumulate) and the folded
+    BatchNorm reduction's dx are bit-identical; the BatchNorm statistics agree to their fp64 grouping."""
+    from pl_yolo_amd._lib import STAT_SLOTS
+    N, H, W, Cin, Cout = shape
+    dt, dev = BF16, hu.DEV
+    torch.manual_seed(sum(shape) + 21)
+    M = N * H * W
+    x = torch.randn(M, Cin + 8, device=dev).to(torch.bfloat16)
+    w = hu.rnd_bf16(torch.randn(Cout, Cin, 3, 3, device=dev) / (9 * Cin) ** 0.5)
+    pk = hu.Packed(w, dt)
+    dy = torch.randn(M, Cout + 8, device=dev).to(torch.bfloat16)
+    d = hu.conv_desc(dt, N, H, W, Cin, Cout, 3, 1, Cin + 8, Cout + 8)
+    res = {}
+    for flat in ("1", "0"):
+        monkeypatch.setenv("PLYOLO_FLAT", "2" if flat == "1" else "0")     # 2: the 40-wide maps too (by default only the 20-wide ones)
+        y = torch.full((M, Cout + 8), 3.0, dtype=torch.bfloat16, device=dev)
+        stats = torch.zeros(STAT_SLOTS, 2, Cout, dtype=torch.float64, device=dev)
+        call("plyolo_conv2d_fwd", C.byref(d), x.data_ptr(), pk.wp.data_ptr(), None, y.data_ptr(), stats.data_ptr(), hu.stream())
+        dxs = []
+        for acc in (0, 1):
+            dx = torch.full((M, Cin + 8), 0.5, dtype=torch.bfloat16, device=dev)
+            call("plyolo_conv2d_dgrad", C.byref(d), dy.data_ptr(), pk.wpd.data_ptr(), dx.data_ptr(), acc, hu.stream())
+            dxs.append(dx)
+        torch.cuda.synchronize()
+        res[flat] = (y, stats.sum(0), dxs)
+    (y1, s1, dx1), (y0, s0, dx0) = res["1"], res["0"]
+    assert torch.equal(y1.view(torch.int16), y0.view(torch.int16)), "forward differs"
+    assert float((s1 - s0).abs().max()) <= 1e-6 * float(s0.abs().max())      # (fp32 partial sums per tile, another tile shape)
+    for a, b in zip(dx1, dx0):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16)), "data gradient differs"
+    assert float(y1[:, :Cout].float().abs().max()) > 0 and torch.all(y1[:, Cout:].float() == 3.0)
 
 
 # (N, H, W, Cin, Cout): wide pointwise layers on the deep-K GEMM tiles of csrc/conv_wgrad1w.hip -- 256 x 256 and 192 x 192 tiles, several
@@ -657,7 +698,9 @@ def test_stride2_dgrad_fused_parity_classes_equal_the_four_job_launch(shape, acc
 RED_SHAPES = [(2, 20, 20, 128, 128, 3, 1, [(0, 128)]), (3, 24, 18, 64, 64, 3, 1, [(0, 32), (32, 64)]), (1, 36, 40, 32, 32, 3, 1, [(0, 32)]),
               (2, 32, 32, 64, 128, 3, 2, [(0, 64)]), (1, 64, 64, 32, 64, 3, 2, [(0, 32)]), (2, 26, 38, 128, 256, 3, 2, [(0, 64), (64, 128)]),
               (2, 20, 20, 128, 128, 1, 1, [(0, 128)]), (3, 13, 9, 64, 96, 1, 1, [(8, 40)]), (2, 40, 40, 256, 80, 1, 1, [(0, 128), (128, 256)]),
-              (4, 20, 20, 128, 16, 1, 1, [(0, 128)])]
+              (4, 20, 20, 128, 16, 1, 1, [(0, 128)]),
+              # row-flattened tiles (conv_mfma_flat.hip): 40- and 20-wide maps, dx blocks of 128 channels (a 192-channel dx = a block and a half)
+              (2, 40, 40, 128, 128, 3, 1, [(0, 128)]), (1, 12, 40, 192, 64, 3, 1, [(0, 64), (64, 192)]), (3, 8, 20, 256, 96, 3, 1, [(0, 128), (128, 256)])]
 
 
 @pytest.mark.parametrize("shape", RED_SHAPES, ids=str)
