@@ -184,9 +184,10 @@ bool use_t4(const ConvP& p, int ksize, int BN, int CK, int TH, bool plain_bf16) 
 bool use_flat(ConvP& p, int ksize, int BN, int CK, bool plain_bf16) {
   const int mode = getenv("PLYOLO_FLAT") ? atoi(getenv("PLYOLO_FLAT")) : 1;
   if (mode == 0 || (mode == 1 && p.OWt != 20)) return false;
+  const int trows = (mode == 3 && p.OWt == 40) ? 2 : 4;      // 3: 40-wide maps as tiles of TWO rows (80 pixels, the 20-wide maps' instance)
   if (!plain_bf16 || ksize != 3 || p.si != 1 || p.so != 1 || CK != 32 || BN != 128 || !(p.db && p.Cin > CK) || p.ablate) return false;
   if ((p.OWt != 20 && p.OWt != 40) || p.OHt % 4 != 0 || p.OWt != p.W || p.OHt != p.H) return false;
-  p.tw = p.OWt; p.trows = 4; p.twinv = (65536 + p.tw - 1) / p.tw;
+  p.tw = p.OWt; p.trows = trows; p.twinv = (65536 + p.tw - 1) / p.tw;
   p.ITH = p.trows + 2; p.ITW = p.tw + 2;
   p.tiles_x = 1; p.tiles_y = p.OHt / p.trows;
   p.nmb = p.N * p.tiles_y;

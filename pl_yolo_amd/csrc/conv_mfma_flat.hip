@@ -31,8 +31,9 @@ namespace plyolo {
 // Cin > 32, more than 64 output channels, bf16 output
 hipError_t conv_mfma_launch_flat(const void* convp, int red, hipStream_t s) {
   const ConvP& p = *(const ConvP*)convp;
-  if (p.tw == 40) return red ? launch_flat_inst<10, true>(p, s) : launch_flat_inst<10, false>(p, s);
-  if (p.tw == 20) return red ? launch_flat_inst<5, true>(p, s) : launch_flat_inst<5, false>(p, s);
+  const int px = p.tw * p.trows;      // pixels per tile: 160 (4 x 40) or 80 (4 x 20, 2 x 40)
+  if (px == 160) return red ? launch_flat_inst<10, true>(p, s) : launch_flat_inst<10, false>(p, s);
+  if (px == 80) return red ? launch_flat_inst<5, true>(p, s) : launch_flat_inst<5, false>(p, s);
   return hipErrorInvalidValue;
 }
 
