@@ -308,12 +308,13 @@ class Graph:
         # the whole graph).  Same readiness rule as the bwd methods, simulated over the views: all channels of an output written.
         sim, live = {}, set()
 
+        # (a gradient the caller supplies -- the outputs of a sub-module traced on its own, module_runner.py -- is marked written before)
         def _ready(a):
-            f = sim.get(id(a.storage))
-            return f is not None and all(f[a.c_off:a.c_off + a.C])
+            f = sim.setdefault(id(a.storage), list(a.storage.ginit))
+            return all(f[a.c_off:a.c_off + a.C])
 
         def _mark(a):
-            f = sim.setdefault(id(a.storage), [False] * a.storage.ld)
+            f = sim.setdefault(id(a.storage), list(a.storage.ginit))
             for i in range(a.c_off, a.c_off + a.C):
                 f[i] = True
         for op in reversed(self.ops):

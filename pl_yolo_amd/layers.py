@@ -38,14 +38,21 @@ def get_normalization(name, out_channels):
 
 
 class HipModule(nn.Module):
-    """Base: sub-modules are graph describers.  Calling one directly (outside a
-    detector) is not part of the hot path and is refused loudly."""
+    """Base: sub-modules are graph describers (`emit`); the detector traces the whole network through them once (runner.py).
+    Called directly they keep the reference's tensor contract -- backbone `Tensor -> list`, neck `list -> list`, head
+    `list -> list of raw NCHW maps`, blocks `Tensor -> Tensor` -- through a traced session of their own (module_runner.py):
+    forward plan, and in training mode an autograd node that replays the recorded backward plan.  That is the boundary for
+    callers that mix these modules with foreign ones, not the hot path.  Modules without an `emit` of that shape (the loss
+    plugins: their `(list, labels) -> dict` has no caller outside OneStageD) refuse a direct call loudly."""
 
     def forward(self, *a, **k):
-        raise PlyoloError(
-            "%s is a graph describer for the HIP launch plan; run it through build_model()/OneStageD "
-            "(pl_yolo_amd has no eager per-module path)" % type(self).__name__
-        )
+        if k or not hasattr(self, "emit") or type(self).__name__ in ("YOLOXLoss", "YOLOv7Loss"):
+            raise PlyoloError(
+                "%s is a graph describer for the HIP launch plan; run it through build_model()/OneStageD "
+                "(its tensor contract has no stand-alone path)" % type(self).__name__
+            )
+        from . import module_runner
+        return module_runner.run(self, *a)
 
 
 class BaseConv(HipModule):
