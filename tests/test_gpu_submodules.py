@@ -92,20 +92,23 @@ def test_block_call_matches_reference_fixture(tag):
     assert e16 <= 3e-2
 
 
-def _cfg(name):
-    with open(os.path.join(ROOT, "configs", "model", "yolox", name + ".yaml")) as f:
+def _cfg(name, family="yolox"):
+    with open(os.path.join(ROOT, "configs", "model", family, name + ".yaml")) as f:
         return yaml.safe_load(f)
 
 
+@pytest.mark.parametrize("family", ["yolox", "yolov7"])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-def test_backbone_neck_head_called_one_by_one_match_the_detector(dtype):
-    g = load_golden("network_yolox_test")
+def test_backbone_neck_head_called_one_by_one_match_the_detector(dtype, family):
+    """CSPDarkNet + CSPPAFPN + DecoupledHead, and EELAN + YOLOv7NECK + ImplicitHead (models/backbones/eelan.py, models/necks/yolov7_neck.py,
+    models/heads/implicit_head.py)."""
+    g = load_golden("network_%s_test" % family)
     nc = int(g["num_classes"])
     sd = {k[6:]: torch.from_numpy(v.copy()) for k, v in g.items() if k.startswith("state/")}
     x = torch.from_numpy(g["x"]).to(hu.DEV)
 
     def build():
-        m = pl_yolo_amd.build_model(dict(_cfg("yolox_test"), compute_dtype=dtype), nc)
+        m = pl_yolo_amd.build_model(dict(_cfg(family + "_test", family), compute_dtype=dtype), nc)
         m.load_state_dict(sd)
         return m.to(hu.DEV).train()
     whole = build()
