@@ -51,10 +51,15 @@ class ModuleRunner:
     # ---------------------------------------------------------------- parameter gradients
     def _flat(self, device):
         params = [p for p in self.m.parameters()]
-        key = tuple(id(p) for p in params)
+        # the recorded launches hold the ADDRESSES of the master weights and of the BatchNorm buffers: if the tensors moved since a
+        # session was traced (the detector adopted the parameters into its flat buffers, .to(), load_state_dict(assign=True)), every
+        # session of this module is stale and is dropped
+        key = tuple((id(p), p.data_ptr()) for p in params) + tuple((id(b), b.data_ptr()) for b in self.m.buffers())
         if self.gflat is None or self.gflat["key"] != key or self.gflat["g"].device != device:
             offs, n = {}, 0
             for p in params:
+                if p.dtype != torch.float32:
+                    raise PlyoloError("parameters must be fp32 master weights")
                 offs[id(p)] = n
                 n += _align(p.numel())
             self.gflat = dict(key=key, offs=offs, g=torch.zeros(max(n, 8), dtype=torch.float32, device=device))

@@ -148,6 +148,13 @@ def test_backbone_neck_head_called_one_by_one_match_the_detector(dtype, family):
     with torch.no_grad():
         f2 = parts.backbone(x)
     assert all(not t.requires_grad for t in f2)
+    # the detector adopts the parameters into its flat buffers (their storage moves): the sub-module's traced sessions notice and re-trace
+    parts.train()
+    before = [t.detach().clone() for t in parts.backbone(x)]
+    parts(x)
+    after = parts.backbone(x)
+    for a, b in zip(after, before):
+        assert hu.relerr(a.detach(), b) <= (1e-6 if dtype == "fp32" else 2e-2)
 
 
 def test_submodule_refusals():
