@@ -116,12 +116,19 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(int M, int C, const T* 
   constexpr int V = Vec<T>::N;
   const int act = ACTC >= 0 ? ACTC : act_rt;
   __shared__ float s_co[FUSED ? 2 * BN_MAXC : 2];
+  const int cvn = C / V;
+  const ColMap cm(cvn);
+  // the first row vector of this thread is requested BEFORE the coefficient prologue (slot sums, fp64 finalisation): on the 20x20 and 40x40
+  // maps a workgroup streams one or two vectors per thread and the launch is two dependent round trips long -- this makes it one
+  const int m_first = blockIdx.x * cm.rpb + cm.trow;
+  const bool pre = FUSED && cm.trow < cm.rpb && m_first < M;
+  // (unconditional, on a clamped row: a request behind a branch is waited for at the join)
+  typename Vec<T>::raw_t pr;
+  if (FUSED) pr = Vec<T>::load_raw(z + (size_t)(m_first < M ? m_first : M - 1) * z_ld + cm.tcol * V);
   if (FUSED) {
     for (int c = threadIdx.x; c < C; c += 256) bn_coef(st, C, c, blockIdx.x == 0, coef, &s_co[c], &s_co[C + c]);
     __syncthreads();
   }
-  const int cvn = C / V;
-  const ColMap cm(cvn);
   if (cm.trow >= cm.rpb) return;
   const int step = gridDim.x * cm.rpb;
   for (int cv = cm.tcol; cv < cvn; cv += cm.cols) {
@@ -136,10 +143,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(int M, int C, const T* 
       if (FUSED) { sc[i] = s_co[c + i]; sh[i] = s_co[C + c + i]; }
       else { sc[i] = coef ? coef[c + i] : 1.f; sh[i] = coef ? coef[C + c + i] : 0.f; }
     }
-#pragma unroll UNR
-    for (int m = blockIdx.x * cm.rpb + cm.trow; m < M; m += step) {
-      float f[V], r[V];
-      Vec<T>::load(z + (size_t)m * z_ld + c, f);
+    auto row = [&](const int m, float* f) {
+      float r[V];
       if (res) Vec<T>::load(res + (size_t)m * r_ld + c, r);
 #pragma unroll
       for (int i = 0; i < V; ++i) {
@@ -147,6 +152,19 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(int M, int C, const T* 
         f[i] = res ? u + r[i] : u;
       }
       Vec<T>::store(ob + (size_t)m * ol, f);
+    };
+    int m = m_first;
+    if (pre && cv == cm.tcol) {
+      float pf[V];
+      Vec<T>::cvt(pr, pf);
+      row(m, pf);
+      m += step;
+    }
+#pragma unroll UNR
+    for (; m < M; m += step) {
+      float f[V];
+      Vec<T>::load(z + (size_t)m * z_ld + c, f);
+      row(m, f);
     }
   }
 }
@@ -229,6 +247,18 @@ __global__ __launch_bounds__(256) void bn_act_bwd_dz_kernel(int M, int C, const 
   constexpr int V = Vec<T>::N;
   const int act = ACTC >= 0 ? ACTC : act_rt;
   __shared__ float s_b[3 * BN_MAXC];
+  const int cvn = C / V;
+  const ColMap cm(cvn);
+  // first row vectors (gradient and z) requested before the coefficient prologue, as in bn_act_fwd_kernel
+  const int m_first = blockIdx.x * cm.rpb + cm.trow;
+  const bool pre = cm.trow < cm.rpb && m_first < M;
+  typename Vec<T>::raw_t prd, prz;
+  {
+    const int c = cm.tcol * V, mp = m_first < M ? m_first : M - 1;
+    const bool second = sp.split > 0 && c >= sp.split;
+    prd = Vec<T>::load_raw((second ? (const T*)sp.p2 + (c - sp.split) : dout + c) + (size_t)mp * (second ? sp.ld2 : d_ld));
+    prz = Vec<T>::load_raw(z + (size_t)mp * z_ld + c);
+  }
   // dz = A*du + B*z + Cc with A = gamma*invstd, B = -A*invstd*mean(du*zhat), Cc = -A*mean(du) - B*mean
   for (int c = threadIdx.x; c < C; c += 256) {
     double s, ss;
@@ -250,8 +280,6 @@ __global__ __launch_bounds__(256) void bn_act_bwd_dz_kernel(int M, int C, const 
     }
   }
   __syncthreads();
-  const int cvn = C / V;
-  const ColMap cm(cvn);
   if (cm.trow >= cm.rpb) return;
   const int step = gridDim.x * cm.rpb;
   for (int cv = cm.tcol; cv < cvn; cv += cm.cols) {
@@ -266,11 +294,12 @@ __global__ __launch_bounds__(256) void bn_act_bwd_dz_kernel(int M, int C, const 
     const T* db = second ? (const T*)sp.p2 + (c - sp.split) : dout + c;
     const int dl = second ? sp.ld2 : d_ld;
     T* fwd = (T*)sp.fwd_to;
-#pragma unroll UNR
-    for (int m = blockIdx.x * cm.rpb + cm.trow; m < M; m += step) {
-      float d[V], zz[V];
-      Vec<T>::load(db + (size_t)m * dl, d);
-      Vec<T>::load(z + (size_t)m * z_ld + c, zz);
+    auto row = [&](const int m, float* d, const float* zz) {
+      float e[V];
+      if (fwd) {   // the shortcut's share of dout: copied / added by the pass that read it (no plyolo_copy_add launch)
+#pragma unroll
+        for (int i = 0; i < V; ++i) e[i] = d[i];
+      }
 #pragma unroll
       for (int i = 0; i < V; ++i) {
         const float u = fmaf(zz[i], sc[i], sh[i]);
@@ -278,9 +307,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_dz_kernel(int M, int C, const 
         d[i] = fmaf(A[i], du, fmaf(B[i], zz[i], Cc[i]));
       }
       Vec<T>::store(dz + (size_t)m * dz_ld + c, d);
-      if (fwd) {   // the shortcut's share of dout: copied / added by the pass that read it (no plyolo_copy_add launch)
-        float e[V];
-        Vec<T>::load(db + (size_t)m * dl, e);     // (an L1 hit: the vector was just loaded)
+      if (fwd) {
         if (sp.fwd_acc) {
           float o[V];
           Vec<T>::load(fwd + (size_t)m * sp.fwd_ld + c, o);
@@ -289,6 +316,21 @@ __global__ __launch_bounds__(256) void bn_act_bwd_dz_kernel(int M, int C, const 
         }
         Vec<T>::store(fwd + (size_t)m * sp.fwd_ld + c, e);
       }
+    };
+    int m = m_first;
+    if (pre && cv == cm.tcol) {
+      float pd[V], pz[V];
+      Vec<T>::cvt(prd, pd);
+      Vec<T>::cvt(prz, pz);
+      row(m, pd, pz);
+      m += step;
+    }
+#pragma unroll UNR
+    for (; m < M; m += step) {
+      float d[V], zz[V];
+      Vec<T>::load(db + (size_t)m * dl, d);
+      Vec<T>::load(z + (size_t)m * z_ld + c, zz);
+      row(m, d, zz);
     }
   }
 }

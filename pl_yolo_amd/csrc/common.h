@@ -114,14 +114,16 @@ DEVINL float act_grad(float u, int act) {
 template <typename T> struct Vec;
 template <> struct Vec<bf16_t> {
   static constexpr int N = 8;
-  static DEVINL void load(const bf16_t* p, float* f) {
-    const u32x4 v = *(const u32x4*)p;
+  typedef u32x4 raw_t;     // a requested vector that nothing has touched yet (the wait for it sits at cvt, not at the request)
+  static DEVINL raw_t load_raw(const bf16_t* p) { return *(const u32x4*)p; }
+  static DEVINL void cvt(const raw_t& v, float* f) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       f[2 * i] = __uint_as_float(v[i] << 16);
       f[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
     }
   }
+  static DEVINL void load(const bf16_t* p, float* f) { cvt(load_raw(p), f); }
   static DEVINL void store(bf16_t* p, const float* f) {
     u32x4 v;
 #pragma unroll
@@ -132,11 +134,13 @@ template <> struct Vec<bf16_t> {
 };
 template <> struct Vec<float> {
   static constexpr int N = 4;
-  static DEVINL void load(const float* p, float* f) {
-    const f32x4 v = *(const f32x4*)p;
+  typedef f32x4 raw_t;
+  static DEVINL raw_t load_raw(const float* p) { return *(const f32x4*)p; }
+  static DEVINL void cvt(const raw_t& v, float* f) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) f[i] = v[i];
   }
+  static DEVINL void load(const float* p, float* f) { cvt(load_raw(p), f); }
   static DEVINL void store(float* p, const float* f) {
     f32x4 v;
 #pragma unroll
