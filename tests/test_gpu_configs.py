@@ -179,7 +179,7 @@ def test_cfg1_nano416_b4_fp32_vs_reference_fixture():
         got, want = float(out[k]), float(g["out/" + k])
         print("cfg1", k, got, want)
         assert abs(got - want) <= 1e-4 * max(1.0, abs(want)), k
-    assert abs(float(out["proportion"]) - float(g["out/proportion"])) <= 1e-5
+    assert abs(float(out["proportion"]) - float(np.asarray(g["out/proportion"]).reshape(-1)[0])) <= 1e-5
     params = dict(model.named_parameters())
     for k in [k for k in g if k.startswith("grad/")]:
         ref = torch.from_numpy(g[k])
@@ -283,7 +283,7 @@ def test_wide_models_vs_reference_fixture(name):
         print("wide", name, k, got, want)
         assert abs(got - want) <= 1e-4 * max(1.0, abs(want)), k
     if "out/proportion" in g:
-        assert abs(float(out["proportion"]) - float(g["out/proportion"])) <= 1e-5
+        assert abs(float(out["proportion"]) - float(np.asarray(g["out/proportion"]).reshape(-1)[0])) <= 1e-5
     for k in [k for k in g if k.startswith("grad/")]:
         ref = torch.from_numpy(g[k])
         got = params[k[5:]].grad.cpu()
