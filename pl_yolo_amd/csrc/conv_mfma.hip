@@ -47,6 +47,7 @@ namespace plyolo {
 hipError_t conv_mfma_launch_s2(const void* convp, int BN, hipStream_t s);   // conv_mfma_s2.hip
 hipError_t conv_mfma_launch_t4(const void* convp, int BN, int red, hipStream_t s);   // conv_mfma_t4.hip
 hipError_t conv_mfma_launch_flat(const void* convp, int red, hipStream_t s);         // conv_mfma_flat.hip
+hipError_t conv_mfma_launch_rag(const void* convp, hipStream_t s);                   // conv_mfma_rag.hip
 // conv_mfma_red.hip: data-gradient instances that fold the upstream BatchNorm-backward reduction into their store loop
 // conv_s2d.hip: 3x3 stride-2 data gradient, the four parity classes on one staged tile
 int conv_s2d_th(int BN);
@@ -194,6 +195,15 @@ bool use_flat(ConvP& p, int ksize, int BN, int CK, bool plain_bf16) {
   return true;
 }
 
+// ragged column blocks (conv_mfma_rag.hip) for a 3x3 stride-1 launch of the 8 x 16 MF16 shape whose Cout leaves at most 64 channels behind
+// its last full 128-channel block (160 = 128 + 32, 320 = 256 + 64: YOLOX-x); PLYOLO_RAG=0: whole 128-channel blocks everywhere
+bool use_rag(const ConvP& p, int ksize, int BN, int CK, int TH, bool plain_bf16) {
+  const int on = getenv("PLYOLO_RAG") ? atoi(getenv("PLYOLO_RAG")) : 1;      // (read per call: the tests switch it)
+  if (!on || !plain_bf16 || ksize != 3 || p.si != 1 || p.so != 1 || BN != 128 || CK != 32 || TH != 8 || !(p.db && p.Cin > CK) || p.ablate) return false;
+  const int rem = p.Cout % 128;
+  return p.Cout > 128 && rem > 0 && rem <= 64;
+}
+
 void set_taps(ConvP& p) {
   p.taps_lo = 0ull;
   p.taps_hi = 0u;
@@ -303,6 +313,13 @@ int conv_mfma_fwd(const plyolo_conv_desc* d, const void* x, const void* wp, cons
     annotate(lab, 2.0 * M * d->Cout * d->Cin * 9.0, M * d->Cout * 2.0 + (double)d->N * d->H * d->W * d->Cin * 2.0);
     return submit(stream, [=](hipStream_t s) { return conv_mfma_launch_s2(&p, bn, s); });
   }
+  if (use_rag(p, d->ksize, BN, CK, TH, !f32 && !p.pre)) {
+    char lab[64];
+    snprintf(lab, sizeof(lab), "conv_mfma_fwd<BN128+%d,CK32,TH8>", p.Cout % 128 <= 32 ? 32 : 64);
+    const double M = (double)p.N * p.OHf * p.OWf;
+    annotate(lab, 2.0 * M * d->Cout * d->Cin * 9.0, M * d->Cout * 2.0 + (double)d->N * d->H * d->W * d->Cin * 2.0);
+    return submit(stream, [=](hipStream_t s) { return conv_mfma_launch_rag(&p, s); });
+  }
   if (use_flat(p, d->ksize, BN, CK, !f32 && !p.pre && !bias && !ep_coef && !ep_res)) {
     char lab[64];
     snprintf(lab, sizeof(lab), "conv_mfma_fwd<BN128,CK32,FLAT%d>", p.tw);
@@ -379,6 +396,13 @@ int conv_mfma_dgrad(const plyolo_conv_desc* d, const void* dy, const void* wpd, 
       });
     }
     if (red_fits) { *red_fits = (d->ksize == 3 && !p.ablate) ? conv_mfma_red_has(BN, CK, TH, 0) : 0; return 0; }
+    if (!(red && red->n > 0) && use_rag(p, d->ksize, BN, CK, TH, true)) {   // (a folded reduction keeps the whole-block RED instance)
+      char lab[64];
+      snprintf(lab, sizeof(lab), "conv_mfma_dgrad<BN128+%d,CK32,TH8>", p.Cout % 128 <= 32 ? 32 : 64);
+      const double Mo = (double)d->N * OH * OW, Mi = (double)d->N * d->H * d->W;
+      annotate(lab, 2.0 * Mo * d->Cout * d->Cin * 9.0, (Mo * Kc + Mi * d->Cin * (accumulate ? 2.0 : 1.0)) * 2.0);
+      return submit(stream, [=](hipStream_t s) { return conv_mfma_launch_rag(&p, s); });
+    }
     if (use_flat(p, d->ksize, BN, CK, true)) {
       const bool rf = red && red->n > 0;
       if (rf) p.red = *red;

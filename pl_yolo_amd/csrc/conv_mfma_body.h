@@ -126,7 +126,7 @@ DEVINL u32x4 pre_apply(u32x4 t, const float* __restrict__ pre, int pre_ld, int a
 // already use them), so a 20-wide map is covered at 100 % instead of 62 % (4 x 16 tiles) and a 40-wide one at 100 % instead of 83 %
 template <int BN, int CK, int TH, bool OUT_F32, int ABL, bool DB = false, bool PRE = false, bool MF16 = false, bool S2 = false, bool RED = false, bool BNB = false,
           bool FLAT = false>
-DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
+DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg, const int cb32 = -1) {
   static_assert(!RED || !OUT_F32, "RED instances store bf16 gradients");
   static_assert(!BNB || (!OUT_F32 && !PRE && !S2), "BNB instances: stride-1 bf16 data gradients");
   static_assert(!FLAT || (MF16 && !S2 && !BNB && !OUT_F32), "FLAT instances: stride-1 bf16 tiles on the 16x16x32 path");
@@ -163,8 +163,11 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg) {
   const int n = t2 / p.tiles_y;
   const int oy0 = tyi * (FLAT ? p.trows : TH), ox0 = txi * TW;
   const int iy0 = oy0 * p.si + p.iy_off, ix0 = ox0 * p.si + p.ix_off;
-  const int cout0 = blockIdx.y * BN;
-  const int nb = blockIdx.y * WN + wn;  // this wave's 32-channel block of the packed weights
+  // first 32-channel block of this workgroup's output columns: blockIdx.y column blocks of BN channels, or handed in by a kernel that mixes
+  // block widths (conv_mfma_rag.hip: full 128-channel blocks + one narrower block for the remainder of a 160- / 320-channel layer)
+  const int nb0 = cb32 >= 0 ? cb32 : (int)blockIdx.y * WN;
+  const int cout0 = nb0 * 32;
+  const int nb = nb0 + wn;  // this wave's 32-channel block of the packed weights
 
   int arow[MT];
 #pragma unroll

@@ -1,0 +1,51 @@
+// RAGGED output-channel blocks for the 3x3 stride-1 bf16 MFMA convolution (conv_mfma_body.h, v_mfma_f32_16x16x32_bf16 path, 8 x 16 tiles,
+// 32-channel double-buffered chunks).  The plain launch tiles Cout with 128-channel blocks: a 160-channel layer (YOLOX-x, 1.25 blocks)
+// runs two blocks of MFMAs for 160 / 256 = 62 % of useful columns, a 320-channel layer three for 83 % -- the waves beyond Cout multiply
+// clamped weights and store nothing.  Here the grid's last column block is a NARROWER instance of the same body (32 channels: four waves
+// share the tile's 128 pixels; 64: two by two), so only real columns are computed; both widths live in ONE kernel (blockIdx.y picks the
+// path) so that the blocks of one pixel tile still share their halo reads in L2 and the short blocks fill the tail of the launch.
+// Measured stand-alone, B = 16: 160 -> 160 @160x160 254 -> see profiles/r05_ab_ragged.txt.  Forward and plain data gradient (no RED fold:
+// the layers this serves lie above the fold's size limit).  Own translation unit: see conv_mfma_body.h.
+#define PLYOLO_CONV_PD 2
+#include "conv_mfma_body.h"
+
+namespace {
+
+template <int REM>
+__global__ __launch_bounds__(256, 2) void conv_mfma_rag_kernel(const ConvP p, const int nfull) {
+  if ((int)blockIdx.y < nfull)
+    conv_mfma_body<128, 32, 8, false, 0, true, false, true>(p, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y * 4);
+  else
+    conv_mfma_body<REM, 32, 8, false, 0, true, false, true>(p, (int)blockIdx.x, (int)gridDim.x, nfull * 4);
+}
+
+template <int REM>
+hipError_t launch_rag_inst(ConvP p, hipStream_t s) {
+  constexpr int CK = 32, TH = 8, BM = TH * TW;
+  constexpr int ROWB = CK * 2 + 32;
+  p.rowp = (p.ITW * ROWB + 255) & ~255;
+  p.bufsz = p.ITH * p.rowp;
+  auto epi = [](int BN) { return (size_t)BM * (BN * 2 + 16) + (size_t)(4 / (BN / 32)) * 2 * BN * 4; };
+  const size_t lds_main = 2 * (size_t)p.bufsz, lds_epi = epi(128) > epi(REM) ? epi(128) : epi(REM);
+  const size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+  auto kern = conv_mfma_rag_kernel<REM>;
+  if (hipError_t e = plyolo::ensure_dynamic_lds((const void*)kern, lds); e != hipSuccess) return e;
+  const int nfull = p.Cout / 128;
+  hipLaunchKernelGGL(kern, dim3(p.nmb, nfull + 1), dim3(256), lds, s, p, nfull);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+namespace plyolo {
+
+// `convp`: a ConvP prepared for the 8 x 16 stride-1 tiles (apply_tiles), 3x3, Cin > 32, double-buffered, bf16 output, no lazy input;
+// Cout = 128 * nfull + rem with nfull >= 1 and rem in (0, 64]
+hipError_t conv_mfma_launch_rag(const void* convp, hipStream_t s) {
+  const ConvP& p = *(const ConvP*)convp;
+  const int rem = p.Cout % 128;
+  if (p.Cout < 128 || rem == 0 || rem > 64) return hipErrorInvalidValue;
+  return rem <= 32 ? launch_rag_inst<32>(p, s) : launch_rag_inst<64>(p, s);
+}
+
+}  // namespace plyolo

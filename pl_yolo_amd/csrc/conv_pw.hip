@@ -95,8 +95,18 @@ template <int BN, bool BNB> constexpr int pw_bm() { return (BNB && BN >= 64) ? 6
 // RED: the bf16 store loop also folds the BatchNorm-backward reduction of the upstream unit(s) (bnred.h)
 // BACT (BNB instances): PLYOLO_ACT_SILU = the activation of the unit is SiLU at compile time (a switch on a run-time activation
 // inside the unrolled element loop of the loader compiles to a branch per element), -1 = p.bact
+// XCD-aware bijective remap (workgroups with equal blockIdx.x % 8 share an XCD's L2): every XCD gets a contiguous run
+// of tiles, BN blocks of one pixel tile adjacent
+DEVINL int pw_tile_of_block() {
+  const int nwg = (int)gridDim.x, bid = (int)blockIdx.x;
+  const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  return (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+}
+
+// tile: position in the XCD-aware order; mt_i: pixel tile; nb0: first 32-channel block of this workgroup's output columns (a kernel that
+// mixes block widths hands in something else than nblk * WN: conv_pw_rag_kernel below)
 template <int BN, int KC, bool OUT_F32, bool PRE, bool PIPE, bool BNB = false, bool RED = false, int BACT = -1>
-__global__ __launch_bounds__(256, BNB ? 3 : 2) void conv_pw_kernel(const PwP p) {
+DEVINL void conv_pw_body(const PwP& p, const int tile, const int nblk, const int mt_i, const int nb0) {
   static_assert(!RED || (!OUT_F32 && !PRE), "RED instances: bf16 data gradients");
   constexpr int BM = pw_bm<BN, BNB>();
   constexpr int WN = BN / 32, WM = 4 / WN, MT = BM / (32 * WM);
@@ -111,18 +121,9 @@ __global__ __launch_bounds__(256, BNB ? 3 : 2) void conv_pw_kernel(const PwP p) 
   const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 31, h = lane >> 5;
 
-  // XCD-aware bijective remap (workgroups with equal blockIdx.x % 8 share an XCD's L2): every XCD gets a contiguous run
-  // of tiles, BN blocks of one pixel tile adjacent
-  int tile;
-  {
-    const int nwg = (int)gridDim.x, bid = (int)blockIdx.x;
-    const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-    tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
-  }
-  const int nblk = tile % p.nnblk, mt_i = tile / p.nnblk;
   const int m0 = mt_i * BM;
-  const int cout0 = nblk * BN;
-  const int nb = nblk * WN + wn;   // this wave's 32-channel block of the packed weights
+  const int cout0 = nb0 * 32;
+  const int nb = nb0 + wn;   // this wave's 32-channel block of the packed weights
   const bool nb_ok = nb < p.nnb;
 
   f32x16 acc[MT];
@@ -474,6 +475,44 @@ __global__ __launch_bounds__(256, BNB ? 3 : 2) void conv_pw_kernel(const PwP p) 
   }
 }
 
+template <int BN, int KC, bool OUT_F32, bool PRE, bool PIPE, bool BNB = false, bool RED = false, int BACT = -1>
+__global__ __launch_bounds__(256, BNB ? 3 : 2) void conv_pw_kernel(const PwP p) {
+  const int tile = pw_tile_of_block();
+  const int nblk = tile % p.nnblk, mt_i = tile / p.nnblk;
+  conv_pw_body<BN, KC, OUT_F32, PRE, PIPE, BNB, RED, BACT>(p, tile, nblk, mt_i, nblk * (BN / 32));
+}
+
+// RAGGED output-channel blocks (plain bf16 forward / data gradient): nnblk - 1 full 128-channel blocks and ONE narrower block (REM = 32 or 64
+// channels) for what a 160- / 320-channel layer leaves behind them -- the plain launch runs a whole 128-channel block of MFMAs there for 32
+// / 64 real columns (YOLOX-x: every pointwise layer).  Both widths in one kernel: the blocks of a pixel tile stay neighbours on one XCD
+template <int REM, int KC>
+__global__ __launch_bounds__(256, 2) void conv_pw_rag_kernel(const PwP p) {
+  const int tile = pw_tile_of_block();
+  const int nblk = tile % p.nnblk, mt_i = tile / p.nnblk;
+  if (nblk + 1 < p.nnblk) conv_pw_body<128, KC, false, false, false>(p, tile, nblk, mt_i, nblk * 4);
+  else conv_pw_body<REM, KC, false, false, false>(p, tile, nblk, mt_i, nblk * 4);
+}
+
+template <int REM, int KC>
+hipError_t pw_launch_rag_inst(const PwP& p, hipStream_t s) {
+  constexpr int ROWB = KC * 2 + 16;
+  auto epi = [](int BN) { return (size_t)PW_BM * (BN * 2 + 16) + (size_t)(4 / (BN / 32)) * 2 * BN * 4; };
+  const size_t lds_main = (size_t)PW_BM * ROWB, lds_epi = epi(128) > epi(REM) ? epi(128) : epi(REM);
+  const size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+  auto kern = conv_pw_rag_kernel<REM, KC>;
+  if (hipError_t e = plyolo::ensure_dynamic_lds((const void*)kern, lds); e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(p.nmt * p.nnblk), dim3(256), lds, s, p);
+  return hipGetLastError();
+}
+
+// N = 128 * nfull + rem, nfull >= 1, 0 < rem <= 64, plain loop, 64-channel chunks, bf16 output, no lazy input (PLYOLO_RAG=0: off)
+bool pw_use_rag(const PwP& p, int BN, int KC, bool plain_bf16) {
+  const int on = getenv("PLYOLO_RAG") ? atoi(getenv("PLYOLO_RAG")) : 1;      // (read per call: the tests switch it)
+  const int rem = p.N % 128;
+  return on && plain_bf16 && BN == 128 && KC == 64 && !p.pipe && p.N > 128 && rem > 0 && rem <= 64;
+}
+hipError_t pw_launch_rag(const PwP& p, hipStream_t s) { return p.N % 128 <= 32 ? pw_launch_rag_inst<32, 64>(p, s) : pw_launch_rag_inst<64, 64>(p, s); }
+
 template <int BN, int KC, bool OUT_F32, bool PRE>
 hipError_t pw_launch_inst(const PwP& p, hipStream_t s) {
   constexpr int WN = BN / 32, WM = 4 / WN;
@@ -598,11 +637,14 @@ int conv_pw_fwd(const plyolo_conv_desc* d, const void* x, const void* wp, const 
   const bool f32 = d->y_f32 != 0, pre = p.pre != nullptr;
   int BN, KC;
   pw_tiles(p, f32, &BN, &KC);
+  const bool rag = pw_use_rag(p, BN, KC, !f32 && !pre);
   {
     char lab[64];
-    snprintf(lab, sizeof(lab), "conv_pw_fwd<BN%d,KC%d>%s%s", BN, KC, f32 ? "f32out" : "", pre ? "+bnact" : "");
+    if (rag) snprintf(lab, sizeof(lab), "conv_pw_fwd<BN128+%d,KC64>", p.N % 128 <= 32 ? 32 : 64);
+    else snprintf(lab, sizeof(lab), "conv_pw_fwd<BN%d,KC%d>%s%s", BN, KC, f32 ? "f32out" : "", pre ? "+bnact" : "");
     annotate(lab, 2.0 * p.M * (double)d->Cout * d->Cin, (double)p.M * (d->Cout * (f32 ? 4.0 : 2.0) + d->Cin * 2.0));
   }
+  if (rag) return submit(stream, [=](hipStream_t s) { return pw_launch_rag(p, s); });
   return submit(stream, [=](hipStream_t s) {
 #ifdef PLYOLO_OPTIN
     if (pre) return f32 ? pw_launch<true, true>(p, BN, KC, s) : pw_launch<false, true>(p, BN, KC, s);
@@ -631,11 +673,14 @@ int conv_pw_dgrad(const plyolo_conv_desc* d, const void* dy, const void* wpd, vo
   const bool use_red = red && red->n > 0;
   if (use_red && (p.pipe || !pw_red_has(BN, KC))) { set_error("conv_pw_dgrad: no RED instance for these tiles (ask plyolo_conv2d_dgrad_red_fits)"); return -1; }
   if (use_red) p.red = *red;
+  const bool rag = !use_red && pw_use_rag(p, BN, KC, true);      // (a folded reduction keeps the whole-block RED instance)
   {
     char lab[64];
-    snprintf(lab, sizeof(lab), "conv_pw_dgrad<BN%d,KC%d>%s", BN, KC, use_red ? "+bnred" : "");
+    if (rag) snprintf(lab, sizeof(lab), "conv_pw_dgrad<BN128+%d,KC64>", p.N % 128 <= 32 ? 32 : 64);
+    else snprintf(lab, sizeof(lab), "conv_pw_dgrad<BN%d,KC%d>%s", BN, KC, use_red ? "+bnred" : "");
     annotate(lab, 2.0 * p.M * (double)d->Cout * d->Cin, (double)p.M * (p.K + d->Cin * ((accumulate ? 2.0 : 1.0) + (use_red ? 1.0 : 0.0))) * 2.0);
   }
+  if (rag) return submit(stream, [=](hipStream_t s) { return pw_launch_rag(p, s); });
   if (use_red) return submit(stream, [=](hipStream_t s) { return pw_launch_red(p, BN, KC, s); });
   return submit(stream, [=](hipStream_t s) { return pw_launch<false, false>(p, BN, KC, s); });
 }

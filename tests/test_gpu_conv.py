@@ -55,6 +55,12 @@ SHAPES = [
     (1, 12, 40, 64, 192, 3, 1),     # Cout 192 = a block and a half; dgrad: dx 64 channels -> rectangular tiles
     (3, 8, 20, 96, 256, 3, 1),      # three input chunks, two output blocks
     (2, 20, 20, 256, 256, 3, 1),
+    # ragged output-channel blocks (conv_mfma_rag.hip): full 128-channel blocks + one 32- / 64-channel block, forward and data gradient
+    (2, 24, 24, 160, 160, 3, 1),    # 128 + 32 both ways (YOLOX-x dark3)
+    (1, 16, 48, 96, 288, 3, 1),     # 2 x 128 + 32 forward; the data gradient's 96 channels keep one whole block
+    (1, 24, 40, 192, 192, 3, 1),    # 128 + 64 both ways
+    (1, 20, 20, 320, 320, 1, 1),    # pointwise, 2 x 128 + 64 both ways (conv_pw_rag_kernel)
+    (2, 12, 16, 96, 160, 1, 1),     # pointwise, 128 + 32 forward
 ]
 
 
@@ -231,6 +237,40 @@ WGRAD1W_SHAPES = [(1, 13, 9, 160, 160), (2, 20, 20, 320, 160), (1, 25, 25, 640, 
                   (2, 16, 16, 1280, 640)]
 
 
+@pytest.mark.parametrize("shape", [(2, 24, 24, 160, 160, 3), (1, 16, 48, 96, 288, 3), (1, 24, 40, 192, 192, 3), (3, 17, 29, 64, 320, 3), (2, 20, 20, 320, 320, 1),
+                                   (2, 12, 16, 96, 160, 1), (1, 33, 7, 200, 448, 1)], ids=str)
+def test_ragged_channel_blocks_match_whole_blocks(shape, monkeypatch):
+    """conv_mfma_rag.hip / conv_pw_rag_kernel: the last output-channel block of a 160- / 320-channel layer as a 32- / 64-channel instance
+    instead of a whole 128-channel block.  Same contraction order per output element: forward, data gradient (plain and accumulating)
+    bit for bit against PLYOLO_RAG=0; the BatchNorm statistics (another fragment-to-wave assignment) to fp32 rounding."""
+    N, H, W, Cin, Cout, k = shape
+    torch.manual_seed(sum(shape))
+    x = hu.rnd_bf16(torch.randn(N, Cin, H, W, device=hu.DEV))
+    w = hu.rnd_bf16(torch.randn(Cout, Cin, k, k, device=hu.DEV) / (Cin * k * k) ** 0.5)
+    dy = hu.rnd_bf16(torch.randn(N, Cout, H, W, device=hu.DEV))
+    x_ld, y_ld = Cin + 8, Cout + 16
+    xm, dym = hu.to_nhwc(x, BF16, x_ld), hu.to_nhwc(dy, BF16, y_ld)
+    pk = hu.Packed(w, BF16)
+    d = hu.conv_desc(BF16, N, H, W, Cin, Cout, k, 1, x_ld, y_ld)
+    out = {}
+    for rag in ("0", "1"):
+        monkeypatch.setenv("PLYOLO_RAG", rag)
+        y = torch.full((N * H * W, y_ld), 3.0, dtype=torch.bfloat16, device=hu.DEV)
+        stats = torch.zeros(hu._lib.STAT_SLOTS, 2, Cout, dtype=torch.float64, device=hu.DEV)
+        call("plyolo_conv2d_fwd", C.byref(d), xm.data_ptr(), pk.wp.data_ptr(), None, y.data_ptr(), stats.data_ptr(), hu.stream())
+        dx = torch.full((N * H * W, x_ld), 2.0, dtype=torch.bfloat16, device=hu.DEV)
+        call("plyolo_conv2d_dgrad", C.byref(d), dym.data_ptr(), pk.wpd.data_ptr(), dx.data_ptr(), 0, hu.stream())
+        dxa = dx.clone()
+        call("plyolo_conv2d_dgrad", C.byref(d), dym.data_ptr(), pk.wpd.data_ptr(), dxa.data_ptr(), 1, hu.stream())
+        torch.cuda.synchronize()
+        out[rag] = (y, stats.sum(0), dx, dxa)
+    assert torch.equal(out["0"][0], out["1"][0])
+    assert torch.equal(out["0"][2], out["1"][2]) and torch.equal(out["0"][3], out["1"][3])
+    assert float((out["0"][1] - out["1"][1]).abs().max()) <= 1e-6 * float(out["0"][1].abs().max())
+    ref = _ref_conv(x, w, 1)
+    assert hu.relerr(hu.from_nhwc(out["1"][0], N, H, W, Cout), ref) <= 2.0 ** -7
+
+
 @pytest.mark.parametrize("shape", WGRAD1W_SHAPES, ids=str)
 @pytest.mark.parametrize("wgs", [0, 24])
 def test_wide_pointwise_wgrad_tiles(shape, wgs, monkeypatch):
@@ -280,7 +320,8 @@ def test_head_pred_backward_bf16(cout):
     print("head_pred_bwd", cout, "dgrad %.3g wgrad %.3g bias %.3g" % (e1, e2, e3))
     assert e1 <= 2.0 ** -6 and e2 <= 1e-4 and e3 <= 1e-4
 
-@pytest.mark.parametrize("shape", [(2, 20, 20, 128, 128, 3, 1), (2, 32, 32, 32, 64, 3, 2), (2, 16, 16, 64, 64, 1, 1), (16, 80, 80, 64, 128, 3, 1)], ids=str)
+@pytest.mark.parametrize("shape", [(2, 20, 20, 128, 128, 3, 1), (2, 32, 32, 32, 64, 3, 2), (2, 16, 16, 64, 64, 1, 1), (16, 80, 80, 64, 128, 3, 1),
+                                   (2, 24, 24, 160, 160, 3, 1), (1, 16, 16, 96, 320, 1, 1), (2, 12, 12, 64, 160, 1, 1), (1, 16, 24, 64, 192, 3, 1)], ids=str)
 @pytest.mark.parametrize("with_res", [False, True])
 def test_conv_fwd_fused_bn_act_inference(shape, with_res):
     """plyolo_conv2d_fwd_bn_act: eval-mode BaseConv (+ Bottleneck shortcut) in one launch ==
