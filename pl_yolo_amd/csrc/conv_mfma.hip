@@ -45,6 +45,7 @@ static inline hipError_t conv3ws_launch(const void*, const void*, void*, double*
 
 namespace plyolo {
 hipError_t conv_mfma_launch_s2(const void* convp, int BN, hipStream_t s);   // conv_mfma_s2.hip
+int conv_mfma_s2_ragged(int Cout);
 hipError_t conv_mfma_launch_t4(const void* convp, int BN, int red, hipStream_t s);   // conv_mfma_t4.hip
 hipError_t conv_mfma_launch_flat(const void* convp, int red, hipStream_t s);         // conv_mfma_flat.hip
 hipError_t conv_mfma_launch_rag(const void* convp, hipStream_t s);                   // conv_mfma_rag.hip
@@ -120,7 +121,54 @@ hipError_t launch_jobs_inst(ConvJobs jobs, hipStream_t s) {
   return hipGetLastError();
 }
 
+// ragged column blocks for the four-job stride-2 data gradient (see conv_mfma_rag.hip): full 128-channel blocks + a 32- / 64-channel block
+template <int REM>
+__global__ __launch_bounds__(256, 2) void conv_mfma_jobs_rag_kernel(const ConvJobs jobs, const int nfull) {
+  int j = 0;
+  for (int k = 1; k < 4; ++k)
+    if (k < jobs.n && (int)blockIdx.x >= jobs.start[k]) j = k;
+  if ((int)blockIdx.y < nfull)
+    conv_mfma_body<128, 32, 8, false, 0, true>(jobs.c[j], (int)blockIdx.x - jobs.start[j], jobs.start[j + 1] - jobs.start[j], (int)blockIdx.y * 4);
+  else
+    conv_mfma_body<REM, 32, 8, false, 0, true>(jobs.c[j], (int)blockIdx.x - jobs.start[j], jobs.start[j + 1] - jobs.start[j], nfull * 4);
+}
+
+// 1: launch_jobs runs these jobs with a ragged last block (128-channel blocks of 8-row tiles, 32-channel double-buffered chunks, every job
+// double-buffer capable, Cout = 128 * n + rem with n >= 1 and 0 < rem <= 64; PLYOLO_RAG=0: never)
+bool jobs_ragged(const ConvJobs& jobs, int BN, int CK, int TH) {
+  const int on = getenv("PLYOLO_RAG") ? atoi(getenv("PLYOLO_RAG")) : 1;
+  if (!on || BN != 128 || CK != 32 || TH != 8 || jobs.n < 1) return false;
+  const int Cout = jobs.c[0].Cout, rem = Cout % 128;
+  if (Cout <= 128 || rem == 0 || rem > 64) return false;
+  for (int j = 0; j < jobs.n; ++j)
+    if (!(jobs.c[j].db && jobs.c[j].si == 1 && jobs.c[j].Cin > CK && !jobs.c[j].ablate) || jobs.c[j].Cout != Cout) return false;
+  return true;
+}
+
+template <int REM>
+hipError_t launch_jobs_rag_inst(ConvJobs jobs, hipStream_t s) {
+  constexpr int CK = 32, TH = 8, BM = TH * TW, ROWB = CK * 2 + 16;
+  size_t lds = (size_t)BM * (128 * 2 + 16) + 1 * 2 * 128 * 4;       // epilogue staging of the 128-channel block (the larger one)
+  int total = 0;
+  for (int j = 0; j < jobs.n; ++j) {
+    ConvP& p = jobs.c[j];
+    p.rowp = (p.ITW * ROWB + 255) & ~255;
+    p.bufsz = p.ITH * p.rowp;
+    const size_t m2 = 2 * (size_t)p.bufsz;
+    lds = m2 > lds ? m2 : lds;
+    jobs.start[j] = total;
+    total += p.nmb;
+  }
+  jobs.start[jobs.n] = total;
+  auto kern = conv_mfma_jobs_rag_kernel<REM>;
+  if (hipError_t e = plyolo::ensure_dynamic_lds((const void*)kern, lds); e != hipSuccess) return e;
+  const int nfull = jobs.c[0].Cout / 128;
+  hipLaunchKernelGGL(kern, dim3(total, nfull + 1), dim3(256), lds, s, jobs, nfull);
+  return hipGetLastError();
+}
+
 hipError_t launch_jobs(const ConvJobs& jobs, int BN, int CK, int TH, hipStream_t s) {
+  if (jobs_ragged(jobs, BN, CK, TH)) return jobs.c[0].Cout % 128 <= 32 ? launch_jobs_rag_inst<32>(jobs, s) : launch_jobs_rag_inst<64>(jobs, s);
 #define PLY_JCASE(bn, ck)                                                \
   if (BN == bn && CK == ck) {                                            \
     if (TH == 16) return launch_jobs_inst<bn, ck, 16>(jobs, s);          \
@@ -308,7 +356,8 @@ int conv_mfma_fwd(const plyolo_conv_desc* d, const void* x, const void* wp, cons
     const int bn = d->Cout > 64 ? 128 : 64;
     apply_tiles(p, 3, 3, 4);
     char lab[64];
-    snprintf(lab, sizeof(lab), "conv_mfma_fwd_s2<BN%d,CK32,TH4>", bn);
+    if (bn == 128 && conv_mfma_s2_ragged(d->Cout)) snprintf(lab, sizeof(lab), "conv_mfma_fwd_s2<BN128+64,CK32,TH4>");
+    else snprintf(lab, sizeof(lab), "conv_mfma_fwd_s2<BN%d,CK32,TH4>", bn);
     const double M = (double)p.N * p.OHf * p.OWf;
     annotate(lab, 2.0 * M * d->Cout * d->Cin * 9.0, M * d->Cout * 2.0 + (double)d->N * d->H * d->W * d->Cin * 2.0);
     return submit(stream, [=](hipStream_t s) { return conv_mfma_launch_s2(&p, bn, s); });
@@ -514,7 +563,8 @@ int conv_mfma_dgrad(const plyolo_conv_desc* d, const void* dy, const void* wpd, 
   }
   {
     char lab[64];
-    snprintf(lab, sizeof(lab), "conv_mfma_dgrad_s2<BN%d,CK%d,TH%d>x%d%s", jBN, jCK, jTH, jobs.n, use_red ? "+bnred" : "");
+    if (!use_red && jobs_ragged(jobs, jBN, jCK, jTH)) snprintf(lab, sizeof(lab), "conv_mfma_dgrad_s2<BN128+%d,CK32,TH8>x%d", jobs.c[0].Cout % 128 <= 32 ? 32 : 64, jobs.n);
+    else snprintf(lab, sizeof(lab), "conv_mfma_dgrad_s2<BN%d,CK%d,TH%d>x%d%s", jBN, jCK, jTH, jobs.n, use_red ? "+bnred" : "");
     annotate(lab, fl, by);
   }
   const int bn = jBN, ck = jCK, th = jTH;

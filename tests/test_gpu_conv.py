@@ -61,6 +61,9 @@ SHAPES = [
     (1, 24, 40, 192, 192, 3, 1),    # 128 + 64 both ways
     (1, 20, 20, 320, 320, 1, 1),    # pointwise, 2 x 128 + 64 both ways (conv_pw_rag_kernel)
     (2, 12, 16, 96, 160, 1, 1),     # pointwise, 128 + 32 forward
+    (2, 34, 30, 80, 160, 3, 2),     # stride 2: forward 128 + (32 of a 64-channel block)
+    (1, 28, 36, 160, 320, 3, 2),    # stride 2: forward 2 x 128 + 64, data gradient (four parity jobs) 128 + 32
+    (1, 20, 24, 320, 320, 3, 2),    # stride 2: data gradient 2 x 128 + 64
 ]
 
 
@@ -237,25 +240,28 @@ WGRAD1W_SHAPES = [(1, 13, 9, 160, 160), (2, 20, 20, 320, 160), (1, 25, 25, 640, 
                   (2, 16, 16, 1280, 640)]
 
 
-@pytest.mark.parametrize("shape", [(2, 24, 24, 160, 160, 3), (1, 16, 48, 96, 288, 3), (1, 24, 40, 192, 192, 3), (3, 17, 29, 64, 320, 3), (2, 20, 20, 320, 320, 1),
-                                   (2, 12, 16, 96, 160, 1), (1, 33, 7, 200, 448, 1)], ids=str)
+@pytest.mark.parametrize("shape", [(2, 24, 24, 160, 160, 3, 1), (1, 16, 48, 96, 288, 3, 1), (1, 24, 40, 192, 192, 3, 1), (3, 17, 29, 64, 320, 3, 1), (2, 20, 20, 320, 320, 1, 1),
+                                   (2, 12, 16, 96, 160, 1, 1), (1, 33, 7, 200, 448, 1, 1), (2, 34, 30, 80, 160, 3, 2), (1, 28, 36, 160, 320, 3, 2), (1, 21, 25, 320, 192, 3, 2)], ids=str)
 def test_ragged_channel_blocks_match_whole_blocks(shape, monkeypatch):
-    """conv_mfma_rag.hip / conv_pw_rag_kernel: the last output-channel block of a 160- / 320-channel layer as a 32- / 64-channel instance
-    instead of a whole 128-channel block.  Same contraction order per output element: forward, data gradient (plain and accumulating)
-    bit for bit against PLYOLO_RAG=0; the BatchNorm statistics (another fragment-to-wave assignment) to fp32 rounding."""
-    N, H, W, Cin, Cout, k = shape
+    """conv_mfma_rag.hip / conv_pw_rag_kernel / the stride-2 forward and four-job data gradient: the last output-channel block of a 160- /
+    320-channel layer as a 32- / 64-channel instance instead of a whole 128-channel block.  Same contraction order per output element:
+    forward, data gradient (plain and accumulating) bit for bit against PLYOLO_RAG=0; the BatchNorm statistics (another
+    fragment-to-wave assignment) to fp32 rounding."""
+    N, H, W, Cin, Cout, k, st = shape
     torch.manual_seed(sum(shape))
     x = hu.rnd_bf16(torch.randn(N, Cin, H, W, device=hu.DEV))
     w = hu.rnd_bf16(torch.randn(Cout, Cin, k, k, device=hu.DEV) / (Cin * k * k) ** 0.5)
-    dy = hu.rnd_bf16(torch.randn(N, Cout, H, W, device=hu.DEV))
+    ref = _ref_conv(x, w, st)
+    OH, OW = ref.shape[2:]
+    dy = hu.rnd_bf16(torch.randn(N, Cout, OH, OW, device=hu.DEV))
     x_ld, y_ld = Cin + 8, Cout + 16
     xm, dym = hu.to_nhwc(x, BF16, x_ld), hu.to_nhwc(dy, BF16, y_ld)
     pk = hu.Packed(w, BF16)
-    d = hu.conv_desc(BF16, N, H, W, Cin, Cout, k, 1, x_ld, y_ld)
+    d = hu.conv_desc(BF16, N, H, W, Cin, Cout, k, st, x_ld, y_ld)
     out = {}
     for rag in ("0", "1"):
         monkeypatch.setenv("PLYOLO_RAG", rag)
-        y = torch.full((N * H * W, y_ld), 3.0, dtype=torch.bfloat16, device=hu.DEV)
+        y = torch.full((N * OH * OW, y_ld), 3.0, dtype=torch.bfloat16, device=hu.DEV)
         stats = torch.zeros(hu._lib.STAT_SLOTS, 2, Cout, dtype=torch.float64, device=hu.DEV)
         call("plyolo_conv2d_fwd", C.byref(d), xm.data_ptr(), pk.wp.data_ptr(), None, y.data_ptr(), stats.data_ptr(), hu.stream())
         dx = torch.full((N * H * W, x_ld), 2.0, dtype=torch.bfloat16, device=hu.DEV)
@@ -267,8 +273,7 @@ def test_ragged_channel_blocks_match_whole_blocks(shape, monkeypatch):
     assert torch.equal(out["0"][0], out["1"][0])
     assert torch.equal(out["0"][2], out["1"][2]) and torch.equal(out["0"][3], out["1"][3])
     assert float((out["0"][1] - out["1"][1]).abs().max()) <= 1e-6 * float(out["0"][1].abs().max())
-    ref = _ref_conv(x, w, 1)
-    assert hu.relerr(hu.from_nhwc(out["1"][0], N, H, W, Cout), ref) <= 2.0 ** -7
+    assert hu.relerr(hu.from_nhwc(out["1"][0], N, OH, OW, Cout), ref) <= 2.0 ** -7
 
 
 @pytest.mark.parametrize("shape", WGRAD1W_SHAPES, ids=str)
