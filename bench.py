@@ -407,6 +407,8 @@ def main():
         # yardstick, measured in this run on this box: the vendor library's best-case bf16 GEMM (a square 4096^3 torch.mm = hipBLASLt).
         # `peak` above stays the 2.5 PFLOP/s of the guide; this is what the matrix pipes deliver to a tuned library kernel here.
         try:
+            if args.no_cpu_baseline:      # (the profiling passes of tools/collect_evidence.sh: keep foreign kernels out of their counter sums)
+                raise RuntimeError("skipped with --no-cpu-baseline")
             ya = torch.randn(4096, 4096, device=dev, dtype=torch.bfloat16)
             yb = torch.randn(4096, 4096, device=dev, dtype=torch.bfloat16)
             for _ in range(3):
