@@ -49,6 +49,8 @@ int conv_mfma_s2_ragged(int Cout);
 hipError_t conv_mfma_launch_t4(const void* convp, int BN, int red, hipStream_t s);   // conv_mfma_t4.hip
 hipError_t conv_mfma_launch_flat(const void* convp, int red, hipStream_t s);         // conv_mfma_flat.hip
 hipError_t conv_mfma_launch_rag(const void* convp, hipStream_t s);                   // conv_mfma_rag.hip
+hipError_t conv_mfma_launch_n96(const void* convp, int CK, hipStream_t s);           // conv_mfma_rag.hip: one 96-channel block of three waves
+hipError_t conv_mfma_launch_jobs_n96(const void* jobsp, hipStream_t s);
 // conv_mfma_red.hip: data-gradient instances that fold the upstream BatchNorm-backward reduction into their store loop
 // conv_s2d.hip: 3x3 stride-2 data gradient, the four parity classes on one staged tile
 int conv_s2d_th(int BN);
@@ -167,7 +169,19 @@ hipError_t launch_jobs_rag_inst(ConvJobs jobs, hipStream_t s) {
   return hipGetLastError();
 }
 
+// 1: launch_jobs runs these jobs as one 96-channel block of three waves (65 .. 96 output channels; conditions as jobs_ragged)
+bool jobs_n96(const ConvJobs& jobs, int BN, int CK, int TH) {
+  const int on = getenv("PLYOLO_RAG") ? atoi(getenv("PLYOLO_RAG")) : 1;
+  if (!on || BN != 128 || CK != 32 || TH != 8 || jobs.n < 1) return false;
+  const int Cout = jobs.c[0].Cout;
+  if (Cout <= 64 || Cout > 96) return false;
+  for (int j = 0; j < jobs.n; ++j)
+    if (!(jobs.c[j].db && jobs.c[j].si == 1 && jobs.c[j].Cin > CK && !jobs.c[j].ablate) || jobs.c[j].Cout != Cout) return false;
+  return true;
+}
+
 hipError_t launch_jobs(const ConvJobs& jobs, int BN, int CK, int TH, hipStream_t s) {
+  if (jobs_n96(jobs, BN, CK, TH)) return plyolo::conv_mfma_launch_jobs_n96(&jobs, s);
   if (jobs_ragged(jobs, BN, CK, TH)) return jobs.c[0].Cout % 128 <= 32 ? launch_jobs_rag_inst<32>(jobs, s) : launch_jobs_rag_inst<64>(jobs, s);
 #define PLY_JCASE(bn, ck)                                                \
   if (BN == bn && CK == ck) {                                            \
@@ -250,6 +264,14 @@ bool use_rag(const ConvP& p, int ksize, int BN, int CK, int TH, bool plain_bf16)
   if (!on || !plain_bf16 || ksize != 3 || p.si != 1 || p.so != 1 || BN != 128 || CK != 32 || TH != 8 || !(p.db && p.Cin > CK) || p.ablate) return false;
   const int rem = p.Cout % 128;
   return p.Cout > 128 && rem > 0 && rem <= 64;
+}
+
+// one 96-channel block of three waves (conv_mfma_rag.hip) for a 3x3 stride-1 launch with 65 .. 96 output channels (YOLOX-x: 80): the MF16
+// instance (32-channel double-buffered chunks, Cin > 32) or the single-chunk one of a first convolution (Cin <= 16); PLYOLO_RAG=0: off
+bool use_n96(const ConvP& p, int ksize, int BN, int CK, int TH, bool plain_bf16) {
+  const int on = getenv("PLYOLO_RAG") ? atoi(getenv("PLYOLO_RAG")) : 1;
+  if (!on || !plain_bf16 || ksize != 3 || p.si != 1 || p.so != 1 || BN != 128 || TH != 8 || p.ablate || p.Cout <= 64 || p.Cout > 96) return false;
+  return (CK == 32 && p.db && p.Cin > CK) || (CK == 16 && p.Cin <= 16);
 }
 
 void set_taps(ConvP& p) {
@@ -362,6 +384,14 @@ int conv_mfma_fwd(const plyolo_conv_desc* d, const void* x, const void* wp, cons
     annotate(lab, 2.0 * M * d->Cout * d->Cin * 9.0, M * d->Cout * 2.0 + (double)d->N * d->H * d->W * d->Cin * 2.0);
     return submit(stream, [=](hipStream_t s) { return conv_mfma_launch_s2(&p, bn, s); });
   }
+  if (use_n96(p, d->ksize, BN, CK, TH, !f32 && !p.pre)) {
+    char lab[64];
+    snprintf(lab, sizeof(lab), "conv_mfma_fwd<BN96,CK%d,TH8>", CK);
+    const double M = (double)p.N * p.OHf * p.OWf;
+    annotate(lab, 2.0 * M * d->Cout * d->Cin * 9.0, M * d->Cout * 2.0 + (double)d->N * d->H * d->W * d->Cin * 2.0);
+    const int ck = CK;
+    return submit(stream, [=](hipStream_t s) { return conv_mfma_launch_n96(&p, ck, s); });
+  }
   if (use_rag(p, d->ksize, BN, CK, TH, !f32 && !p.pre)) {
     char lab[64];
     snprintf(lab, sizeof(lab), "conv_mfma_fwd<BN128+%d,CK32,TH8>", p.Cout % 128 <= 32 ? 32 : 64);
@@ -445,6 +475,14 @@ int conv_mfma_dgrad(const plyolo_conv_desc* d, const void* dy, const void* wpd, 
       });
     }
     if (red_fits) { *red_fits = (d->ksize == 3 && !p.ablate) ? conv_mfma_red_has(BN, CK, TH, 0) : 0; return 0; }
+    if (!(red && red->n > 0) && use_n96(p, d->ksize, BN, CK, TH, true)) {
+      char lab[64];
+      snprintf(lab, sizeof(lab), "conv_mfma_dgrad<BN96,CK%d,TH8>", CK);
+      const double Mo = (double)d->N * OH * OW, Mi = (double)d->N * d->H * d->W;
+      annotate(lab, 2.0 * Mo * d->Cout * d->Cin * 9.0, (Mo * Kc + Mi * d->Cin * (accumulate ? 2.0 : 1.0)) * 2.0);
+      const int ck = CK;
+      return submit(stream, [=](hipStream_t s) { return conv_mfma_launch_n96(&p, ck, s); });
+    }
     if (!(red && red->n > 0) && use_rag(p, d->ksize, BN, CK, TH, true)) {   // (a folded reduction keeps the whole-block RED instance)
       char lab[64];
       snprintf(lab, sizeof(lab), "conv_mfma_dgrad<BN128+%d,CK32,TH8>", p.Cout % 128 <= 32 ? 32 : 64);
@@ -563,7 +601,8 @@ int conv_mfma_dgrad(const plyolo_conv_desc* d, const void* dy, const void* wpd, 
   }
   {
     char lab[64];
-    if (!use_red && jobs_ragged(jobs, jBN, jCK, jTH)) snprintf(lab, sizeof(lab), "conv_mfma_dgrad_s2<BN128+%d,CK32,TH8>x%d", jobs.c[0].Cout % 128 <= 32 ? 32 : 64, jobs.n);
+    if (!use_red && jobs_n96(jobs, jBN, jCK, jTH)) snprintf(lab, sizeof(lab), "conv_mfma_dgrad_s2<BN96,CK32,TH8>x%d", jobs.n);
+    else if (!use_red && jobs_ragged(jobs, jBN, jCK, jTH)) snprintf(lab, sizeof(lab), "conv_mfma_dgrad_s2<BN128+%d,CK32,TH8>x%d", jobs.c[0].Cout % 128 <= 32 ? 32 : 64, jobs.n);
     else snprintf(lab, sizeof(lab), "conv_mfma_dgrad_s2<BN%d,CK%d,TH%d>x%d%s", jBN, jCK, jTH, jobs.n, use_red ? "+bnred" : "");
     annotate(lab, fl, by);
   }

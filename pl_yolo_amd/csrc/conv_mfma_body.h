@@ -134,6 +134,8 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg, const i
   static_assert(!S2 || (DB && !MF16 && !PRE && !OUT_F32), "S2 instances: double-buffered bf16 tiles");
   constexpr int BM = TH * TW;
   constexpr int WN = BN / 32, WM = 4 / WN, MT = BM / (32 * WM);
+  constexpr int NT = 64 * WN * WM;     // threads per workgroup: 256, or 192 for the 96-channel block (three waves, one 32-channel block each)
+  static_assert(BN % 32 == 0 && WM >= 1, "whole 32-channel blocks per wave");
   constexpr int MT16 = FLAT ? BM / (16 * WM) : 2 * MT;   // MF16: 16-pixel fragments per wave ...
   constexpr int HALF16 = (MT16 + 1) / 2, HALF16B = MT16 - HALF16;   // ... and per software-pipeline half (5 = 3 + 2 on the 80-pixel FLAT tile)
   // pixel m of a tile -> (row, column) inside the tile
@@ -257,9 +259,10 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg, const i
   // vectors is the same for every Cin chunk, so it is computed ONCE per tile: in-kernel stamps showed the halo
   // phases at ~10k cycles each, most of it the per-vector index arithmetic (a runtime division by the tile
   // width, bounds tests, 64-bit addresses) repeated for the loads, again for the LDS stores, and per chunk.
-  constexpr int HVT = S2 ? ((2 * TH + 1) * 33 * CV + 255) / 256 : (FLAT ? (6 * 42 * CV + 255) / 256 : ((TH + 2) * 18 * CV + 255) / 256);   // vectors per thread of a 3x3 halo tile
+  constexpr int HVT = S2 ? ((2 * TH + 1) * 33 * CV + NT - 1) / NT : (FLAT ? (6 * 42 * CV + NT - 1) / NT : ((TH + 2) * 18 * CV + NT - 1) / NT);   // vectors per thread of a 3x3 halo tile
+  static_assert(NT % CV == 0, "a thread always owns the same channel vector");
   const int nvec = p.ITH * p.ITW * CV;
-  const bool fastpath = nvec <= HVT * 256;                 // stride-2 forward tiles take the generic loop
+  const bool fastpath = nvec <= HVT * NT;                 // stride-2 forward tiles take the generic loop
   const bf16_t* xn = p.x + (size_t)n * p.H * p.W * p.x_ld;
   const int cvt = tid % CV;                                // 256 % CV == 0: a thread always owns the same channel vector
   int goff[HVT], loff[HVT];
@@ -267,7 +270,7 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg, const i
   if (fastpath) {
 #pragma unroll
     for (int v = 0; v < HVT; ++v) {
-      const int idx = tid + v * 256;
+      const int idx = tid + v * NT;
       goff[v] = -1;
       loff[v] = -1;
       if (idx < nvec) {
@@ -385,7 +388,7 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg, const i
       float* tab = (float*)(smem + p.btab);
       const int Kp = p.Cin;
       const double cnt = (double)p.N * p.H * p.W;
-      for (int ch = tid; ch < Kp; ch += 256) {
+      for (int ch = tid; ch < Kp; ch += NT) {
         double su = 0.0, suz = 0.0;
 #pragma unroll
         for (int sl = 0; sl < PLYOLO_STAT_SLOTS; ++sl) {
@@ -415,11 +418,11 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg, const i
   // generic loader (stride-2 forward tiles): batches of HV 16-byte loads in flight before the first LDS write
   auto halo_generic = [&](const int c0) {
     constexpr int HV = 6;
-    for (int base = 0; base < nvec; base += HV * 256) {
+    for (int base = 0; base < nvec; base += HV * NT) {
       u32x4 hv[HV];
 #pragma unroll
       for (int v = 0; v < HV; ++v) {
-        const int idx = base + tid + v * 256;
+        const int idx = base + tid + v * NT;
         u32x4 val = {0u, 0u, 0u, 0u};
         if (idx < nvec) {
           const int pix = idx / CV, cv = idx - pix * CV;
@@ -434,7 +437,7 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg, const i
       }
 #pragma unroll
       for (int v = 0; v < HV; ++v) {
-        const int idx = base + tid + v * 256;
+        const int idx = base + tid + v * NT;
         if (idx < nvec) {
           const int pix = idx / CV, cv = idx - pix * CV;
           const int iy = pix / p.ITW, ix = pix - iy * p.ITW;
@@ -775,7 +778,7 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg, const i
     typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
     float* y = (float*)p.y;
     constexpr int VPR4 = BN / 4;
-    for (int idx = tid; idx < BM * VPR4; idx += 256) {
+    for (int idx = tid; idx < BM * VPR4; idx += NT) {
       const int m = idx / VPR4, v = idx - m * VPR4;
       const int a = oy0 + (m >> 4), b = ox0 + (m & 15), co = cout0 + v * 4;
       if (a < p.OHt && b < p.OWt && co < p.Cout) {
@@ -802,8 +805,8 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg, const i
     if constexpr (RED) {
       // same rows, same stores; every thread owns ONE channel vector (256 % VPR == 0) and NIT rows.  The upstream unit's z vectors
       // (and the old dx rows of an accumulating launch) are requested up front -- one memory round trip for the whole loop
-      constexpr int NIT = BM * VPR / 256;
-      static_assert(256 % VPR == 0 && (BM * VPR) % 256 == 0, "RED: whole rows per thread");
+      constexpr int NIT = BM * VPR / NT;
+      static_assert(NT % VPR == 0 && (BM * VPR) % NT == 0, "RED: whole rows per thread");
       const int v = tid % VPR, co = cout0 + v * 8;
       BnRedThread rt;
       bnred_init(rt, p.red, co);
@@ -818,7 +821,7 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg, const i
       bool ok[NIP];
 #pragma unroll
       for (int it = 0; it < NIP; ++it) {
-        const int m = (tid + (ps * NIP + it) * 256) / VPR;
+        const int m = (tid + (ps * NIP + it) * NT) / VPR;
         int rr_, cc_;
         tile_rc(m, rr_, cc_);
         const int a = oy0 + rr_, b = ox0 + cc_;
@@ -830,7 +833,7 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg, const i
       }
 #pragma unroll
       for (int it = 0; it < NIP; ++it) {
-        const int m = (tid + (ps * NIP + it) * 256) / VPR;
+        const int m = (tid + (ps * NIP + it) * NT) / VPR;
         if (ok[it]) {
           u32x4 val = *(const u32x4*)(smem + m * SROW + v * 16);
           if (p.accumulate) val = add_bf16x8(old[it], val);
@@ -840,9 +843,9 @@ DEVINL void conv_mfma_body(const ConvP& p, const int bid, const int nwg, const i
       }
       }
       __syncthreads();   // every thread is done with the staging rows: the fold reuses them
-      bnred_flush<256, VPR>(rt, p.red, cout0, (float*)smem, tid, tile % PLYOLO_STAT_SLOTS);
+      bnred_flush<NT, VPR>(rt, p.red, cout0, (float*)smem, tid, tile % PLYOLO_STAT_SLOTS);
     } else {
-    for (int idx = tid; idx < BM * VPR; idx += 256) {
+    for (int idx = tid; idx < BM * VPR; idx += NT) {
       const int m = idx / VPR, v = idx - m * VPR;
       int rr_, cc_;
       tile_rc(m, rr_, cc_);

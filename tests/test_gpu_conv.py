@@ -64,6 +64,10 @@ SHAPES = [
     (2, 34, 30, 80, 160, 3, 2),     # stride 2: forward 128 + (32 of a 64-channel block)
     (1, 28, 36, 160, 320, 3, 2),    # stride 2: forward 2 x 128 + 64, data gradient (four parity jobs) 128 + 32
     (1, 20, 24, 320, 320, 3, 2),    # stride 2: data gradient 2 x 128 + 64
+    # one 96-channel block of three waves (65 .. 96 output channels)
+    (2, 40, 48, 80, 80, 3, 1),      # YOLOX-x dark2 bottleneck: both ways
+    (2, 32, 32, 16, 80, 3, 1),      # YOLOX-x stem: a single 16-channel chunk
+    (1, 30, 34, 96, 96, 3, 1),      # YOLOX-m width
 ]
 
 
@@ -241,10 +245,11 @@ WGRAD1W_SHAPES = [(1, 13, 9, 160, 160), (2, 20, 20, 320, 160), (1, 25, 25, 640, 
 
 
 @pytest.mark.parametrize("shape", [(2, 24, 24, 160, 160, 3, 1), (1, 16, 48, 96, 288, 3, 1), (1, 24, 40, 192, 192, 3, 1), (3, 17, 29, 64, 320, 3, 1), (2, 20, 20, 320, 320, 1, 1),
-                                   (2, 12, 16, 96, 160, 1, 1), (1, 33, 7, 200, 448, 1, 1), (2, 34, 30, 80, 160, 3, 2), (1, 28, 36, 160, 320, 3, 2), (1, 21, 25, 320, 192, 3, 2)], ids=str)
+                                   (2, 12, 16, 96, 160, 1, 1), (1, 33, 7, 200, 448, 1, 1), (2, 34, 30, 80, 160, 3, 2), (1, 28, 36, 160, 320, 3, 2), (1, 21, 25, 320, 192, 3, 2),
+                                   (2, 40, 48, 80, 80, 3, 1), (2, 32, 32, 16, 80, 3, 1), (1, 30, 34, 96, 96, 3, 1), (3, 18, 22, 72, 96, 3, 2)], ids=str)
 def test_ragged_channel_blocks_match_whole_blocks(shape, monkeypatch):
     """conv_mfma_rag.hip / conv_pw_rag_kernel / the stride-2 forward and four-job data gradient: the last output-channel block of a 160- /
-    320-channel layer as a 32- / 64-channel instance instead of a whole 128-channel block.  Same contraction order per output element:
+    320-channel layer as a 32- / 64-channel instance instead of a whole 128-channel block, and a 65 .. 96-channel layer as one block of three waves.  Same contraction order per output element:
     forward, data gradient (plain and accumulating) bit for bit against PLYOLO_RAG=0; the BatchNorm statistics (another
     fragment-to-wave assignment) to fp32 rounding."""
     N, H, W, Cin, Cout, k, st = shape
