@@ -306,10 +306,14 @@ def test_bench_rccl_path_single_rank():
     """bench.py under torchrun with one rank and PLYOLO_BENCH_FORCE_DDP=1: RCCL process-group init, weight
     broadcast, the gradient all-reduce after every backward and the barriers of the timing protocol all execute
     on this GPU (the multi-GPU runs are the driver's; this keeps their code path from rotting)."""
-    import json, subprocess, sys
+    import json, socket, subprocess, sys
     env = dict(os.environ, PLYOLO_BENCH_FORCE_DDP="1", MASTER_ADDR="127.0.0.1")
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))        # a port that is free now (a fixed one can still sit in another test's or another user's hands)
+    port = sk.getsockname()[1]
+    sk.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", "29531", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
            "--batch", "4", "--size", "320", "--no-cpu-baseline"]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
