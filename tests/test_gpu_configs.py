@@ -318,6 +318,34 @@ def test_wide_models_vs_reference_fixture(name):
 
 
 # ---------------------------------------------------------------------------------------------- cfg3
+@pytest.mark.parametrize("name", ["yolox_m", "yolox_tiny", "yolox_x"])
+def test_ragged_channel_blocks_end_to_end(name, monkeypatch):
+    """The reference's other widths through the column tiling that fits them (csrc/conv_mfma_rag.hip, conv_pw_rag_kernel): yolox_m (96 / 192 / 384 /
+    768 channels: one 96-channel block of three waves, 128 + 64), yolox_tiny (96 / 192 / 384), yolox_x (80 / 160 / 320).  EVAL forward (BatchNorm
+    folded into the convolution epilogues, every concat pitch / merged pair / shortcut of the real graph) with PLYOLO_RAG=1 (default) against
+    PLYOLO_RAG=0: bit-identical predictions.  In training mode the two differ only in how the fp32 partials of the BatchNorm statistics are grouped
+    -- which a randomly initialised 100-layer network amplifies to tens of percent at its outputs, exactly as forcing 64-channel whole blocks does
+    (tools/diag_ragged.py, profiles/r05_ab_ragged.txt) -- so the training step is checked for what it must be: finite, every parameter reached."""
+    cfg = _cfg("yolox", name)
+    imgs, labels = _batch(2, 128, 4321, num_gt=6)
+    imgs, labels = imgs.to(hu.DEV), labels.to(hu.DEV)
+    res = {}
+    for rag in ("0", "1"):
+        monkeypatch.setenv("PLYOLO_RAG", rag)
+        model, sd0 = _build(cfg, "bf16")
+        model.eval()
+        with torch.no_grad():
+            res[rag] = model(imgs, labels).float().cpu()
+        if rag == "1":
+            losses, g, trained = _step(model, sd0, imgs, labels)
+            assert all(np.isfinite(v) for v in losses.values()) and bool(torch.isfinite(g).all())
+            missing = [n for n, p in model.named_parameters() if p.grad is None and not _dead(n)]
+            assert not missing, missing[:5]
+        del model
+    assert bool(torch.isfinite(res["1"]).all())
+    assert torch.equal(res["0"], res["1"])
+
+
 @pytest.mark.parametrize("repconv", [False, True])
 def test_cfg3_yolov7_640_b32(repconv):
     cfg = _cfg("yolov7", "yolov7", repconv)
