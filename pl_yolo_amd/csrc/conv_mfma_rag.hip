@@ -4,8 +4,10 @@
 // clamped weights and store nothing.  Here the grid's last column block is a NARROWER instance of the same body (32 channels: four waves
 // share the tile's 128 pixels; 64: two by two), so only real columns are computed; both widths live in ONE kernel (blockIdx.y picks the
 // path) so that the blocks of one pixel tile still share their halo reads in L2 and the short blocks fill the tail of the launch.
-// Measured stand-alone, B = 16: 160 -> 160 @160x160 254 -> see profiles/r05_ab_ragged.txt.  Forward and plain data gradient (no RED fold:
-// the layers this serves lie above the fold's size limit).  Own translation unit: see conv_mfma_body.h.
+// Measured stand-alone, B = 16 (profiles/r05_ab_ragged.txt): 160 -> 160 @160x160 260 -> 204 us, 320 -> 320 @80x80 192 -> 169, @160x160 752 -> 680;
+// outputs bit-identical to whole blocks.  Forward and plain data gradient (a folded BatchNorm reduction keeps the whole-block RED instance: the
+// layers this serves lie above the fold's size limit).  Below: one 96-channel block of three waves for layers with 65 .. 96 output channels.
+// Own translation unit: see conv_mfma_body.h.
 #define PLYOLO_CONV_PD 2
 #include "conv_mfma_body.h"
 

@@ -7,7 +7,7 @@ import os, sys, torch, yaml, numpy as np
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, "tests")
 import pl_yolo_amd
 def run(env, name, size=128, B=2, train=True):
-    for k in ("PLYOLO_RAG", "PLYOLO_FLAT", "PLYOLO_PAIR", "PLYOLO_FORCE_BN"): os.environ.pop(k, None)
+    for k in ("PLYOLO_RAG", "PLYOLO_FORCE_BN"): os.environ.pop(k, None)
     os.environ.update(env)
     cfg = yaml.safe_load(open("configs/model/yolox/%s.yaml" % name))
     torch.manual_seed(96)
