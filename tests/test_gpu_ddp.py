@@ -111,9 +111,11 @@ def test_rccl_allreduce_bucket_through_the_c_abi():
     assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
     lib = _lib.lib()
     assert lib.plyolo_rccl_set_library(path.encode()) == 0
+    torch.manual_seed(11)
     g = torch.randn(1 << 20, device=hu.DEV)
     want = g.clone()
     st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())      # randn / clone were queued on the current stream: without this the side stream may double g before the clone has read it
     with torch.cuda.stream(st):
         g.mul_(2.0)                                                  # queued before the collective on the same stream
         _lib.call("plyolo_rccl_allreduce_bucket", comm, g.data_ptr() + 4 * 1024, g.numel() - 2048, 1, st.cuda_stream)
