@@ -47,7 +47,13 @@ extern "C" {
 #define PLYOLO_ACT_GELU 5 /* nn.GELU(): 0.5 x (1 + erf(x / sqrt 2)), models/layers/activation.py:16-17 */
 
 /* ---------------------------------------------------------------- probes */
-int plyolo_version(void);            /* ABI version */
+/* ABI version: bumped whenever a struct of this header changes size or layout, or an entry point changes its arguments (the structs
+ * carry no size field).  A host compiled against this header must find plyolo_version() == PLYOLO_ABI_VERSION in the library it loads
+ * and refuse to run otherwise -- e.g. plyolo_bn_bwd_fuse grew `fwd_to` / `fwd_ld` in version 5: an older host calling
+ * plyolo_conv2d_dgrad_bn on a 3x3 unit would make the library read past its struct.  Hosts zero-initialise every struct they pass.
+ *   1-4  rounds 1-4 (not tracked per change)    5  plyolo_bn_bwd_fuse.fwd_to / fwd_ld    6  this header */
+#define PLYOLO_ABI_VERSION 6
+int plyolo_version(void);            /* == PLYOLO_ABI_VERSION of the header the library was built from */
 const char* plyolo_arch(void);       /* "gfx950" */
 /* What this build of the library carries beyond the default kernels: PLYOLO_BUILD_OPTIN = the measured-slower opt-in paths
  * (lazy-input instances behind plyolo_conv_desc.x_coef, the weights-stationary 3x3 kernel, the tap-row split of the weight

@@ -152,6 +152,8 @@ class FmtImage(C.Structure):   # plyolo_fmt_image
 _vp, _i, _f, _d, _sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
 _P = C.POINTER
 
+ABI_VERSION = 6   # == PLYOLO_ABI_VERSION of include/plyolo.h: the ctypes mirrors below follow THAT header's struct layouts
+
 # name -> (restype, argtypes); every symbol include/plyolo.h declares
 SIGNATURES = {
     "plyolo_version": (_i, []),
@@ -289,6 +291,9 @@ def lib():
             fn = getattr(l, name)  # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
+        if l.plyolo_version() != ABI_VERSION:
+            raise PlyoloError("libplyolo_hip.so has ABI version %d, this package binds version %d (include/plyolo.h: PLYOLO_ABI_VERSION): "
+                              "rebuild the library (`make -C pl_yolo_amd/csrc`)" % (l.plyolo_version(), ABI_VERSION))
         _lib = l
     return _lib
 

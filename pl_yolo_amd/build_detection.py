@@ -94,14 +94,7 @@ class OneStageD(nn.Module):
         out = R.train_step(r, x, labels)       # fp32 loss vector, differentiable
         if isinstance(self.loss, YOLOv7Loss):  # yolov7_loss.py:150-153 returns {"loss": tensor[1]}
             return {"loss": out[0:1]}
-        return {
-            "loss": out[0],
-            "loss_iou": out[1],
-            "loss_obj": out[2],
-            "loss_cls": out[3],
-            "loss_l1": out[7] if self.loss.use_l1 else 0.0,   # the python float 0.0 without use_l1, as the reference (yolox_loss.py:159-160)
-            "proportion": out[6].detach(),
-        }
+        return self.loss.loss_dict(out)
 
 
 # ---- plugin registry (names as in the reference YAMLs) --------------------------

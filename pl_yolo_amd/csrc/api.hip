@@ -128,7 +128,7 @@ using namespace plyolo;
 
 extern "C" {
 
-int plyolo_version(void) { return 1; }
+int plyolo_version(void) { return PLYOLO_ABI_VERSION; }
 int plyolo_build_flags(void) {
   int f = 0;
 #ifdef PLYOLO_OPTIN

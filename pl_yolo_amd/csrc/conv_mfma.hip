@@ -44,7 +44,7 @@ static inline hipError_t conv3ws_launch(const void*, const void*, void*, double*
 }
 
 namespace plyolo {
-hipError_t conv_mfma_launch_s2(const void* convp, int BN, hipStream_t s);   // conv_mfma_s2.hip
+hipError_t conv_mfma_launch_s2(const void* convp, int BN, int ragged, hipStream_t s);   // conv_mfma_s2.hip
 int conv_mfma_s2_ragged(int Cout);
 hipError_t conv_mfma_launch_t4(const void* convp, int BN, int red, hipStream_t s);   // conv_mfma_t4.hip
 hipError_t conv_mfma_launch_flat(const void* convp, int red, hipStream_t s);         // conv_mfma_flat.hip
@@ -180,9 +180,11 @@ bool jobs_n96(const ConvJobs& jobs, int BN, int CK, int TH) {
   return true;
 }
 
-hipError_t launch_jobs(const ConvJobs& jobs, int BN, int CK, int TH, hipStream_t s) {
-  if (jobs_n96(jobs, BN, CK, TH)) return plyolo::conv_mfma_launch_jobs_n96(&jobs, s);
-  if (jobs_ragged(jobs, BN, CK, TH)) return jobs.c[0].Cout % 128 <= 32 ? launch_jobs_rag_inst<32>(jobs, s) : launch_jobs_rag_inst<64>(jobs, s);
+// `mode`: decided ONCE where the launch is recorded (PLYOLO_RAG is read there; a recorded launch replays what its label says):
+// 0 whole 128-channel blocks, 1 ragged last block (jobs_ragged), 2 one 96-channel block (jobs_n96)
+hipError_t launch_jobs(const ConvJobs& jobs, int BN, int CK, int TH, int mode, hipStream_t s) {
+  if (mode == 2) return plyolo::conv_mfma_launch_jobs_n96(&jobs, s);
+  if (mode == 1) return jobs.c[0].Cout % 128 <= 32 ? launch_jobs_rag_inst<32>(jobs, s) : launch_jobs_rag_inst<64>(jobs, s);
 #define PLY_JCASE(bn, ck)                                                \
   if (BN == bn && CK == ck) {                                            \
     if (TH == 16) return launch_jobs_inst<bn, ck, 16>(jobs, s);          \
@@ -378,11 +380,12 @@ int conv_mfma_fwd(const plyolo_conv_desc* d, const void* x, const void* wp, cons
     const int bn = d->Cout > 64 ? 128 : 64;
     apply_tiles(p, 3, 3, 4);
     char lab[64];
-    if (bn == 128 && conv_mfma_s2_ragged(d->Cout)) snprintf(lab, sizeof(lab), "conv_mfma_fwd_s2<BN128+64,CK32,TH4>");
+    const int rag = bn == 128 && conv_mfma_s2_ragged(d->Cout);      // decided here, once: the recorded launch replays what its label says
+    if (rag) snprintf(lab, sizeof(lab), "conv_mfma_fwd_s2<BN128+64,CK32,TH4>");
     else snprintf(lab, sizeof(lab), "conv_mfma_fwd_s2<BN%d,CK32,TH4>", bn);
     const double M = (double)p.N * p.OHf * p.OWf;
     annotate(lab, 2.0 * M * d->Cout * d->Cin * 9.0, M * d->Cout * 2.0 + (double)d->N * d->H * d->W * d->Cin * 2.0);
-    return submit(stream, [=](hipStream_t s) { return conv_mfma_launch_s2(&p, bn, s); });
+    return submit(stream, [=](hipStream_t s) { return conv_mfma_launch_s2(&p, bn, rag, s); });
   }
   if (use_n96(p, d->ksize, BN, CK, TH, !f32 && !p.pre)) {
     char lab[64];
@@ -599,16 +602,17 @@ int conv_mfma_dgrad(const plyolo_conv_desc* d, const void* dy, const void* wpd, 
     for (int j = 0; j < jobs.n; ++j) jobs.c[j].red = *red;
     by += (double)d->N * d->H * d->W * d->Cin * 2.0;
   }
+  const int jmode = use_red ? 0 : (jobs_n96(jobs, jBN, jCK, jTH) ? 2 : (jobs_ragged(jobs, jBN, jCK, jTH) ? 1 : 0));
   {
     char lab[64];
-    if (!use_red && jobs_n96(jobs, jBN, jCK, jTH)) snprintf(lab, sizeof(lab), "conv_mfma_dgrad_s2<BN96,CK32,TH8>x%d", jobs.n);
-    else if (!use_red && jobs_ragged(jobs, jBN, jCK, jTH)) snprintf(lab, sizeof(lab), "conv_mfma_dgrad_s2<BN128+%d,CK32,TH8>x%d", jobs.c[0].Cout % 128 <= 32 ? 32 : 64, jobs.n);
+    if (jmode == 2) snprintf(lab, sizeof(lab), "conv_mfma_dgrad_s2<BN96,CK32,TH8>x%d", jobs.n);
+    else if (jmode == 1) snprintf(lab, sizeof(lab), "conv_mfma_dgrad_s2<BN128+%d,CK32,TH8>x%d", jobs.c[0].Cout % 128 <= 32 ? 32 : 64, jobs.n);
     else snprintf(lab, sizeof(lab), "conv_mfma_dgrad_s2<BN%d,CK%d,TH%d>x%d%s", jBN, jCK, jTH, jobs.n, use_red ? "+bnred" : "");
     annotate(lab, fl, by);
   }
   const int bn = jBN, ck = jCK, th = jTH;
   if (use_red) return submit(stream, [=](hipStream_t s) { return conv_mfma_launch_jobs_red(&jobs, bn, ck, th, s); });
-  return submit(stream, [=](hipStream_t s) { return launch_jobs(jobs, bn, ck, th, s); });
+  return submit(stream, [=](hipStream_t s) { return launch_jobs(jobs, bn, ck, th, jmode, s); });
 }
 
 

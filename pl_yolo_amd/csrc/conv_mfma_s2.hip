@@ -59,10 +59,11 @@ int conv_mfma_s2_ragged(int Cout) {
   return on && Cout > 128 && rem > 0 && rem <= 64;
 }
 
-// `convp`: a ConvP prepared for 4-row tiles (ITH 9, ITW 33, si 2)
-hipError_t conv_mfma_launch_s2(const void* convp, int BN, hipStream_t s) {
+// `convp`: a ConvP prepared for 4-row tiles (ITH 9, ITW 33, si 2); `ragged`: conv_mfma_s2_ragged(Cout), evaluated by the caller where
+// the launch is recorded
+hipError_t conv_mfma_launch_s2(const void* convp, int BN, int ragged, hipStream_t s) {
   const ConvP& p = *(const ConvP*)convp;
-  if (BN == 128 && conv_mfma_s2_ragged(p.Cout)) return launch_s2_rag(p, s);
+  if (BN == 128 && ragged) return launch_s2_rag(p, s);
   if (BN == 128) return launch_s2_inst<128>(p, s);
   if (BN == 64) return launch_s2_inst<64>(p, s);
   return hipErrorInvalidValue;

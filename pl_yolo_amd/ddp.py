@@ -17,6 +17,7 @@ The exchange is bucketed and overlapped with the backward plan:
 Single bucket / no overlap remains available as GradAllReduce.all_reduce_ (and is what the bucketed path must equal bit
 for bit: tests/test_ddp_cpu.py)."""
 import os
+import warnings
 
 import torch
 import torch.distributed as dist
@@ -276,11 +277,30 @@ class BucketSchedule:
             raise PlyoloError("gradient exchange failed inside the backward plan: %r" % (e,))
 
 
+def _check_hw_queues():
+    """The plans run three launch lanes (+ RCCL's own stream) on the runtime's hardware queues.  Measured on MI355X / ROCm 7.2
+    (INTEGRATION.md): GPU_MAX_HW_QUEUES = 4 (the runtime's default) is the optimum, 3: +3.5 %, 2: +22 %, and FIVE OR
+    MORE HALVE the throughput (9.26 -> 16.9 ms per step).  A launch script that exports a larger value -- common advice for
+    multi-stream RCCL jobs -- would cost every rank a factor of two: say so once, loudly, where the data-parallel run starts."""
+    v = os.environ.get("GPU_MAX_HW_QUEUES")
+    if v is None:
+        return
+    try:
+        n = int(v)
+    except ValueError:
+        return
+    if n != 4:
+        warnings.warn("GPU_MAX_HW_QUEUES=%d: pl_yolo_amd's launch plans are tuned for the runtime's default of 4 hardware queues "
+                      "(measured: 3 queues +3.5 %% step time, 2 +22 %%, 5 or more about 2x slower); unset it or set it to 4" % n,
+                      RuntimeWarning, stacklevel=3)
+
+
 def attach(model, group=None):
     """Make `model` (a pl_yolo_amd OneStageD) average its gradients across ranks inside every backward, and start from
     rank 0's weights."""
     if not dist.is_initialized():
         raise RuntimeError("torch.distributed is not initialised")
+    _check_hw_queues()
     r = model.runner()
     dev = next(model.parameters()).device
     if not r._adopted_ok(dev):

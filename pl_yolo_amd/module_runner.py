@@ -8,9 +8,11 @@ one traced session per (input shapes, dtype, mode), NHWC staging at the API edge
 mode with gradients enabled -- one autograd node whose backward replays the recorded backward plan.  It is the boundary for
 callers that mix these modules with foreign ones; the detector's hot path never comes through here.
 
-No CPU path: a CPU tensor or a missing library raises PlyoloError.  Loss modules keep refusing a direct call: their contract
-`(list, labels) -> dict` has no caller in the reference outside OneStageD (PL_Modules/build_detection.py:46-53)."""
+No CPU path: a CPU tensor or a missing library raises PlyoloError.  The loss plugins have their own stand-alone entry
+(`loss(list, labels) -> dict | Tensor`, pl_yolo_amd/losses.py).  Eval mode has no backward: an input that requires a gradient raises
+(the reference's modules would propagate it), parameters that do are warned about once."""
 import os
+import warnings
 
 import torch
 
@@ -220,7 +222,10 @@ class ModuleRunner:
     def session(self, xs, image, in_is_list, dtype, training, want_grad):
         device = xs[0].device
         self._flat(device)
-        key = (tuple(tuple(x.shape) for x in xs), image, in_is_list, dtype, training, want_grad)
+        # the recorded backward holds the gradient ADDRESS of every parameter that required a gradient at trace time (`grad_ptr_of`,
+        # `used_params`): freezing / unfreezing a parameter afterwards is another session
+        mask = tuple(p.requires_grad for p in self.m.parameters()) if want_grad else ()
+        key = (tuple(tuple(x.shape) for x in xs), image, in_is_list, dtype, training, want_grad, mask)
         s = self.sessions.get(key)
         if s is None:
             s = self._build([tuple(x.shape) for x in xs], image, in_is_list, dtype, training, want_grad, device)
@@ -299,6 +304,18 @@ def run(module, *args):
     dtype = _dtype_of(module)
     params = [p for p in module.parameters() if p.requires_grad]
     want_grad = module.training and torch.is_grad_enabled() and (any(t.requires_grad for t in xs) or len(params) > 0)
+    if not module.training and torch.is_grad_enabled():
+        # eval mode runs the inference plan (BatchNorm folded into the convolution epilogues, no `z` kept): it has no backward.  The
+        # reference's nn.Modules do propagate gradients in eval mode (running statistics as constants) -- a caller who needs that
+        # (a frozen `neck.eval()` between a trainable backbone and head) must not get detached outputs silently:
+        if any(t.requires_grad for t in xs):
+            raise PlyoloError("%s is in eval mode and its input requires a gradient: the eval-mode launch plan has no backward, the "
+                              "gradient would be cut here; call it in train() mode, or under torch.no_grad() / with detached inputs if "
+                              "no gradient is wanted" % type(module).__name__)
+        if params and not module.__dict__.get("_warned_eval_grad"):
+            module.__dict__["_warned_eval_grad"] = True
+            warnings.warn("%s called in eval mode with gradients enabled: its outputs carry no grad_fn (the parameters get no gradient "
+                          "from this call); wrap the call in torch.no_grad() to silence this" % type(module).__name__, stacklevel=3)
     s = r.session(xs, image, in_is_list, dtype, module.training, want_grad)
     if want_grad:
         outs = list(_ModuleStep.apply(r, s, len(xs), *xs, *params))

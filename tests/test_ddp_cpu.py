@@ -118,3 +118,19 @@ def test_grad_allreduce_world2(tmp_path):
     assert contiguous == 1.0 and nbuckets >= 3, "buckets must tile the live range"
     assert hooks == nbuckets, "one host hook per bucket in the data-parallel backward plan"
     assert dead_behind == 1.0
+
+
+def test_attach_warns_about_a_hardware_queue_count_off_the_optimum(monkeypatch):
+    """five or more hardware queues halve the step rate; a launch script that exports
+    GPU_MAX_HW_QUEUES != 4 is told so where the data-parallel run starts."""
+    import warnings
+    from pl_yolo_amd import ddp
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        ddp._check_hw_queues()                       # unset: the runtime's default (4), silent
+        monkeypatch.setenv("GPU_MAX_HW_QUEUES", "4")
+        ddp._check_hw_queues()
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "8")
+    with pytest.warns(RuntimeWarning, match="GPU_MAX_HW_QUEUES=8"):
+        ddp._check_hw_queues()

@@ -346,6 +346,47 @@ def test_ragged_channel_blocks_end_to_end(name, monkeypatch):
     assert torch.equal(res["0"], res["1"])
 
 
+RAG_WARM_LOSS_TOL, RAG_WARM_COS, RAG_WARM_STATS = 2e-2, 0.98, 5e-2
+
+
+@pytest.mark.parametrize("name", ["yolox_tiny", "yolox_m"])
+def test_ragged_channel_blocks_training_step_on_warm_weights(name, monkeypatch):
+    """the TRAINING path of the ragged / 96-channel column blocks (BatchNorm-statistics epilogue of the 32 / 64 / 96-channel
+    blocks, merged pairs, folded reductions) at network level, on something stable: the net is first warmed by 30 bf16 SGD steps (the bf16
+    mode is deterministic; a warm net no longer amplifies the regrouped fp32 partials of the statistics the way a random initialisation
+    does), then ONE step from that state with PLYOLO_RAG=0 (whole 128-channel blocks) and with PLYOLO_RAG=1: loss, every BatchNorm's
+    running statistics after the step, and the gradients must agree within the bf16 band.  A wrong statistics epilogue, a mis-indexed
+    short block or a stale slab would show as O(1)."""
+    from pl_yolo_amd.trainer import Trainer
+    cfg = _cfg("yolox", name)
+    monkeypatch.setenv("PLYOLO_RAG", "1")
+    warm, _ = _build(cfg, "bf16")
+    data = [_batch(4, 128, 700 + i, num_gt=5, max_gt=8) for i in range(3)]
+    tr = Trainer(warm, learning_rate=0.01, momentum=0.9, warmup=0.1, total_steps=300, ema=False)
+    losses = [float(tr.train_step(*data[i % 3])["loss"].detach()) for i in range(30)]
+    assert all(np.isfinite(losses)) and sum(losses[-5:]) < sum(losses[:5])
+    state = {k: v.detach().clone() for k, v in warm.state_dict().items()}
+    del warm, tr
+    imgs, labels = _batch(4, 128, 799, num_gt=5, max_gt=8)
+    res = {}
+    for rag in ("0", "1"):
+        monkeypatch.setenv("PLYOLO_RAG", rag)
+        m, _ = _build(cfg, "bf16")
+        ls, g, trained = _step(m, state, imgs, labels)
+        stats = {k: v.detach().double().cpu().clone() for k, v in m.state_dict().items() if k.endswith(("running_mean", "running_var"))}
+        res[rag] = (ls, g.double().cpu(), [n for n, _ in trained], stats)
+        del m
+    (l0, g0, n0, s0), (l1, g1, n1, s1) = res["0"], res["1"]
+    assert n0 == n1 and set(s0) == set(s1)
+    cs = float((g0 * g1).sum() / (g0.norm() * g1.norm()))
+    worst = max(float((s0[k] - s1[k]).abs().max() / (s0[k].abs().max() + 1e-6)) for k in s0)
+    print("ragged blocks, warm %s: loss RAG=0 %.5f RAG=1 %.5f | all-parameter gradient cosine %.6f | worst running-statistic deviation %.3g"
+          " | warm-up %.3f -> %.3f" % (name, l0["loss"], l1["loss"], cs, worst, sum(losses[:5]) / 5, sum(losses[-5:]) / 5))
+    assert abs(l0["loss"] - l1["loss"]) <= RAG_WARM_LOSS_TOL * abs(l0["loss"])
+    assert cs >= RAG_WARM_COS
+    assert worst <= RAG_WARM_STATS
+
+
 @pytest.mark.parametrize("repconv", [False, True])
 def test_cfg3_yolov7_640_b32(repconv):
     cfg = _cfg("yolov7", "yolov7", repconv)

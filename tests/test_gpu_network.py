@@ -341,6 +341,30 @@ def test_bench_two_gpus_rccl():
     assert all(0 <= e < t for e, t in zip(pr["exposed_comm_ms_per_step"], pr["ms_per_step"]))
 
 
+def test_bench_two_ranks_share_one_gpu_dry_run():
+    """`PLYOLO_BENCH_SHARE_GPU=1 python bench.py --gpus 2` on a ONE-GPU box: two real processes share the device and gloo carries the
+    exchange -- the whole N-rank path of the bench (self-launch, weight broadcast, bucket hooks in the backward plan, barrier +
+    max-over-ranks timing, per_rank.exposed_comm_ms_per_step gathered over the ranks) runs end to end across process boundaries.  A
+    plumbing check: the line is marked `dry_run_shared_gpu` and its value is no scaling figure."""
+    import json, subprocess, sys
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("a multi-GPU node runs the real thing (test_bench_two_gpus_rccl)")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--no-cpu-baseline",
+           "--model", "yolox_test", "--size", "64", "--batch", "2"]
+    env = dict(os.environ, PLYOLO_BENCH_SHARE_GPU="1")
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["dry_run_shared_gpu"] is True and out["value"] > 0 and np.isfinite(out["config"]["loss"])
+    assert out["config"]["global_batch"] == 4 and "gloo" in out["config"]["parallelism"]
+    pr = out["per_rank"]
+    assert len(pr["ms_per_step"]) == 2 and all(v > 0 for v in pr["ms_per_step"])
+    assert len(pr["exposed_comm_ms_per_step"]) == 2 and all(0 <= e < t for e, t in zip(pr["exposed_comm_ms_per_step"], pr["ms_per_step"]))
+    # without the switch the same command refuses instead of benchmarking one GPU twice
+    r2 = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, PLYOLO_BENCH_SHARE_GPU="0"), capture_output=True, text=True, timeout=300)
+    assert r2.returncode != 0 and "exposes" in r2.stderr
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # bf16 GRADIENT parity: the bf16-emulating oracle run through its backward, and the warm-weights fixture
 # ----------------------------------------------------------------------------------------------------------------

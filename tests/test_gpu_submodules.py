@@ -7,7 +7,7 @@ models/heads/decoupled_head.py:77-95).
     gradient, running statistics) through `module(x)` + `backward` in the fp32 parity mode, and the output in bf16;
   * backbone -> neck -> head called one after the other == the raw maps of the whole detector (same launches, another trace), and the
     gradients of a functional of those maps == the detector's (labels=None path);
-  * the loss plugins and CPU tensors keep refusing loudly."""
+  * CPU tensors and malformed inputs keep refusing loudly (the loss plugins' own call: tests/test_gpu_loss_plugins.py)."""
 import os
 
 import numpy as np
@@ -167,5 +167,5 @@ def test_submodule_refusals():
         m.conv = torch.nn.Conv2d(6, 16, 3, 1, 1, bias=False).to(hu.DEV)
         m(torch.zeros(1, 6, 8, 8, device=hu.DEV))        # 6 channels: no whole channel vector
     model = pl_yolo_amd.build_model(_cfg("yolox_test"), 3).to(hu.DEV)
-    with pytest.raises(RuntimeError):
+    with pytest.raises(PlyoloError, match="strides"):       # one map for a three-level loss
         model.loss([torch.zeros(1, 8, 4, 4, device=hu.DEV)], torch.zeros(1, 1, 5, device=hu.DEV))

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     l = _lib.lib()
-    assert l.plyolo_version() == 1 and l.plyolo_arch() == b"gfx950"
+    assert l.plyolo_version() == _lib.ABI_VERSION == 6 and l.plyolo_arch() == b"gfx950"   # include/plyolo.h: PLYOLO_ABI_VERSION
 
 
 def test_error_reporting_across_the_abi():

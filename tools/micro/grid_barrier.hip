@@ -6,8 +6,11 @@
 // Compared with: the same work split over two launches on one stream.   hipcc --offload-arch=gfx950 -O3 -o grid_barrier grid_barrier.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+__device__ int g_sleep = 2;     // round 6: 0 = spin without s_sleep (set from argv[1])
 
 __device__ __forceinline__ bool grid_barrier(unsigned* counter, unsigned target, unsigned* err) {
   __syncthreads();
@@ -15,8 +18,9 @@ __device__ __forceinline__ bool grid_barrier(unsigned* counter, unsigned target,
   if (threadIdx.x == 0) {
     __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     int spins = 0;
+    const int sl = g_sleep;
     while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(2);
+      if (sl) __builtin_amdgcn_s_sleep(2);
       if (++spins > (1 << 22)) { *err = 1u; ok = false; break; }   // bounded: a hung GPU costs the lease
     }
   }
@@ -57,15 +61,20 @@ __global__ __launch_bounds__(256) void k_stats(double* slots, int C, unsigned* c
   }
 }
 
-int main() {
+int main(int argc, char** argv) {
   const int C = 128;
+  // round 6 (review item 4): the workgroup counts of the 20x20 layers (64 ... 200) beside the 256 / 512 / 768 of round 5;
+  // argv[1] = 0: spin without s_sleep
+  const int sleep_on = argc > 1 ? atoi(argv[1]) : 2;
+  CK(hipMemcpyToSymbol(HIP_SYMBOL(g_sleep), &sleep_on, sizeof(int)));
+  printf("spin %s s_sleep\n", sleep_on ? "with" : "without");
   unsigned *counter, *err; double* slots; float *sink, *out;
   CK(hipMalloc(&counter, 4)); CK(hipMalloc(&err, 4)); CK(hipMalloc(&slots, 8 * 2 * C * 8)); CK(hipMalloc(&sink, 4)); CK(hipMalloc(&out, 2 * C * 4));
   CK(hipMemset(err, 0, 4));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   int nb = 0; CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_barriers, 256, 0));
   printf("occupancy: %d workgroups of 256 threads per CU\n", nb);
-  for (int G : {256, 512, 768}) {
+  for (int G : {32, 64, 100, 128, 200, 256, 512, 768}) {
     float t0 = 0.f;
     for (int K : {0, 1, 2, 4, 8}) {
       float best = 1e9;
