@@ -1,7 +1,7 @@
 """pl_yolo_amd -- MI355X-native (gfx950) YOLOX detection path behind the pl_YOLO
 plugin API.  Host logic in Python on PyTorch-ROCm tensors, compute in
 libplyolo_hip.so (hand-written HIP) through the C ABI of include/plyolo.h."""
-# Streams and hardware queues (MI355X / ROCm 7.2; tools/ab_r3h.sh, profiles/r03_stream_layout.txt).  A plan replays on three
+# Streams and hardware queues (MI355X / ROCm 7.2; tools/ab/ab_r3h.sh, profiles/r03_stream_layout.txt).  A plan replays on three
 # streams of its OWN -- main lane, weight-gradient lane, side lane (csrc/api.hip: issue_lanes; PLYOLO_OWN_MAIN=0 puts lane 0 on the
 # caller's stream instead) -- created back to back, so they sit on distinct hardware queues whatever the application created before;
 # the caller's stream only forks into / joins from the plan.  ROCclr maps a process's streams onto GPU_MAX_HW_QUEUES queues, default 4,

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# PLYOLO_LIB: another build of the same library (same-box A/Bs of two builds, tools/ab_lib.sh); the default is the in-tree one
+# PLYOLO_LIB: another build of the same library (same-box A/Bs of two builds, tools/ab/ab_lib.sh); the default is the in-tree one
 LIB_PATH = os.environ.get("PLYOLO_LIB") or os.path.join(_HERE, "libplyolo_hip.so")
 
 BF16, F32 = 0, 1

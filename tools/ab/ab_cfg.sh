@@ -1,5 +1,5 @@
 #!/bin/bash
-# Same-box A/B of environment variants on another config: tools/ab_cfg.sh <tag> <reps> "<bench args>" "ENV.." "ENV.." ...  ("-" = default)
+# Same-box A/B of environment variants on another config: tools/ab/ab_cfg.sh <tag> <reps> "<bench args>" "ENV.." "ENV.." ...  ("-" = default)
 tag=$1; reps=$2; args=$3; shift 3
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O
 out=$O/${tag}_ab.txt; : > $out

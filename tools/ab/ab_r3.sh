@@ -1,5 +1,5 @@
 # same-box A/B, round 3: the round-2 tree (git worktree _r2 at 0f77289, built separately, not kept in the tree) against the
-# current tree and its lane-placement switches.   usage: bash tools/ab_r3.sh [alternations] [steps]
+# current tree and its lane-placement switches.   usage: bash tools/ab/ab_r3.sh [alternations] [steps]
 n=${1:-2}; steps=${2:-60}
 run() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', round(d['value']), round(d['ms_per_step'],3))"; }
 for i in $(seq 1 $n); do

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Same-box A/B of environment variants (round 4): tools/ab_r4.sh <tag> <reps> "ENV1=.. ENV2=.." "ENV3=.." ...
+# Same-box A/B of environment variants (round 4): tools/ab/ab_r4.sh <tag> <reps> "ENV1=.. ENV2=.." "ENV3=.." ...
 # ("-" = the default environment).  Per variant: <reps> alternating bench lines (ms/step), then one plan profile + lane times.
 tag=$1; reps=$2; shift 2
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O

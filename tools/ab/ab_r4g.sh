@@ -1,6 +1,6 @@
 #!/bin/bash
 # Same-box A/B of the current tree against the round-3 head (_r3/: git worktree at 2f83f23, built separately): YOLOX-s default bench,
-# alternating, then the other BASELINE configs.   tools/ab_r4g.sh <reps>   (run through gpurun)
+# alternating, then the other BASELINE configs.   tools/ab/ab_r4g.sh <reps>   (run through gpurun)
 reps=${1:-3}
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O
 out=$O/r04_ab_vs_r3.txt; : > $out

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Same-box A/B of environment variants on any bench configuration (round 5):
-#   tools/ab_r5.sh <tag> <reps> "<bench args>" "ENV1=.. ENV2=.." "ENV3=.." ...     ("-" = the default environment)
+#   tools/ab/ab_r5.sh <tag> <reps> "<bench args>" "ENV1=.. ENV2=.." "ENV3=.." ...     ("-" = the default environment)
 # Per variant: <reps> alternating bench lines (ms/step); PROFILE=1 adds one per-family plan profile per variant.
 tag=$1; reps=$2; bargs=$3; shift 3
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O

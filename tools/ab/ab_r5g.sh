@@ -1,7 +1,7 @@
 #!/bin/bash
 # Same-box A/B of the current tree against the round-4 head (_r4/: git worktree at e08942a, built separately; it is listed in
 # .gpurunignore -- take it out for this call): YOLOX-s default bench, alternating, then the other BASELINE configs.
-#   tools/ab_r5g.sh <reps>   (run through gpurun)
+#   tools/ab/ab_r5g.sh <reps>   (run through gpurun)
 reps=${1:-3}
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O
 out=$O/r05_ab_vs_r4.txt; : > $out

@@ -14,7 +14,7 @@ timeout 600 python bench.py > $O/r06_bench0.json 2> $O/r06_bench0.err
 tail -1 $O/r06_bench0.json | cut -c1-300
 OPT=$R/_optin/libplyolo_hip_optin.so
 if [ -f $OPT ]; then
-  STEPS=10 WARMUP=3 timeout 1500 tools/ab_r5.sh r06_lazy_x 2 "--model yolox_x --size 1280 --batch 16" "-" "PLYOLO_LIB=$OPT" "PLYOLO_LIB=$OPT PLYOLO_LAZY=1" "PLYOLO_LIB=$OPT PLYOLO_LAZY=2" \
+  STEPS=10 WARMUP=3 timeout 1500 tools/ab/ab_r5.sh r06_lazy_x 2 "--model yolox_x --size 1280 --batch 16" "-" "PLYOLO_LIB=$OPT" "PLYOLO_LIB=$OPT PLYOLO_LAZY=1" "PLYOLO_LIB=$OPT PLYOLO_LAZY=2" \
      "PLYOLO_LIB=$OPT PLYOLO_LAZY=1 PLYOLO_BNRED_MAX_MB=400" "PLYOLO_BNRED_MAX_MB=400" | tail -12
-  STEPS=15 WARMUP=3 timeout 1200 tools/ab_r5.sh r06_lazy_v7 2 "--model yolov7 --size 640 --batch 32" "-" "PLYOLO_LIB=$OPT" "PLYOLO_LIB=$OPT PLYOLO_LAZY=1" "PLYOLO_LIB=$OPT PLYOLO_LAZY=2" | tail -8
+  STEPS=15 WARMUP=3 timeout 1200 tools/ab/ab_r5.sh r06_lazy_v7 2 "--model yolov7 --size 640 --batch 32" "-" "PLYOLO_LIB=$OPT" "PLYOLO_LIB=$OPT PLYOLO_LAZY=1" "PLYOLO_LIB=$OPT PLYOLO_LAZY=2" | tail -8
 fi
