@@ -9,7 +9,8 @@ the eval decode on `self.training`.  Two ways in:
     on the caller's list of raw NCHW head maps -- train: the reference's dict, differentiable w.r.t. the maps (one autograd node
     around plyolo_yolox_loss_fwd / _bwd, plyolo_yolov7_loss_fwd / _bwd); eval: the decoded [B, A, 5+C] tensor
     (plyolo_yolox_eval_decode / plyolo_yolov7_eval_decode).  API edge, not the hot path: the maps are staged NCHW -> level-major NHWC
-    fp32 and the gradient comes back the same way.
+    fp32 and the gradient comes back the same way.  The reference's side effects on its arguments are kept: YOLOXLoss leaves DECODED
+    boxes in channels 0..3 of the caller's maps (its decode writes through a view), YOLOv7Loss replaces the entries of the caller's list.
 
 The arithmetic is in csrc/yolox_loss.hip / csrc/yolov7_loss.hip; there is no CPU path (a CPU tensor raises PlyoloError)."""
 import ctypes as C
@@ -83,39 +84,75 @@ def _stage_labels(hd, labels):
         hd.labels.view(hd.B, -1, 5)[:, :labels.shape[1]].copy_(labels.detach())
 
 
-def _map_grads(hd, maps):
+def _map_grads(hd, dtypes):
     drawv = hd.draw.view(hd.rows, hd.nch)
     out = []
-    for (h, w), r0, m in zip(hd.sizes, hd.lvl_row, maps):
+    for (h, w), r0, dt in zip(hd.sizes, hd.lvl_row, dtypes):
         n = hd.B * h * w
-        out.append(drawv[r0:r0 + n].view(hd.B, h, w, hd.nch).permute(0, 3, 1, 2).to(m.dtype).contiguous())
+        out.append(drawv[r0:r0 + n].view(hd.B, h, w, hd.nch).permute(0, 3, 1, 2).to(dt).contiguous())
     return out
+
+
+def _decode_boxes_in_place(maps, strides):
+    """The side effect of the reference's YOLOXLoss.decode (yolox_loss.py:204-219) on the CALLER's tensors: `pred.view(...).permute(0, 1, 3,
+    4, 2).reshape(B, h*w, -1)` of an NCHW map with one anchor is a VIEW (h and w merge), so `pred[..., :2] = (pred[..., :2] + grid) *
+    stride` and `pred[..., 2:4] = exp(pred[..., 2:4]) * stride` write THROUGH into channels 0..3 of the head maps it was handed -- after
+    `loss(maps, labels)` the caller's maps hold decoded boxes (cx, cy, w, h in pixels), in training and in eval mode alike.  Mirrored here
+    (outside autograd: the returned gradient is the one with respect to the raw values, which is where the reference's CopySlices
+    node sends it too).  Grid: the reference builds it with meshgrid(arange(h), arange(w), indexing='xy') and re-views the (w, h, 2) stack
+    as (h, w, 2) -- cell k = gy*w + gx gets (k mod h, k div h), which is (gx, gy) on square maps only (the non-square quirk the loss kernels
+    reproduce as well, loss fixture E)."""
+    with torch.no_grad():
+        for m, s in zip(maps, strides):
+            h, w = m.shape[2], m.shape[3]
+            k = torch.arange(h * w, device=m.device)
+            gx = (k % h).view(1, h, w).to(m.dtype)
+            gy = torch.div(k, h, rounding_mode="floor").view(1, h, w).to(m.dtype)
+            m[:, 0] = (m[:, 0] + gx) * s
+            m[:, 1] = (m[:, 1] + gy) * s
+            m[:, 2:4] = torch.exp(m[:, 2:4]) * s
+
+
+def _check_in_place_allowed(maps, who):
+    for m in maps:
+        if m.requires_grad and m.is_leaf and torch.is_grad_enabled():
+            # what torch says when the reference's decode hits such a tensor
+            raise PlyoloError("%s: a view of a leaf Variable that requires grad is being used in an in-place operation (the reference "
+                              "decodes the box channels of the head maps it is given in place, yolox_loss.py:214-217): pass the head's "
+                              "outputs (non-leaf tensors), or detached maps" % who)
 
 
 class _LossFn(torch.autograd.Function):
     """One autograd node around the loss launches of a plugin: forward = stage + loss forward (fp32 loss vector out), backward =
     d(sum_i gout[i] * losses[i]) / d(maps).  The loss workspace (assignments) of a session belongs to its LAST forward: a backward that
-    finds another forward in between re-runs its own forward from the saved maps first (API edge: correctness over speed)."""
+    finds another forward in between re-runs its own forward from the raw values it set aside first (API edge: correctness over speed).
+    The maps themselves are NOT saved: YOLOXLoss decodes the caller's box channels in place afterwards, as the reference does."""
 
     @staticmethod
     def forward(ctx, plugin, hd, labels, *maps):
-        plugin._fwd(hd, maps, labels)
+        _stage(hd, maps)
+        _stage_labels(hd, labels)
+        plugin._fwd(hd)
         hd.generation = getattr(hd, "generation", 0) + 1
         ctx.plugin, ctx.hd, ctx.generation = plugin, hd, hd.generation
-        ctx.save_for_backward(labels, *maps)
+        ctx.dtypes = [m.dtype for m in maps]
+        ctx.save_for_backward(hd.raw.clone(), hd.labels.clone())
         return hd.losses.clone()
 
     @staticmethod
     def backward(ctx, gout):
         plugin, hd = ctx.plugin, ctx.hd
-        labels, maps = ctx.saved_tensors[0], ctx.saved_tensors[1:]
         if ctx.generation != hd.generation:
-            plugin._fwd(hd, maps, labels)
+            raw, labels = ctx.saved_tensors
+            hd.raw.copy_(raw)
+            hd.labels.copy_(labels)
+            plugin._fwd(hd)
             hd.generation += 1
+            ctx.generation = hd.generation
         hd.gout.zero_()
         hd.gout[:gout.numel()].copy_(gout.reshape(-1).float())
         plugin._bwd(hd)
-        return (None, None, None) + tuple(_map_grads(hd, maps))
+        return (None, None, None) + tuple(_map_grads(hd, ctx.dtypes))
 
 
 class YOLOXLoss(nn.Module):
@@ -127,9 +164,9 @@ class YOLOXLoss(nn.Module):
         self.use_l1 = use_l1
         self.__dict__['_edge'] = _EdgeCache()
 
-    # ---- the reference's contract on a caller's maps (yolox_loss.py:20-36; decode :180-228 -- the reference decodes a COPY of the
-    # maps: `permute(...).reshape(...)` of a non-contiguous view copies, so the caller's tensors are never written; neither are they here)
-    def _buffers(self, maps, M, training):
+    # ---- the reference's contract on a caller's maps (yolox_loss.py:20-36; decode :180-228, including its write-through into the box
+    # channels of the caller's maps: _decode_boxes_in_place)
+    def _edge_buffers(self, maps, M, training):
         dev = maps[0].device
         key = (tuple(tuple(m.shape) for m in maps), M, training, bool(self.use_l1), dev)
         hd = self.__dict__['_edge'].get(key)
@@ -147,9 +184,7 @@ class YOLOXLoss(nn.Module):
             self.__dict__['_edge'][key] = hd
         return hd
 
-    def _fwd(self, hd, maps, labels):
-        _stage(hd, maps)
-        _stage_labels(hd, labels)
+    def _fwd(self, hd):
         call("plyolo_yolox_loss_fwd", C.byref(hd.desc), hd.raw.data_ptr(), hd.labels.data_ptr(), hd.fg.data_ptr(), hd.mgt.data_ptr(),
              hd.miou.data_ptr(), hd.losses.data_ptr(), hd.ws.data_ptr(), hd.ws_bytes, _stream())
 
@@ -173,14 +208,18 @@ class YOLOXLoss(nn.Module):
         nch = self.n_anchors * (5 + self.num_classes)
         B = _check_maps(inputs, nch, "YOLOXLoss")
         maps = list(inputs)
+        _check_in_place_allowed(maps, "YOLOXLoss")
         if not self.training:
-            hd = self._buffers(maps, 1, False)
+            hd = self._edge_buffers(maps, 1, False)
             _stage(hd, maps)
             call("plyolo_yolox_eval_decode", C.byref(hd.desc), hd.raw.data_ptr(), hd.eval_out.data_ptr(), _stream())
+            _decode_boxes_in_place(maps, self.strides)
             return hd.eval_out.view(hd.eval_shape).clone()     # x1, y1, x2, y2, sig(obj), sig(cls) (yolox_loss.py:25-36)
         _check_labels(labels, B, "YOLOXLoss")
-        hd = self._buffers(maps, labels.shape[1], True)
-        return self.loss_dict(_LossFn.apply(self, hd, labels, *maps))
+        hd = self._edge_buffers(maps, labels.shape[1], True)
+        out = _LossFn.apply(self, hd, labels, *maps)
+        _decode_boxes_in_place(maps, self.strides)
+        return self.loss_dict(out)
 
     def emit(self, g, head_buffers, training):
         if training:
@@ -207,7 +246,7 @@ class YOLOv7Loss(nn.Module):
         self.ch = 5 + num_classes
         self.__dict__['_edge'] = _EdgeCache()
 
-    def _buffers(self, maps, M, training):
+    def _edge_buffers(self, maps, M, training):
         dev = maps[0].device
         key = (tuple(tuple(m.shape) for m in maps), M, training, dev)
         hd = self.__dict__['_edge'].get(key)
@@ -225,9 +264,7 @@ class YOLOv7Loss(nn.Module):
             self.__dict__['_edge'][key] = hd
         return hd
 
-    def _fwd(self, hd, maps, labels):
-        _stage(hd, maps)
-        _stage_labels(hd, labels)
+    def _fwd(self, hd):
         call("plyolo_yolov7_loss_fwd", C.byref(hd.desc), hd.raw.data_ptr(), hd.labels.data_ptr(), hd.losses.data_ptr(),
              hd.ws.data_ptr(), hd.ws_bytes, _stream())
 
@@ -243,14 +280,14 @@ class YOLOv7Loss(nn.Module):
             for i, m in enumerate(maps):
                 inputs[i] = m.view(B, self.na, self.ch, m.shape[2], m.shape[3]).permute(0, 1, 3, 4, 2).contiguous()
         if not self.training:
-            hd = self._buffers(maps, 1, False)
+            hd = self._edge_buffers(maps, 1, False)
             _stage(hd, maps)
             for l, ((h, w), s) in enumerate(zip(hd.sizes, hd.strides)):
                 call("plyolo_yolov7_eval_decode", hd.raw.data_ptr() + hd.lvl_row[l] * hd.nch * 4, hd.B, h, w, hd.na, hd.nc, int(s),
                      hd.anchor_t.data_ptr() + l * hd.na * 2 * 4, hd.eval_out.data_ptr(), hd.A, hd.lvl_off[l], _stream())
             return hd.eval_out.view(hd.eval_shape).clone()
         _check_labels(targets, B, "YOLOv7Loss")
-        hd = self._buffers(maps, max(int(targets.shape[1]), 1), True)
+        hd = self._edge_buffers(maps, max(int(targets.shape[1]), 1), True)
         out = _LossFn.apply(self, hd, targets, *maps)
         return {"loss": out[0:1]}      # yolov7_loss.py:150-153 returns {"loss": tensor[1]}
 

@@ -346,7 +346,7 @@ def test_ragged_channel_blocks_end_to_end(name, monkeypatch):
     assert torch.equal(res["0"], res["1"])
 
 
-RAG_WARM_LOSS_TOL, RAG_WARM_COS, RAG_WARM_STATS = 2e-2, 0.98, 5e-2
+RAG_WARM_LOSS_TOL, RAG_WARM_COS, RAG_WARM_STATS = 1e-3, 0.9995, 5e-3   # measured 2e-5 / 8e-5, 0.99997 / 0.99998, 2e-4 (yolox_tiny / yolox_m)
 
 
 @pytest.mark.parametrize("name", ["yolox_tiny", "yolox_m"])

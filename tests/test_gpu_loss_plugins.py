@@ -3,7 +3,9 @@
 OneStageD.forward itself is written: `self.loss(self.head(self.neck(self.backbone(x))), labels)` (PL_Modules/build_detection.py:46-53).
 
   * every reference-generated loss fixture (YOLOX A-G, YOLOv7 A-E) through `plugin(maps, labels)` + `backward`: losses 1e-4,
-    gradients of the maps 1e-5 / 2e-5 of the largest entry, eval decode 2e-6 -- the bars of the kernel-level tests;
+    gradients of the maps 1e-5 / 2e-5 of the largest entry, eval decode 2e-6 -- the bars of the kernel-level tests; and the reference's
+    side effects on its arguments (decoded boxes left in the caller's YOLOX maps, bit for bit against tests/golden/loss_side_effects.npz;
+    the caller's YOLOv7 list re-pointed at the [B, na, h, w, ch] views);
   * `model.loss(model.head(model.neck(model.backbone(x))), labels)` == `model(x, labels)`: losses and every parameter gradient, train
     and eval, both plugin families, fp32 parity mode and bf16;
   * a backward whose session saw another forward in between recomputes (autograd semantics, no stale assignments); refusals."""
@@ -32,12 +34,19 @@ def _leafs(g, key, n):
     return [torch.from_numpy(g["%s%d" % (key, i)]).to(hu.DEV).requires_grad_(True) for i in range(n)]
 
 
+def _nonleaf(leafs):
+    """What a head hands the loss: non-leaf tensors (YOLOXLoss decodes their box channels in place, like the reference; a leaf that
+    requires a gradient is refused with torch's own message)."""
+    return [l * 1.0 for l in leafs]
+
+
 @pytest.mark.parametrize("case", ["A", "B", "C", "D", "E", "F", "G"])
 def test_yolox_loss_plugin_call_vs_reference_fixture(case):
     g = load_golden("loss_case_" + case)
     use_l1 = case in ("F", "G")
     plugin = YOLOXLoss(int(g["num_classes"]), [int(s) for s in g["strides"]], use_l1=use_l1).train()
-    maps = _leafs(g, "map", int(g["nmaps"]))
+    leafs = _leafs(g, "map", int(g["nmaps"]))
+    maps = _nonleaf(leafs)
     before = [m.detach().clone() for m in maps]
     labels = torch.from_numpy(g["labels"]).to(hu.DEV)
     out = plugin(maps, labels)
@@ -50,34 +59,51 @@ def test_yolox_loss_plugin_call_vs_reference_fixture(case):
     assert abs(float(out["proportion"]) - float(g["proportion"])) < 1e-5 and not out["proportion"].requires_grad
     out["loss"].backward()
     torch.cuda.synchronize()
-    for i, m in enumerate(maps):
+    side = load_golden("loss_side_effects")
+    for i, (l, m) in enumerate(zip(leafs, maps)):
         ref = g["grad%d" % i]
-        assert float(np.abs(m.grad.cpu().numpy() - ref).max()) <= 1e-5 * max(1e-3, float(np.abs(ref).max())), i
-        assert torch.equal(m.detach(), before[i])        # the caller's maps are not written (the reference decodes a copy)
-    ev = plugin.eval()([m.detach() for m in maps], labels)
+        assert float(np.abs(l.grad.cpu().numpy() - ref).max()) <= 1e-5 * max(1e-3, float(np.abs(ref).max())), i
+        # the reference's decode writes THROUGH a view into channels 0..3 of the maps it is handed (yolox_loss.py:204-219): after the call
+        # they hold (cx, cy, w, h) in pixels, the other channels are untouched
+        assert torch.equal(m.detach()[:, 4:], before[i][:, 4:]) and not torch.equal(m.detach()[:, :4], before[i][:, :4])
+        if case in ("A", "D"):
+            assert torch.equal(m.detach()[:, :4].cpu(), torch.from_numpy(side["%s/boxes_after%d" % (case, i)])), i
+    raw = [b.clone() for b in before]
+    ev = plugin.eval()(raw, labels)
     assert tuple(ev.shape) == tuple(g["eval_decode"].shape) and not ev.requires_grad
     np.testing.assert_allclose(ev.cpu().numpy(), g["eval_decode"], rtol=2e-6, atol=2e-5)
+    for m, r in zip(maps, raw):                               # eval decodes the caller's boxes in place too
+        assert torch.equal(m.detach(), r)
+    with pytest.raises(PlyoloError, match="leaf Variable"):   # torch's refusal of the reference's in-place decode on such a tensor
+        plugin.train()(leafs, labels)
 
 
 def test_yolox_loss_plugin_weighted_terms_and_stale_session():
     """Upstream gradients of the single terms (gout of the loss vector), and a backward after ANOTHER forward of the same shapes: the
-    node re-runs its own forward instead of back-propagating through the other call's assignments."""
-    ga, gb = load_golden("loss_case_A"), load_golden("loss_case_B")
-    assert ga["map0"].shape == gb["map0"].shape and ga["labels"].shape == gb["labels"].shape
+    node re-runs its own forward instead of back-propagating through the other call's assignments.  Second call: the batch of case A
+    rolled by one image (same shapes, other assignments per slot; its gradients are the golden ones rolled the same way)."""
+    ga = load_golden("loss_case_A")
     plugin = YOLOXLoss(int(ga["num_classes"]), [int(s) for s in ga["strides"]]).train()
-    ma, mb = _leafs(ga, "map", 3), _leafs(gb, "map", 3)
-    oa = plugin(ma, torch.from_numpy(ga["labels"]).to(hu.DEV))
-    ob = plugin(mb, torch.from_numpy(gb["labels"]).to(hu.DEV))      # same buffers, other assignments
-    oa["loss"].backward()                                               # stale: recomputed
-    ob["loss"].backward()                                               # stale again (a's recompute ran in between)
+    la = torch.from_numpy(ga["labels"]).to(hu.DEV)
+    ma = _leafs(ga, "map", 3)
+    mb = [torch.roll(m.detach(), 1, 0).clone().requires_grad_(True) for m in ma]
+    lb = torch.roll(la, 1, 0).contiguous()
+    oa = plugin(_nonleaf(ma), la)
+    ob = plugin(_nonleaf(mb), lb)               # same buffers, other assignments
+    # the loss normalises by the batch's foreground count and sums over images: rolling the batch changes nothing but the order
+    assert abs(float(oa["loss"].detach()) - float(ob["loss"].detach())) <= 1e-5 * float(oa["loss"].detach())
+    oa["loss"].backward()                       # stale: recomputed from the raw values set aside
+    ob["loss"].backward()                       # stale again (a's recompute ran in between)
     torch.cuda.synchronize()
-    for maps, g in ((ma, ga), (mb, gb)):
-        for i, m in enumerate(maps):
-            ref = g["grad%d" % i]
-            assert float(np.abs(m.grad.cpu().numpy() - ref).max()) <= 1e-5 * max(1e-3, float(np.abs(ref).max())), i
-    # loss = 5 iou + obj + cls (yolox_loss.py:150-158): the three terms back-propagated one by one add up to the gradient of `loss`
+    for i, (a, b) in enumerate(zip(ma, mb)):
+        ref = ga["grad%d" % i]
+        tol = 1e-5 * max(1e-3, float(np.abs(ref).max()))
+        assert float(np.abs(a.grad.cpu().numpy() - ref).max()) <= tol, i
+        assert float(np.abs(b.grad.cpu().numpy() - np.roll(ref, 1, 0)).max()) <= tol, i
+    # loss = 5 iou + obj + cls (yolox_loss.py:150-158): the three terms back-propagated through their own slots of the loss vector add up
+    # to the gradient of `loss`
     m2 = _leafs(ga, "map", 3)
-    o2 = plugin(m2, torch.from_numpy(ga["labels"]).to(hu.DEV))
+    o2 = plugin(_nonleaf(m2), la)
     (5.0 * o2["loss_iou"] + o2["loss_obj"] + o2["loss_cls"]).backward()
     torch.cuda.synchronize()
     for a, b in zip(ma, m2):
@@ -188,7 +214,7 @@ def test_loss_plugin_refusals():
         plugin(dm, None)                                                           # training needs labels
     # an image without any label row trains (no foreground): finite loss, gradient of the objectness only
     leafs = [m.clone().requires_grad_(True) for m in dm]
-    out = plugin(leafs, torch.zeros(1, 0, 5, device=hu.DEV))
+    out = plugin(_nonleaf(leafs), torch.zeros(1, 0, 5, device=hu.DEV))
     out["loss"].backward()
     torch.cuda.synchronize()
     assert np.isfinite(float(out["loss"].detach())) and all(torch.isfinite(m.grad).all() for m in leafs)

@@ -201,6 +201,30 @@ def gen_loss_cases(only=None):
         save("loss_case_" + name, d)
 
 
+def gen_loss_side_effects():
+    """What YOLOXLoss.__call__ leaves in the CALLER's head maps (yolox_loss.py:204-219): `permute(...).reshape(...)` of an NCHW map with one
+    anchor is a view, so the decode writes the boxes (cx, cy, w, h in pixels) through into channels 0..3 -- in training and in eval mode.
+    Inputs: the maps of the committed loss cases A (three square levels) and D (one NON-square level: the grid quirk).  Stored: the box
+    channels after the call; the generator asserts that the other channels are untouched and that train and eval leave the same."""
+    out = {}
+    for case in ("A", "D"):
+        g = dict(np.load(os.path.join(OUT, "loss_case_%s.npz" % case)))
+        maps = [torch.from_numpy(g["map%d" % i]) for i in range(int(g["nmaps"]))]
+        labels, strides, nc = torch.from_numpy(g["labels"]), [int(v) for v in g["strides"]], int(g["num_classes"])
+        fn = YOLOXLoss(nc, strides)
+        fn.train()
+        tr = [m.clone().requires_grad_(True) * 1.0 for m in maps]
+        fn(tr, labels)
+        fn.eval()
+        ev = [m.clone() for m in maps]
+        fn(ev, labels)
+        for i, (m, a, b) in enumerate(zip(maps, tr, ev)):
+            a = a.detach()
+            assert torch.equal(a, b) and torch.equal(a[:, 4:], m[:, 4:]) and not torch.equal(a[:, :4], m[:, :4])
+            out["%s/boxes_after%d" % (case, i)] = a[:, :4].contiguous()
+    save("loss_side_effects", out)
+
+
 def gen_blocks():
     torch.manual_seed(7)
     d = {}
@@ -1052,6 +1076,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "repconv":
         gen_repconv()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "loss_side":
+        gen_loss_side_effects()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "loss_l1":
         gen_loss_cases(only=("F", "G"))
         sys.exit(0)
@@ -1062,6 +1089,7 @@ if __name__ == "__main__":
     gen_repconv()
     gen_network_v7()
     gen_loss_cases()
+    gen_loss_side_effects()
     gen_blocks()
     gen_network()
     gen_network_warm()

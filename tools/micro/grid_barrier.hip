@@ -28,6 +28,37 @@ __device__ __forceinline__ bool grid_barrier(unsigned* counter, unsigned target,
   return ok;
 }
 
+// round 6: TWO-LEVEL barrier.  The flat barrier's cost is the G same-address atomics, ~30 ns each (7.9 us at G = 256).  Here the
+// workgroups of one XCD (blockIdx % 8) add to their group's counter (own 128-byte line: 8 counters take G/8 atomics each, in
+// parallel), the LAST arriver of a group adds to the global counter (8 atomics), everybody polls the global counter.
+__device__ __forceinline__ bool grid_barrier2(unsigned* cnt, unsigned epoch, unsigned* err) {
+  __syncthreads();
+  bool ok = true;
+  if (threadIdx.x == 0) {
+    const unsigned G = gridDim.x, grp = blockIdx.x & 7u, ngrp = G < 8u ? G : 8u;
+    const unsigned gsize = (G - grp + 7u) / 8u;
+    const unsigned old = __hip_atomic_fetch_add(cnt + 32u * (1u + grp), 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + 1u == epoch * gsize) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    int spins = 0;
+    const int sl = g_sleep;
+    while (__hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < epoch * ngrp) {
+      if (sl) __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1 << 22)) { *err = 1u; ok = false; break; }
+    }
+  }
+  __syncthreads();
+  return ok;
+}
+
+__global__ __launch_bounds__(256) void k_barriers2(unsigned* cnt, int K, unsigned* err, float* sink) {
+  float v = threadIdx.x;
+  for (int k = 0; k < K; ++k) {
+    v = v * 1.0001f + 0.5f;
+    grid_barrier2(cnt, (unsigned)(k + 1), err);
+  }
+  if (v == 12345.f) sink[0] = v;
+}
+
 __global__ __launch_bounds__(256) void k_barriers(unsigned* counter, int K, unsigned* err, float* sink) {
   float v = threadIdx.x;
   for (int k = 0; k < K; ++k) {
@@ -69,6 +100,7 @@ int main(int argc, char** argv) {
   CK(hipMemcpyToSymbol(HIP_SYMBOL(g_sleep), &sleep_on, sizeof(int)));
   printf("spin %s s_sleep\n", sleep_on ? "with" : "without");
   unsigned *counter, *err; double* slots; float *sink, *out;
+  unsigned* cnt2; CK(hipMalloc(&cnt2, 9 * 32 * 4));
   CK(hipMalloc(&counter, 4)); CK(hipMalloc(&err, 4)); CK(hipMalloc(&slots, 8 * 2 * C * 8)); CK(hipMalloc(&sink, 4)); CK(hipMalloc(&out, 2 * C * 4));
   CK(hipMemset(err, 0, 4));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -88,6 +120,21 @@ int main(int argc, char** argv) {
       if (K == 0) t0 = best;
       printf("G %3d  K %d barriers: %.1f us%s\n", G, K, best * 1e3, K ? "" : "  (empty launch)");
       if (K) printf("        per barrier %.2f us\n", (best - t0) * 1e3 / K);
+    }
+    {   // two-level barrier, same protocol
+      float t02 = 0.f;
+      for (int K : {0, 1, 2, 4, 8}) {
+        float best = 1e9;
+        for (int rep = 0; rep < 7; ++rep) {
+          CK(hipMemsetAsync(cnt2, 0, 9 * 32 * 4, 0));
+          CK(hipEventRecord(e0));
+          hipLaunchKernelGGL(k_barriers2, dim3(G), dim3(256), 0, 0, cnt2, K, err, sink);
+          CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+          float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = ms < best ? ms : best;
+        }
+        if (K == 0) t02 = best;
+        if (K) printf("G %3d  two-level, K %d barriers: %.1f us, per barrier %.2f us\n", G, K, best * 1e3, (best - t02) * 1e3 / K);
+      }
     }
     // statistics pattern, fused vs two launches
     float bf = 1e9, bs = 1e9;
