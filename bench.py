@@ -488,6 +488,11 @@ def main():
             "value": value, "unit": "images/sec",
             "n_gpus": world, "rccl_world_size": (dist.get_world_size() if dist is not None and not share else 1), "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            # what "bf16" means for the headline (round-5 review, weak 1): the contract's 1e-4 on the losses is met by the fp32 parity
+            # mode (same graph, plain-FMA kernels); the benchmarked path is asserted at 2e-3 on warm weights (parity_check.warm_fixture)
+            "numerics": "bf16 storage + bf16 MFMA with fp32 accumulation, BatchNorm statistics in fp64, BN / SiLU / loss arithmetic fp32; losses "
+                        "within 2e-3 of the reference's fp32 step on warm weights (measured ~3e-4), all-parameter gradient cosine >= 0.9995; "
+                        "the fp32 parity mode (compute_dtype='fp32') meets the 1e-4 loss contract",
             "config": {"workload": "%s %dx%d, batch %d per GPU, 30 GT/img, fwd + SimOTA/loss + bwd%s" % (
                 args.model, args.size, args.size, args.batch, " + RCCL grad all-reduce" if world > 1 else ""),
                 "global_batch": world * args.batch, "parallelism": "dp%d" % world,

@@ -66,8 +66,10 @@ def test_yolox_loss_plugin_call_vs_reference_fixture(case):
         # the reference's decode writes THROUGH a view into channels 0..3 of the maps it is handed (yolox_loss.py:204-219): after the call
         # they hold (cx, cy, w, h) in pixels, the other channels are untouched
         assert torch.equal(m.detach()[:, 4:], before[i][:, 4:]) and not torch.equal(m.detach()[:, :4], before[i][:, :4])
-        if case in ("A", "D"):
-            assert torch.equal(m.detach()[:, :4].cpu(), torch.from_numpy(side["%s/boxes_after%d" % (case, i)])), i
+        if case in ("A", "D"):     # the fixture is the reference run on the CPU: centres exact, extents to the ulp of the device's exp
+            want = side["%s/boxes_after%d" % (case, i)]
+            assert np.array_equal(m.detach()[:, :2].cpu().numpy(), want[:, :2]), i
+            np.testing.assert_allclose(m.detach()[:, 2:4].cpu().numpy(), want[:, 2:4], rtol=1e-6, atol=0)
     raw = [b.clone() for b in before]
     ev = plugin.eval()(raw, labels)
     assert tuple(ev.shape) == tuple(g["eval_decode"].shape) and not ev.requires_grad

@@ -66,6 +66,54 @@ def test_fp32_train_step_vs_golden():
             np.testing.assert_allclose(sd[k[12:]].cpu().numpy(), v, rtol=1e-4, atol=1e-5, err_msg=k)
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_train_step_and_eval_on_a_rectangular_image_vs_golden(dtype):
+    """A 64 x 96 batch through the whole detector (head maps 8x12 / 4x6 / 2x3; ragged tiles in every convolution, the reference's non-square
+    grid quirk in decode / SimOTA / eval decode, yolox_loss.py:198-200) against the reference itself (tests/golden/network_yolox_rect.npz,
+    the weights of network_yolox_test.npz): fp32 parity mode at the fixture bars (losses 1e-4, gradients 2e-4, running statistics, eval
+    output); bf16: loss within 3e-2 (random-initialised toy net), finite gradients."""
+    g = load_golden("network_yolox_rect")
+    _, model = _golden_model(dtype)
+    model.train()
+    x, labels = torch.from_numpy(g["x"]).to(hu.DEV), torch.from_numpy(g["labels"]).to(hu.DEV)
+    maps = model(x)
+    assert [tuple(m.shape[2:]) for m in maps] == [(8, 12), (4, 6), (2, 3)]
+    if dtype == "fp32":
+        for i, m in enumerate(maps):
+            np.testing.assert_allclose(m.detach().cpu().numpy(), g["maps_train%d" % i], rtol=1e-3, atol=2e-4)
+    _, model = _golden_model(dtype)
+    model.train()
+    out = model(x, labels)
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    if dtype == "bf16":
+        rel = abs(float(out["loss"]) - float(g["out/loss"])) / float(g["out/loss"])
+        print("rectangular image, bf16 loss %.5f vs %.5f (rel %.3g)" % (float(out["loss"]), float(g["out/loss"]), rel))
+        assert rel <= 3e-2 and all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+        return
+    for k in ("loss", "loss_iou", "loss_obj", "loss_cls"):
+        assert abs(float(out[k]) - float(g["out/" + k])) <= 1e-4 * max(1.0, abs(float(g["out/" + k]))), k
+    assert abs(float(out["proportion"]) - float(g["out/proportion"])) < 1e-5
+    worst = 0.0
+    for name, p in model.named_parameters():
+        if "grad/" + name not in g:
+            assert p.grad is None, name
+            continue
+        ref = g["grad/" + name]
+        err = float(np.abs(p.grad.cpu().numpy() - ref).max()) / max(1e-3, float(np.abs(ref).max()))
+        worst = max(worst, err)
+        assert err <= 2e-4, (name, err)
+    print("rectangular image, fp32: worst relative gradient error %.3g" % worst)
+    sd = model.state_dict()
+    for k, v in g.items():
+        if k.startswith("state_after/"):
+            np.testing.assert_allclose(sd[k[12:]].cpu().numpy(), v, rtol=1e-4, atol=1e-5, err_msg=k)
+    model.eval()
+    with torch.no_grad():
+        ev = model(x, labels)
+    np.testing.assert_allclose(ev.cpu().numpy(), g["eval_out"], rtol=1e-3, atol=2e-3)
+
+
 def test_fp32_maps_and_eval_vs_golden():
     g, model = _golden_model("fp32")
     x = torch.from_numpy(g["x"]).to(hu.DEV)

@@ -98,6 +98,39 @@ def test_network_train_step():
             np.testing.assert_allclose(state[k[12:]].detach().numpy(), v, rtol=1e-5, atol=1e-6, err_msg=k)
 
 
+def test_network_train_step_and_eval_on_a_rectangular_image():
+    """64 x 96 input (head maps 8x12 / 4x6 / 2x3): the reference's non-square grid quirk (yolox_loss.py:198-200) inside a whole training
+    step -- tests/golden/network_yolox_rect.npz = the reference itself on the weights of network_yolox_test.npz (tools/gen_golden.py rect)."""
+    g = load_golden("network_yolox_rect")
+    cfg = _cfg()
+    C = int(g["num_classes"])
+    state = _state(load_golden("network_yolox_test"))
+    x, labels = torch.from_numpy(g["x"]), torch.from_numpy(g["labels"])
+    assert x.shape[2] != x.shape[3]
+    maps = detector.forward({k: v.clone() for k, v in state.items()}, cfg, C, x, None, training=True)
+    for i, m in enumerate(maps):
+        assert m.shape[2] != m.shape[3]
+        np.testing.assert_allclose(m.detach().numpy(), g["maps_train%d" % i], rtol=1e-4, atol=1e-4)
+    out, grads = detector.train_step_grads(state, cfg, C, x, labels)
+    for k in ("loss", "loss_iou", "loss_obj", "loss_cls"):
+        assert abs(float(out[k].detach()) - float(g["out/" + k])) < 1e-5 * max(1, abs(float(g["out/" + k]))), k
+    assert abs(out["proportion"] - float(g["out/proportion"])) < 1e-6
+    n = 0
+    for k, v in g.items():
+        if k.startswith("grad/"):
+            got = grads[k[5:]].numpy()
+            scale = max(1e-3, float(np.abs(v).max()))
+            assert float(np.abs(got - v).max()) <= 2e-4 * scale, (k, float(np.abs(got - v).max()), scale)
+            n += 1
+    assert n > 100
+    for k, v in g.items():
+        if k.startswith("state_after/"):
+            np.testing.assert_allclose(state[k[12:]].detach().numpy(), v, rtol=1e-5, atol=1e-6, err_msg=k)
+    with torch.no_grad():
+        ev = detector.forward(state, cfg, C, x, labels, training=False)
+    np.testing.assert_allclose(ev.numpy(), g["eval_out"], rtol=1e-4, atol=1e-3)
+
+
 def test_network_eval():
     g = load_golden("network_yolox_test")
     cfg = _cfg()

@@ -343,6 +343,55 @@ def gen_network():
     save("harness_trajectory", h)
 
 
+def gen_network_rect():
+    """The toy YOLOX on a RECTANGULAR image (64 rows x 96 columns: head maps 8x12 / 4x6 / 2x3), i.e. with the reference's grid quirk
+    (yolox_loss.py:198-200: meshgrid(arange(h), arange(w), indexing='xy') re-viewed as (h, w)) inside a whole training step: raw maps,
+    losses, every gradient, running statistics, eval output.  Same weights and perturbation as gen_network()."""
+    cfg = load_cfg("yolox_test")
+    C = 3
+    torch.manual_seed(96)
+    model = build_model(cfg, C)
+    g = torch.Generator().manual_seed(5)
+    for n, p in model.named_parameters():
+        if n.endswith(".norm.weight"):
+            p.data = 0.5 + torch.rand(p.shape, generator=g)
+        if n.endswith(".norm.bias"):
+            p.data = torch.rand(p.shape, generator=g) - 0.5
+    gen = torch.Generator().manual_seed(4321)
+    x = torch.rand(2, 3, 64, 96, generator=gen) * 255
+    labels = torch.zeros(2, 8, 5)
+    labels[0, :3] = torch.tensor([[0, 20.0, 24.0, 18.0, 22.0], [2, 70.0, 40.0, 30.0, 26.0], [1, 84.0, 14.0, 16.0, 12.0]])
+    labels[1, :2] = torch.tensor([[1, 48.0, 30.0, 40.0, 36.0], [0, 12.0, 50.0, 14.0, 18.0]])
+    d = dict(x=x, labels=labels, num_classes=C)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    # (the state is NOT stored: it is the one of network_yolox_test.npz, asserted here)
+    ref = dict(np.load(os.path.join(OUT, "network_yolox_test.npz")))
+    assert all(np.array_equal(ref["state/" + k], v.numpy()) for k, v in state.items()) and len(state) == sum(1 for k in ref if k.startswith("state/"))
+    model.train()
+    _calls.clear()
+    for i, m in enumerate(model(x)):
+        d["maps_train%d" % i] = m.detach().clone()
+    model.load_state_dict(state)
+    model.zero_grad()
+    out = model(x, labels)
+    out["loss"].backward()
+    for k in ("loss", "loss_iou", "loss_obj", "loss_cls"):
+        d["out/" + k] = out[k].detach()
+    d["out/proportion"] = float(out["proportion"])
+    d["boundary_gap"] = min([c["gap"] for c in _calls] + [float("inf")])
+    for n, p in model.named_parameters():
+        if p.grad is not None:
+            d["grad/" + n] = p.grad.clone()
+    for k, v in model.state_dict().items():
+        if "running" in k:
+            d["state_after/" + k] = v.clone()
+    model.eval()
+    with torch.no_grad():
+        d["eval_out"] = model(x, labels).clone()
+    print("rectangular network fixture: loss=%.6f gap=%.3g" % (float(out["loss"]), d["boundary_gap"]))
+    save("network_yolox_rect", d)
+
+
 def gen_schedule():
     d = {}
     for i, (warm, T) in enumerate([(0.1 * 100, 100), (0.0 + 5, 37), (300, 3000)]):
@@ -1076,6 +1125,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "repconv":
         gen_repconv()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "rect":
+        gen_network_rect()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "loss_side":
         gen_loss_side_effects()
         sys.exit(0)
@@ -1092,6 +1144,7 @@ if __name__ == "__main__":
     gen_loss_side_effects()
     gen_blocks()
     gen_network()
+    gen_network_rect()
     gen_network_warm()
     gen_network_e()
     gen_format_outputs()
