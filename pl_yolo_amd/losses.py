@@ -101,7 +101,7 @@ def _decode_boxes_in_place(maps, strides):
     (outside autograd: the returned gradient is the one with respect to the raw values, which is where the reference's CopySlices
     node sends it too).  Grid: the reference builds it with meshgrid(arange(h), arange(w), indexing='xy') and re-views the (w, h, 2) stack
     as (h, w, 2) -- cell k = gy*w + gx gets (k mod h, k div h), which is (gx, gy) on square maps only (the non-square quirk the loss kernels
-    reproduce as well, loss fixture E)."""
+    reproduce as well, loss fixture D)."""
     with torch.no_grad():
         for m, s in zip(maps, strides):
             h, w = m.shape[2], m.shape[3]
