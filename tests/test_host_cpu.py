@@ -116,3 +116,21 @@ def test_repconv_module_keys_match_reference_fixture():
         want = {k[len(tag) + 7:]: v.shape for k, v in g.items() if k.startswith(tag + "/state/")}
         got = {k: tuple(v.shape) for k, v in RepConv(c1, c2, 3, 1).state_dict().items()}
         assert got == {k: tuple(v) for k, v in want.items()}
+
+
+def test_model_summary_counts_match_the_reference_tables(capsys):
+    """utils/flops.py:5-9 (thop) counts 0 operations on a model whose leaf modules never run; pl_yolo_amd.utils.model_summary prints the
+    reference's line from a CPU dry trace of the launch graph.  Numbers: BASELINE.md section 2 (counted from the reference's own modules;
+    the upstream YOLOX tables: 26.8 / 155.6 GFLOPs)."""
+    from pl_yolo_amd.utils import conv_macs, model_summary
+    want = {("yolox", "yolox_s", 640): (26.69, 8.971), ("yolox", "yolox_l", 640): (155.29, 54.226), ("yolov7", "yolov7", 640): (112.48, 47.698),
+            ("yolox", "yolox_nano", 416): (2.91, 2.258)}
+    for (family, name, size), (gf, mp) in want.items():
+        with open(os.path.join(ROOT, "configs", "model", family, name + ".yaml")) as f:
+            model = pl_yolo_amd.build_model(yaml.safe_load(f), 80)
+        assert abs(2.0 * conv_macs(model, size, size) / 1e9 - gf) < 0.006, name
+        assert abs(sum(p.numel() for p in model.parameters()) / 1e6 - mp) < 0.0006, name
+    assert model_summary(model, (416, 416), None) is None
+    assert capsys.readouterr().out.strip() == "------- params: 2.258M ------- flops: 2.913G"
+    with pytest.raises(_lib.PlyoloError, match="multiple of 32"):
+        conv_macs(model, 400, 416)
